@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- body-pair interactions/s of the all-pairs n-body step on 1..8 MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched as
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`` (one rank per
+GPU).  W untimed warm-up steps, then EXACTLY K steps timed between barrier + device sync on both
+sides, MAX over ranks, rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): 65 536 bodies, fp32, seeded two-shell state (seed 1),
+dt 0.1, damping 1, soft^2 25, mass 70000/N (the parity regime; timing does not depend on mass).
+A "step" is one Compute::Simulate over all bodies.  Inputs are resident in HBM when the timed
+region starts.  metric = N^2 ordered pairs x steps / wall seconds, whole job.
+
+roofline: the force kernel is bound by the fp32 VECTOR ALU, not HBM and not MFMA (arithmetic
+intensity ~23 000 flop/B); `peak` is CUs x clock x 256 flop/clk = 157.3 TFLOP/s, which is also the
+dense f32 MFMA peak of MI355X_MICROARCH.md.  `achieved` = 20 flop per ordered pair
+x the pairs one launch processes / the force kernel's mean launch duration, measured live with
+HIP events recorded on the compute stream around every force launch of the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+FLOP_PER_PAIR = 20          # op count of nBodyGravityCS.hlsl:44-57, rsqrt = 1 flop
+HBM_BYTES_PER_BODY = 56     # 16+12 read, 16+12 written
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--bodies", type=int, default=65536)
+    ap.add_argument("--mode", choices=["all_pairs", "central_well"], default="all_pairs")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--plan", default="", help="kernel,bodies_per_lane,waves,sb,fused e.g. lds,4,8,1,1")
+    ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl")
+    ap.add_argument("--no-timers", action="store_true", help="disable the per-step event timers")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--graph", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(n, seed, target_seconds):
+    """The CPU restatement (oracle, kind 'port': the reference has no CPU path) timed
+    on the host cores of this box on a bounded sample of the same workload: bodies [0, k) of
+    the N-body state against all N bodies, one step, all host threads."""
+    from oracle import Oracle, Params
+    o = Oracle()
+    cores = o.hardware_threads()
+    pos, vel = o.initial_state(n, seed=seed)
+    prm = Params(mass=70000.0 / n)
+    k = min(n, 64 * cores)
+    t0 = time.perf_counter(); o.step_slice(pos, vel, 0, k, params=prm); t = time.perf_counter() - t0
+    rate = k * n / t
+    k = int(min(n, max(k, rate * target_seconds / n))) // 16 * 16
+    t0 = time.perf_counter(); o.step_slice(pos, vel, 0, k, params=prm); t = time.perf_counter() - t0
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    return {"value": k * n / t, "unit": "body-pair interactions/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (C, fp32, exact HLSL op order) advancing bodies [0,{k}) of {n} against all {n}, "
+                      f"1 step, {cores} threads, {t:.1f} s", "cpu": model}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    dist = None
+    torch = None
+    if world > 1:
+        import torch            # first: its HIP runtime is then the one libmapn binds to
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import mapn
+    from mapn.compute import device_info
+
+    n = a.bodies
+    mode = mapn.FORCE_ALL_PAIRS if a.mode == "all_pairs" else mapn.FORCE_CENTRAL_WELL
+    flags = mapn.FLAG_USE_GRAPH if a.graph else 0
+    c = mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed,
+                     rank=rank, world_size=world, flags=flags)
+    info = device_info(local_rank)
+    transport = "none"
+    gather_fn = None
+    if world > 1:
+        transport = a.transport
+        if transport == "rccl":
+            try:
+                c.comm_init_torch()
+            except Exception as e:     # RCCL-in-library unavailable: use torch's RCCL instead, loudly
+                print(f"[bench rank {rank}] native RCCL transport failed ({e}); falling back to torch.distributed all-gather",
+                      file=sys.stderr, flush=True)
+                transport = "torch"
+        if transport == "torch":
+            c.set_external_gather(True)
+            gather_fn = make_torch_gather(c, torch, dist, n, rank, world)
+    if a.plan:
+        kname, k, w, sb, fused = a.plan.split(",")
+        c.set_force_plan({"lds": mapn.KERNEL_LDS, "sgpr": mapn.KERNEL_SCALAR}[kname], int(k), int(w), int(sb), bool(int(fused)))
+    if a.no_timers:
+        c.set_timers(False)
+
+    def step():
+        fence = c.GetFenceValue()             # Particles.cpp:446-448
+        c.Simulate(n, fence)
+        if gather_fn:
+            gather_fn()
+
+    def sync():
+        c.WaitForGpu()
+        if torch is not None:
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    c.kernel_stats(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st = c.kernel_stats()
+    first, count = c.shard_range()
+    if rank == 0:
+        pairs_per_step = float(n) * float(n) if a.mode == "all_pairs" else float(n)
+        value = pairs_per_step * a.steps / elapsed
+        out = {
+            "metric": "body-pair interactions/s" if a.mode == "all_pairs" else "bodies/s",
+            "value": value,
+            "unit": "interactions/s" if a.mode == "all_pairs" else "bodies/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{n} bodies, all-pairs softened gravity + kick-drift step, fp32 (BASELINE configs[1])"
+                       if a.mode == "all_pairs" else f"{n} bodies, central-well step as shipped (nBodyGravityCS.hlsl:86-109)",
+                       "bodies": n, "mode": a.mode, "parallelism": f"bodies sharded x{world}" if world > 1 else "1 GPU",
+                       "transport": transport, "seed": a.seed, "mass": "70000/N", "device": info.name.decode(),
+                       "kernel": st.kernel_name.decode(), "bodies_per_lane": st.bodies_per_lane, "j_splits": st.j_splits,
+                       "grid": [st.grid_x, st.grid_y], "block": st.block_x, "fused_integrator": bool(st.fused)},
+        }
+        if a.mode == "all_pairs":
+            peak = info.peak_fp32_flops / 1e12
+            if st.launches and st.avg_seconds > 0:
+                pairs_per_launch = float(count) * float(n)
+                ach = FLOP_PER_PAIR * pairs_per_launch / st.avg_seconds / 1e12
+                out["roofline"] = {"bound": "valu_fp32", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                   "traffic": None, "kernel": st.kernel_name.decode(), "launches_timed": int(st.launches),
+                                   "avg_launch_ms": st.avg_seconds * 1e3, "flop_per_pair": FLOP_PER_PAIR,
+                                   "pairs_per_launch": pairs_per_launch,
+                                   "algorithmic_hbm_GBps": HBM_BYTES_PER_BODY * count / st.avg_seconds / 1e9,
+                                   "note": "peak = CUs x clock x 256 flop/clk (fp32 vector = dense f32 MFMA peak, 157.3 TF)"}
+            else:
+                out["roofline"] = None
+        else:
+            if st.launches == 0:
+                pass
+            out["roofline"] = {"bound": "hbm", "achieved": HBM_BYTES_PER_BODY * n * a.steps / elapsed / 1e9, "peak": 8000.0,
+                               "unit": "GB/s", "frac": HBM_BYTES_PER_BODY * n * a.steps / elapsed / 8e12, "traffic": None}
+        if world == 1 and not a.no_cpu_baseline and a.mode == "all_pairs":
+            out["cpu_baseline"] = cpu_baseline(n, a.seed, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    c.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def make_torch_gather(c, torch, dist, n, rank, world):
+    """Fallback transport: torch.distributed (RCCL) all-gather on zero-copy views of the
+    library's position buffers."""
+    h = c.GetSharedHandles(consumer_fence=False)
+
+    class _View:
+        def __init__(self, ptr):
+            self.__cuda_array_interface__ = {"shape": (n, 4), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+    bufs = [torch.as_tensor(_View(h.positions[i]), device="cuda") for i in range(2)]
+    count = n // world
+
+    def gather():
+        c.WaitForGpu()
+        w = 1 - c.buffer_index                     # buffer the step just wrote
+        dist.all_gather_into_tensor(bufs[w], bufs[w][rank * count:(rank + 1) * count].clone())
+        torch.cuda.synchronize()
+
+    return gather
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,255 @@
+/*
+ * mapn.h -- C ABI of the MI355X-native n-body compute step ("libmapn.so").
+ *
+ * Drop-in boundary: the public surface of the reference's `class Compute`
+ * (reference/Particles/Compute.h:33-78 + AdapterShared.h:51-60), whose only caller is
+ * `class Particles` (Particles.cpp) from one host thread.  Each entry point below names the
+ * reference member it replaces.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - every function returning `int` returns MAPN_OK (0) or a negative mapn_status; the
+ *     reference throws HrException / asserts instead (DXSampleHelper.h:29-46) -- the C++ shim
+ *     compat/Compute.hpp turns a non-zero status back into std::runtime_error.
+ *   - mapn_last_error() returns a thread-local description of the last failure.
+ *   - a context is NOT thread-safe (the reference has no locks; all calls come from the UI
+ *     thread, Main-Particles.cpp:76-90).
+ *   - state layout at the ABI (kept verbatim from the reference):
+ *       positions  float4[N], 16-byte stride, w = |accel| of the last step
+ *                  (Render.h:85-88, nBodyGravityCS.hlsl:67-70,107)
+ *       velocities float3[N], packed 12-byte stride (Compute.h:66-69, nBodyGravityCS.hlsl:72-75)
+ *     two ping-pong buffers of each (Compute.h:107-108); a step reads buffer 1-index and
+ *     writes buffer index, then flips (Compute.cpp:1022,1034-1035,1003; hlsl:77-81).
+ */
+#ifndef MAPN_H
+#define MAPN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAPN_ABI_VERSION 1
+
+typedef struct mapn_ctx mapn_ctx;
+
+typedef enum mapn_status {
+    MAPN_OK = 0,
+    MAPN_ERR_INVALID_ARGUMENT = -1,
+    MAPN_ERR_HIP = -2,          /* a HIP runtime call failed; text in mapn_last_error() */
+    MAPN_ERR_NO_DEVICE = -3,    /* no usable gfx950 device: there is NO CPU fallback */
+    MAPN_ERR_COMM = -4,         /* RCCL missing or a collective failed */
+    MAPN_ERR_STATE = -5         /* call not valid in the context's current mode */
+} mapn_status;
+
+typedef enum mapn_force_mode {
+    MAPN_FORCE_ALL_PAIRS = 0,   /* sum of bodyBodyInteraction over all bodies, hlsl:44-57 */
+    MAPN_FORCE_CENTRAL_WELL = 1 /* CSMain exactly as shipped, hlsl:92-101 */
+} mapn_force_mode;
+
+/* Kernel selection for the all-pairs force (MAPN_KERNEL_AUTO picks per N and device). */
+typedef enum mapn_kernel {
+    MAPN_KERNEL_AUTO = 0,
+    MAPN_KERNEL_LDS = 1,        /* j-tiles staged through LDS, broadcast ds_read */
+    MAPN_KERNEL_SCALAR = 2,     /* j-bodies through the scalar cache into SGPRs */
+    MAPN_KERNEL_MFMA = 3        /* accumulation recast on v_mfma_f32_4x4x1 (A/B experiment) */
+} mapn_kernel;
+
+#define MAPN_FLAG_USE_GRAPH   0x1u  /* replay the step from a captured hipGraph */
+#define MAPN_FLAG_NO_INIT     0x2u  /* leave state zeroed; caller will mapn_upload_state() */
+
+/*
+ * Everything `Compute::Compute(numParticles, adapter, useIntelExt, old)` (Compute.h:36-39)
+ * takes, plus what the reference hard-codes: the cbuffer values (Compute.cpp:542-546), the
+ * shader constants (nBodyGravityCS.hlsl:37-38) and the initial-state constants
+ * (defines.h:39,42).  mapn_config_default() fills in exactly those values.
+ */
+typedef struct mapn_config {
+    uint32_t struct_size;        /* sizeof(mapn_config), for ABI growth */
+    uint32_t num_particles;      /* N; reference range 256Ki..4Mi (defines.h:44-45), any N >= 1 here */
+    int32_t  device;             /* HIP device ordinal (replaces IDXGIAdapter1*) */
+    int32_t  force_mode;         /* mapn_force_mode */
+    float    mass;               /* 70000  (hlsl:38) */
+    float    softening_squared;  /* 25     (hlsl:37) */
+    float    dt;                 /* 0.1f   (Compute.cpp:545) */
+    float    damping;            /* 1.0f   (Compute.cpp:546) */
+    uint32_t seed;               /* initial-state seed (reference: random_device, Compute.cpp:679) */
+    float    spread;             /* 400    (defines.h:42 PARTICLE_SPREAD) */
+    float    initial_speed;      /* 15     (defines.h:39 INITIAL_PARTICLE_SPEED) */
+    uint32_t flags;              /* MAPN_FLAG_* */
+    int32_t  kernel;             /* mapn_kernel */
+    int32_t  rank;               /* shard index p in [0, world_size) */
+    int32_t  world_size;         /* number of shards P (1 = unsharded); P must divide N */
+    int32_t  reserved[5];
+} mapn_config;
+
+int mapn_abi_version(void);
+const char *mapn_last_error(void);
+
+/* Fills cfg with the reference's literal constants, device 0, ALL_PAIRS, seed 1, 1 shard. */
+int mapn_config_default(mapn_config *cfg);
+
+/*
+ * Compute::Compute(...) fresh path (Compute.cpp:72-98 -> Initialize, InitializeParticles,
+ * WaitForGpu).  Generates the seeded two-shell initial state (unless MAPN_FLAG_NO_INIT),
+ * uploads it to BOTH ping-pong buffers (Compute.cpp:881-882,903-904) and blocks until ready.
+ */
+int mapn_create(const mapn_config *cfg, mapn_ctx **out_ctx);
+
+/*
+ * Compute::Compute(..., Compute* old) migrate path (Compute.cpp:91-94 -> CopyState :303-410):
+ * new context on cfg->device takes both position buffers, both velocity buffers and the
+ * buffer index from `old` (device-to-device, possibly across GPUs).  `old` stays valid and
+ * is drained first, as Particles.cpp:467-471 does.
+ */
+int mapn_create_from(const mapn_config *cfg, mapn_ctx *old, mapn_ctx **out_ctx);
+
+/* Compute::~Compute (Compute.cpp:102-123): drain the device, then free. */
+int mapn_destroy(mapn_ctx *ctx);
+
+/*
+ * Compute::Simulate(int numActive, UINT64 sharedFenceValue) (Compute.h:48, Compute.cpp:1009-1055).
+ * Asynchronous: enqueues one step and returns.  Bodies [0, min(roundup64(num_active), N))
+ * advance (Compute.cpp:1041), the rest of the written buffer is left untouched.  If a consumer
+ * is attached (mapn_set_consumer), the step first waits, on the device, until the consumer has
+ * signalled `wait_value - 1` (Compute.cpp:1012); pass 0 when there is no consumer.  Afterwards
+ * the fence value is +1 and the buffer index flipped (MoveToNextFrame, Compute.cpp:993-1004).
+ */
+int mapn_simulate(mapn_ctx *ctx, int num_active, uint64_t wait_value);
+
+/* Compute::GetFenceValue (Compute.h:64): the value the NEXT simulate will signal. */
+uint64_t mapn_fence_value(const mapn_ctx *ctx);
+
+/* Highest fence value the device has completed (ID3D12Fence::GetCompletedValue analogue). */
+uint64_t mapn_completed_value(mapn_ctx *ctx);
+
+/* Compute::WaitForGpu (Compute.cpp:928-940): signal, fence value +1, host-block until idle. */
+int mapn_wait_idle(mapn_ctx *ctx);
+
+/* m_bufferIndex: the buffer the NEXT step writes; the latest results are in 1 - index. */
+uint32_t mapn_buffer_index(const mapn_ctx *ctx);
+uint32_t mapn_num_particles(const mapn_ctx *ctx);
+
+/*
+ * Compute::GetSharedHandles (Compute.h:54-62, Compute.cpp:944-950) -> {heap, fence,
+ * alignedDataSize, bufferIndex}.  HIP analogue: device pointers of the two position buffers,
+ * a hipEvent_t recorded after every step, the per-buffer byte size and the buffer index.
+ * Borrowed views, valid until mapn_destroy / mapn_adopt_position_buffers.  Velocities are
+ * never exported (Compute.cpp:231-237).
+ */
+typedef struct mapn_shared_handles {
+    void    *positions[2];       /* device float4[N] */
+    void    *step_done_event;    /* hipEvent_t, recorded on the compute stream after each step */
+    uint64_t aligned_data_size;  /* bytes per position buffer, 64 KiB aligned (Compute.cpp:185-194) */
+    uint32_t buffer_index;
+    uint32_t reserved;
+} mapn_shared_handles;
+int mapn_get_shared_handles(mapn_ctx *ctx, mapn_shared_handles *out);
+
+/*
+ * The consumer's fence (the `in_fenceHandle` of GetSharedHandles / `in_fence` of SetAsync):
+ * a host-visible monotonically increasing counter the consumer bumps with
+ * mapn_consumer_signal(); mapn_simulate(wait_value) does not overwrite a position buffer
+ * before the counter reaches wait_value - 1.
+ */
+int mapn_set_consumer(mapn_ctx *ctx, int enabled);
+int mapn_consumer_signal(mapn_ctx *ctx, uint64_t value);
+/* device-side form: the consumer reaches `value` when hip_event (a hipEvent_t it has already
+ * recorded on its own stream) fires; simulate then waits for it on the GPU, not on the host */
+int mapn_consumer_signal_event(mapn_ctx *ctx, uint64_t value, void *hip_event);
+
+/*
+ * Compute::SetAsync (Compute.h:74-77, Compute.cpp:956-987): compute straight into two
+ * caller-owned device float4[N] buffers (same device); the next step writes
+ * buffers[1 - buffer_index].  Compute::ResetFromAsyncHelper (Compute.cpp:260-298) undoes it,
+ * copying the current positions back into the context's own buffers.
+ */
+int mapn_adopt_position_buffers(mapn_ctx *ctx, void *buffers[2], uint32_t buffer_index);
+int mapn_reset_from_async(mapn_ctx *ctx);
+
+/* AdapterShared::GetGpuTimes (AdapterShared.h:51; D3D12GpuTimer.h:133-160): EMA-20 of the
+ * step's device time in seconds, timer name "simulate ms". */
+float mapn_last_step_seconds(mapn_ctx *ctx);
+const char *mapn_timer_name(void);
+
+/* Vendor-hint stubs (Compute.h:51, AdapterShared.h:54,60): no AMD analogue, always false. */
+int mapn_set_use_intel_command_queue_extension(mapn_ctx *ctx, int desired);
+int mapn_get_using_intel_command_queue_extension(const mapn_ctx *ctx);
+int mapn_get_is_uma(const mapn_ctx *ctx);
+
+/*
+ * State hand-off used by the parity harness and by checkpoint/restore (the reference has only
+ * the in-memory CopyState).  upload writes the same data into BOTH ping-pong buffers, like
+ * InitializeParticles; download reads the latest state (buffer 1 - index) after draining.
+ * pos4: N*4 floats, vel3: N*3 floats, host memory; either may be NULL.
+ */
+int mapn_upload_state(mapn_ctx *ctx, const float *pos4, const float *vel3);
+int mapn_download_state(mapn_ctx *ctx, float *pos4, float *vel3);
+/* Raw access to one ping-pong buffer pair (index 0 or 1), for exact state comparison. */
+int mapn_download_buffer(mapn_ctx *ctx, uint32_t index, float *pos4, float *vel3);
+
+/*
+ * LoadParticles / InitializeParticles (Compute.cpp:667-812, 820-844), made deterministic:
+ * host-side generator, no device needed.  See csrc/mapn_init.cpp for the specification.
+ */
+int mapn_generate_initial_state(uint32_t seed, uint32_t num_particles, float spread,
+                                float initial_speed, float *pos4, float *vel3);
+
+/* The 32-byte constant block of Compute.cpp:542-546 as this context would upload it. */
+int mapn_get_cbuffer(const mapn_ctx *ctx, uint32_t out_param[4], float out_paramf[4]);
+
+/* ---- sharded (multi-GPU) mode: one process per GPU, bodies [p*N/P, (p+1)*N/P) per rank ---- */
+
+#define MAPN_UNIQUE_ID_BYTES 128
+/* rank 0 creates the id (ncclGetUniqueId), the launcher broadcasts it to all ranks */
+int mapn_comm_get_unique_id(void *out_id128);
+/* collective over all ranks of the job; afterwards every mapn_simulate ends with an
+ * all-gather of the new position slices over RCCL/xGMI on the context's comm stream */
+int mapn_comm_init(mapn_ctx *ctx, const void *id128);
+/* alternative transport: the caller all-gathers the written position buffer itself after every
+ * step (e.g. torch.distributed.all_gather_into_tensor on the exported buffers) */
+int mapn_set_external_gather(mapn_ctx *ctx, int enabled);
+/* the slice [first, first+count) of bodies this context owns */
+int mapn_shard_range(const mapn_ctx *ctx, uint32_t *first, uint32_t *count);
+
+/* ---- introspection for the bench harness ---- */
+typedef struct mapn_device_info {
+    char     name[128];
+    char     arch[64];
+    int32_t  compute_units;
+    int32_t  clock_khz;
+    int32_t  wavefront_size;
+    int32_t  reserved;
+    double   peak_fp32_flops;    /* CUs x clock x 256 flop/clk/CU */
+    uint64_t total_memory_bytes;
+} mapn_device_info;
+int mapn_get_device_info(int device, mapn_device_info *out);
+int mapn_device_count(void);
+
+/* Force-kernel statistics accumulated by mapn_simulate: every step records HIP events on the
+ * compute stream around the all-pairs force launch(es); avg_seconds is their mean device time
+ * since the last reset.  This is what bench.py's roofline line is computed from. */
+typedef struct mapn_kernel_stats {
+    char     kernel_name[64];
+    uint64_t launches;
+    double   avg_seconds;
+    uint32_t grid_x, grid_y, block_x;
+    uint32_t bodies_per_lane, j_splits;
+    uint32_t fused;              /* 1: integrator fused into the force kernel */
+} mapn_kernel_stats;
+int mapn_get_kernel_stats(mapn_ctx *ctx, int reset, mapn_kernel_stats *out);
+
+/* Tuning hooks (tests exercise every kernel variant through these; AUTO restores the default).
+ * bodies_per_lane in {2,4,8}, waves in {1,2,4,8,16}, sb >= 1 (j-split across workgroups). */
+int mapn_set_force_plan(mapn_ctx *ctx, int kernel, uint32_t bodies_per_lane, uint32_t waves,
+                        uint32_t sb, int fused);
+/* Per-step event timers on/off (on by default, like the reference's D3D12GpuTimer). */
+int mapn_set_timers(mapn_ctx *ctx, int enabled);
+/* The compute stream (hipStream_t) steps are enqueued on, for callers that record events. */
+void *mapn_compute_stream(mapn_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAPN_H */

@@ -1,0 +1,22 @@
+"""mapn -- MI355X-native n-body compute step (host-side Python mirror of the C ABI).
+
+The product is ``libmapn.so`` (HIP kernels for gfx950 + the C ABI of ``include/mapn.h``); this
+package is a thin ctypes binding that mirrors the reference's ``class Compute``
+(reference/Particles/Compute.h:33-78) so tests and the bench harness read like its caller,
+``Particles::Draw`` (Particles.cpp:432-456).  There is no CPU fallback: without the built
+library, or without a gfx950 device, construction raises.
+"""
+from ._lib import (  # noqa: F401
+    FORCE_ALL_PAIRS, FORCE_CENTRAL_WELL, KERNEL_AUTO, KERNEL_LDS, KERNEL_SCALAR,
+    FLAG_NO_INIT, FLAG_USE_GRAPH, Config, DeviceInfo, KernelStats, MapnError, SharedHandles,
+    build_library, library_path, load_library,
+)
+from .compute import Compute, generate_initial_state  # noqa: F401
+from .shard import ShardPlan, shard_range, remote_segments  # noqa: F401
+
+__all__ = [
+    "Compute", "Config", "MapnError", "ShardPlan", "shard_range", "remote_segments",
+    "generate_initial_state", "build_library", "load_library", "library_path",
+    "FORCE_ALL_PAIRS", "FORCE_CENTRAL_WELL", "KERNEL_AUTO", "KERNEL_LDS", "KERNEL_SCALAR",
+    "FLAG_NO_INIT", "FLAG_USE_GRAPH",
+]

@@ -1,0 +1,214 @@
+"""Python mirror of the reference's ``class Compute`` over the C ABI.
+
+Method names, argument meaning and error behaviour follow reference/Particles/Compute.h:33-78
+and AdapterShared.h:51-60, so a parity test reads like ``Particles::Draw`` (Particles.cpp:446-448):
+
+    fence = compute.GetFenceValue()
+    compute.Simulate(num_simulated, fence)
+
+Errors raise ``MapnError`` (the reference throws HrException, DXSampleHelper.h:29-46).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Config, KernelStats, MapnError, SharedHandles, check, load_library
+
+
+def generate_initial_state(num_particles: int, seed: int = 1, spread: float = 400.0, speed: float = 15.0):
+    """LoadParticles / InitializeParticles made deterministic (csrc/mapn_init.cpp)."""
+    lib = load_library()
+    pos = np.zeros((num_particles, 4), np.float32)
+    vel = np.zeros((num_particles, 3), np.float32)
+    check(lib.mapn_generate_initial_state(seed, num_particles, spread, speed,
+                                          pos.ctypes.data_as(_lib._fp), vel.ctypes.data_as(_lib._fp)))
+    return pos, vel
+
+
+class Compute:
+    """``Compute(numParticles, adapter, useIntelCommandQueueExtension, old=None)`` (Compute.h:36-39).
+
+    ``device`` replaces the DXGI adapter.  The keyword arguments are what the reference
+    hard-codes (nBodyGravityCS.hlsl:37-38, Compute.cpp:545-546, defines.h:39,42) plus the
+    sharding coordinates of the multi-GPU mode.
+    """
+
+    def __init__(self, num_particles: int, device: int = 0, use_intel_command_queue_extension: bool = False,
+                 old: "Compute | None" = None, *, force_mode: int = _lib.FORCE_ALL_PAIRS,
+                 mass: float = 70000.0, softening_squared: float = 25.0, dt: float = 0.1,
+                 damping: float = 1.0, seed: int = 1, spread: float = 400.0, initial_speed: float = 15.0,
+                 flags: int = 0, kernel: int = _lib.KERNEL_AUTO, rank: int = 0, world_size: int = 1):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        cfg = Config()
+        check(self._lib.mapn_config_default(C.byref(cfg)))
+        cfg.num_particles, cfg.device, cfg.force_mode = num_particles, device, force_mode
+        cfg.mass, cfg.softening_squared, cfg.dt, cfg.damping = mass, softening_squared, dt, damping
+        cfg.seed, cfg.spread, cfg.initial_speed = seed, spread, initial_speed
+        cfg.flags, cfg.kernel, cfg.rank, cfg.world_size = flags, kernel, rank, world_size
+        self.config = cfg
+        self.num_particles = num_particles
+        if old is not None:
+            check(self._lib.mapn_create_from(C.byref(cfg), old._ctx, C.byref(self._ctx)))   # CopyState
+        else:
+            check(self._lib.mapn_create(C.byref(cfg), C.byref(self._ctx)))
+        self._using_intel_ext = False   # vendor hint only; no AMD analogue
+
+    # -- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.mapn_destroy(self._ctx)          # ~Compute: WaitForGpu, then free
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- the reference's public surface ----------------------------------------------------------
+    def Simulate(self, num_active_particles: int, shared_fence_value: int = 0):
+        """Compute.cpp:1009-1055.  Asynchronous enqueue of one step."""
+        check(self._lib.mapn_simulate(self._ctx, int(num_active_particles), int(shared_fence_value)))
+
+    def GetFenceValue(self) -> int:
+        """Compute.h:64 -- the value the next Simulate will signal."""
+        return int(self._lib.mapn_fence_value(self._ctx))
+
+    def GetCompletedValue(self) -> int:
+        return int(self._lib.mapn_completed_value(self._ctx))
+
+    def WaitForGpu(self):
+        """Compute.cpp:928-940."""
+        check(self._lib.mapn_wait_idle(self._ctx))
+
+    def GetSharedHandles(self, consumer_fence: bool = True) -> SharedHandles:
+        """Compute.cpp:944-950: export the position ping-pong pair + completion event; attaching
+        the consumer's fence makes Simulate honour ``shared_fence_value``."""
+        check(self._lib.mapn_set_consumer(self._ctx, 1 if consumer_fence else 0))
+        h = SharedHandles()
+        check(self._lib.mapn_get_shared_handles(self._ctx, C.byref(h)))
+        return h
+
+    def ConsumerSignal(self, value: int, hip_event: int | None = None):
+        """The consumer's ``Signal(fence, value)`` (Render.cpp:826): host-side, or device-side
+        when given a hipEvent_t already recorded on the consumer's stream."""
+        if hip_event is None:
+            check(self._lib.mapn_consumer_signal(self._ctx, int(value)))
+        else:
+            check(self._lib.mapn_consumer_signal_event(self._ctx, int(value), C.c_void_p(hip_event)))
+
+    def SetAsync(self, buffers, buffer_index: int):
+        """Compute.cpp:956-987: compute directly into two caller-owned device float4[N] buffers."""
+        arr = (C.c_void_p * 2)(C.c_void_p(int(buffers[0])), C.c_void_p(int(buffers[1])))
+        check(self._lib.mapn_adopt_position_buffers(self._ctx, C.byref(arr), int(buffer_index)))
+
+    def ResetFromAsyncHelper(self):
+        """Compute.cpp:260-298."""
+        check(self._lib.mapn_reset_from_async(self._ctx))
+
+    def SetUseIntelCommandQueueExtension(self, desired: bool):
+        check(self._lib.mapn_set_use_intel_command_queue_extension(self._ctx, int(bool(desired))))
+
+    def GetUsingIntelCommandQueueExtension(self) -> bool:
+        return bool(self._lib.mapn_get_using_intel_command_queue_extension(self._ctx))
+
+    def GetIsUMA(self) -> bool:
+        return bool(self._lib.mapn_get_is_uma(self._ctx))
+
+    def GetGpuTimes(self):
+        """AdapterShared.h:51 -> vector<pair<float seconds, string name>> (D3D12GpuTimer.h:54-55)."""
+        return [(float(self._lib.mapn_last_step_seconds(self._ctx)), self._lib.mapn_timer_name().decode())]
+
+    # -- state hand-off ------------------------------------------------------------------------
+    @property
+    def buffer_index(self) -> int:
+        return int(self._lib.mapn_buffer_index(self._ctx))
+
+    def upload_state(self, pos, vel):
+        pos = np.ascontiguousarray(pos, np.float32)
+        vel = np.ascontiguousarray(vel, np.float32)
+        if pos.shape != (self.num_particles, 4) or vel.shape != (self.num_particles, 3):
+            raise ValueError("upload_state: pos must be (N,4) and vel (N,3) float32")
+        check(self._lib.mapn_upload_state(self._ctx, pos.ctypes.data_as(_lib._fp), vel.ctypes.data_as(_lib._fp)))
+
+    def download_state(self):
+        pos = np.empty((self.num_particles, 4), np.float32)
+        vel = np.empty((self.num_particles, 3), np.float32)
+        check(self._lib.mapn_download_state(self._ctx, pos.ctypes.data_as(_lib._fp), vel.ctypes.data_as(_lib._fp)))
+        return pos, vel
+
+    def download_buffer(self, index: int):
+        pos = np.empty((self.num_particles, 4), np.float32)
+        vel = np.empty((self.num_particles, 3), np.float32)
+        check(self._lib.mapn_download_buffer(self._ctx, index, pos.ctypes.data_as(_lib._fp), vel.ctypes.data_as(_lib._fp)))
+        return pos, vel
+
+    def cbuffer(self):
+        p, f = (C.c_uint32 * 4)(), (C.c_float * 4)()
+        check(self._lib.mapn_get_cbuffer(self._ctx, C.byref(p), C.byref(f)))
+        return list(p), np.array(list(f), np.float32)
+
+    # -- sharded mode --------------------------------------------------------------------------
+    def shard_range(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        check(self._lib.mapn_shard_range(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        check(load_library().mapn_comm_get_unique_id(C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes):
+        if len(unique_id) != _lib.UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        buf = C.create_string_buffer(unique_id, _lib.UNIQUE_ID_BYTES)
+        check(self._lib.mapn_comm_init(self._ctx, C.cast(buf, C.c_void_p)))
+
+    def comm_init_torch(self):
+        """Rendezvous through an already-initialised torch.distributed group: rank 0 creates the
+        RCCL unique id, everybody receives it, then all ranks join the communicator."""
+        import torch.distributed as dist
+        ids = [self.comm_unique_id() if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        self.comm_init(ids[0])
+
+    def set_external_gather(self, enabled: bool = True):
+        check(self._lib.mapn_set_external_gather(self._ctx, int(bool(enabled))))
+
+    # -- tuning / introspection ----------------------------------------------------------------
+    def set_force_plan(self, kernel: int, bodies_per_lane: int = 4, waves: int = 8, sb: int = 1, fused: bool = True):
+        check(self._lib.mapn_set_force_plan(self._ctx, kernel, bodies_per_lane, waves, sb, int(bool(fused))))
+
+    def set_timers(self, enabled: bool):
+        check(self._lib.mapn_set_timers(self._ctx, int(bool(enabled))))
+
+    def kernel_stats(self, reset: bool = False) -> KernelStats:
+        st = KernelStats()
+        check(self._lib.mapn_get_kernel_stats(self._ctx, int(reset), C.byref(st)))
+        return st
+
+    @property
+    def compute_stream(self) -> int:
+        return int(self._lib.mapn_compute_stream(self._ctx) or 0)
+
+
+def device_info(device: int = 0) -> _lib.DeviceInfo:
+    info = _lib.DeviceInfo()
+    check(load_library().mapn_get_device_info(device, C.byref(info)))
+    return info
+
+
+def device_count() -> int:
+    return int(load_library().mapn_device_count())

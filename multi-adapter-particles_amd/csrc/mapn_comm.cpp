@@ -1,0 +1,115 @@
+// mapn_comm.cpp -- see mapn_comm.h.  The reference has no collective at all (its two adapters
+// exchange positions through a D3D12 cross-adapter heap in system memory, Compute.cpp:163-201,
+// Render.cpp:789-831); this is the data-sharded replacement: one ncclAllGather of the new
+// float4 position slices per step.
+#include "mapn_comm.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+namespace mapn {
+
+namespace {
+
+thread_local std::string g_err;
+
+struct Api {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+Api g_api;
+std::once_flag g_once;
+
+void load_api()
+{
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        g_api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (g_api.handle) break;
+    }
+    if (!g_api.handle) return;
+    g_api.GetUniqueId = reinterpret_cast<decltype(g_api.GetUniqueId)>(dlsym(g_api.handle, "ncclGetUniqueId"));
+    g_api.CommInitRank = reinterpret_cast<decltype(g_api.CommInitRank)>(dlsym(g_api.handle, "ncclCommInitRank"));
+    g_api.CommDestroy = reinterpret_cast<decltype(g_api.CommDestroy)>(dlsym(g_api.handle, "ncclCommDestroy"));
+    g_api.AllGather = reinterpret_cast<decltype(g_api.AllGather)>(dlsym(g_api.handle, "ncclAllGather"));
+    g_api.GetErrorString = reinterpret_cast<decltype(g_api.GetErrorString)>(dlsym(g_api.handle, "ncclGetErrorString"));
+    g_api.ok = g_api.GetUniqueId && g_api.CommInitRank && g_api.CommDestroy && g_api.AllGather && g_api.GetErrorString;
+}
+
+bool api()
+{
+    std::call_once(g_once, load_api);
+    if (!g_api.ok) g_err = "librccl.so.1 could not be loaded (dlopen/dlsym failed): RCCL is required for sharded mode";
+    return g_api.ok;
+}
+
+int check(ncclResult_t r, const char *what)
+{
+    if (r == ncclSuccess) return 0;
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, g_api.GetErrorString(r));
+    g_err = buf;
+    return -1;
+}
+
+}  // namespace
+
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+};
+
+static_assert(sizeof(ncclUniqueId) == 128, "mapn.h MAPN_UNIQUE_ID_BYTES must match ncclUniqueId");
+
+int comm_get_unique_id(void *out_id128)
+{
+    if (!api()) return -1;
+    ncclUniqueId id;
+    if (check(g_api.GetUniqueId(&id), "ncclGetUniqueId")) return -1;
+    memcpy(out_id128, &id, sizeof id);
+    return 0;
+}
+
+Comm *comm_create(const void *id128, int rank, int nranks)
+{
+    if (!api()) return nullptr;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    Comm *c = new Comm();
+    c->rank = rank;
+    c->nranks = nranks;
+    if (check(g_api.CommInitRank(&c->comm, nranks, id, rank), "ncclCommInitRank")) {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void comm_destroy(Comm *c)
+{
+    if (!c) return;
+    if (c->comm && g_api.ok) g_api.CommDestroy(c->comm);
+    delete c;
+}
+
+int comm_all_gather_inplace(Comm *c, void *buf, size_t floats_per_rank, hipStream_t stream)
+{
+    if (!c || !g_api.ok) { g_err = "communicator not initialised"; return -1; }
+    const float *send = static_cast<const float *>(buf) + (size_t)c->rank * floats_per_rank;
+    return check(g_api.AllGather(send, buf, floats_per_rank, ncclFloat, c->comm, stream), "ncclAllGather");
+}
+
+const char *comm_last_error() { return g_err.c_str(); }
+
+}  // namespace mapn

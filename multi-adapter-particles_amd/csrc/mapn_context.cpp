@@ -1,0 +1,779 @@
+// mapn_context.cpp -- host side of libmapn.so: the C ABI of include/mapn.h.
+//
+// Mirrors the public surface of the reference's `class Compute`
+// (reference/Particles/Compute.h:33-78, Compute.cpp) on HIP: device, two streams (compute +
+// comm), ping-pong position / velocity buffers, a monotonically increasing fence value backed
+// by hipEvents, event timers with the reference's EMA, and the sharded multi-GPU step with an
+// RCCL all-gather.  No CPU fallback: without a gfx950 device mapn_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mapn.h"
+#include "mapn_comm.h"
+#include "mapn_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(MAPN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                        __FILE__, __LINE__);                                                      \
+    } while (0)
+
+constexpr uint32_t kBlock = 64;            // defines.h:37 BLOCK_SIZE: granularity of num_active
+constexpr int kTimerRing = 64;             // in-flight step timers
+constexpr int kAverageOver = 20;           // D3D12GpuTimer.h averageOver (Compute.cpp:445)
+constexpr uint64_t kHeapAlign = 64 * 1024; // Compute.cpp:185-194: 64 KiB placement alignment
+
+struct StepTimer {
+    hipEvent_t start = nullptr, force_done = nullptr, stop = nullptr;
+    bool pending = false;
+    bool has_force = false;
+};
+
+}  // namespace
+
+struct mapn_ctx {
+    mapn_config cfg{};
+    uint32_t n = 0;
+    uint32_t first = 0, count = 0;            // shard [first, first+count)
+    int device = 0;
+    int cus = 0;
+    hipStream_t compute = nullptr, comm_stream = nullptr;
+
+    float4 *pos_heap = nullptr;               // one allocation holding both position buffers
+    float4 *pos_own[2] = {nullptr, nullptr};
+    float4 *pos[2] = {nullptr, nullptr};      // active (own or adopted, SetAsync)
+    float *vel[2] = {nullptr, nullptr};
+    bool adopted = false;
+    uint64_t aligned_data_size = 0;
+
+    float4 *partial = nullptr;
+    size_t partial_bytes = 0;
+
+    uint32_t buffer_index = 0;                // Compute.cpp:80 m_bufferIndex(0)
+    uint64_t fence_value = 0;                 // Compute.cpp:82 m_fenceValue(0)
+    uint64_t completed = 0;
+    hipEvent_t fence_events[kTimerRing] = {};
+    uint64_t fence_event_value[kTimerRing] = {};
+    hipEvent_t step_done = nullptr;           // exported: recorded after every step
+
+    // consumer fence (the render adapter's shared fence, Compute.cpp:1012)
+    bool consumer_enabled = false;
+    uint64_t consumer_value = 0;
+    std::vector<std::pair<uint64_t, hipEvent_t>> consumer_events;
+
+    // timers (D3D12GpuTimer analogue)
+    StepTimer timers[kTimerRing];
+    uint32_t timer_head = 0;
+    float ema_seconds = 0.f;
+    bool timers_enabled = true;
+    double force_seconds_sum = 0.0;
+    uint64_t force_launches = 0;
+
+    // force plan
+    bool plan_forced = false;
+    mapn::ForcePlan forced_plan{};
+
+    // sharded mode
+    mapn::Comm *comm = nullptr;
+    hipEvent_t integrate_done = nullptr;
+    hipEvent_t gather_done[2] = {nullptr, nullptr};
+    bool gather_recorded[2] = {false, false};
+    bool external_gather = false;
+
+    // graph replay
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+    int graph_active[2] = {-1, -1};
+};
+
+namespace {
+
+int resolve_timers(mapn_ctx *c, bool block)
+{
+    for (int k = 0; k < kTimerRing; k++) {
+        StepTimer &t = c->timers[(c->timer_head + k) % kTimerRing];
+        if (!t.pending) continue;
+        hipError_t q = hipEventQuery(t.stop);
+        if (q == hipErrorNotReady) {
+            if (!block) continue;
+            HIP_TRY(hipEventSynchronize(t.stop));
+        } else if (q != hipSuccess) {
+            return fail(MAPN_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
+        }
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
+        // D3D12GpuTimer.h:151-153: t = t*(averageOver-1); t = (t + delta)/averageOver
+        c->ema_seconds = (c->ema_seconds * (kAverageOver - 1) + ms * 1e-3f) / kAverageOver;
+        if (t.has_force) {
+            float fms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&fms, t.start, t.force_done));
+            c->force_seconds_sum += fms * 1e-3;
+            c->force_launches++;
+        }
+        t.pending = false;
+    }
+    return MAPN_OK;
+}
+
+int update_completed(mapn_ctx *c)
+{
+    for (int k = 0; k < kTimerRing; k++) {
+        const uint64_t v = c->fence_event_value[k];
+        if (v > c->completed && c->fence_events[k] && hipEventQuery(c->fence_events[k]) == hipSuccess)
+            c->completed = v;
+    }
+    return MAPN_OK;
+}
+
+// Signal(fence, value) on the compute stream
+int signal_fence(mapn_ctx *c, uint64_t value)
+{
+    const int slot = (int)(value % kTimerRing);
+    HIP_TRY(hipEventRecord(c->fence_events[slot], c->compute));
+    c->fence_event_value[slot] = value;
+    return MAPN_OK;
+}
+
+uint32_t active_bodies(int num_active, uint32_t n)
+{
+    if (num_active <= 0) return 0;
+    const uint64_t groups = ((uint64_t)num_active + kBlock - 1) / kBlock;   // Compute.cpp:1041
+    return (uint32_t)std::min<uint64_t>(groups * kBlock, n);
+}
+
+// Pick the j-split so that the launch puts >= ~6 waves on each of the 4*CUs SIMDs.
+mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_total, uint32_t nseg, bool allow_fused)
+{
+    mapn::ForcePlan p{};
+    if (c->plan_forced) {
+        p = c->forced_plan;
+        p.nseg = nseg;
+        if (!allow_fused || p.sb != 1 || nseg != 1) p.fused = false;
+        return p;
+    }
+    p.kind = c->cfg.kernel == MAPN_KERNEL_SCALAR ? mapn::KERNEL_SGPR : mapn::KERNEL_LDS;
+    p.k = 4;
+    p.nseg = nseg;
+    const uint64_t simds = (uint64_t)c->cus * 4;
+    const uint64_t i_waves = (i_count + 64ull * p.k - 1) / (64ull * p.k);
+    const uint64_t want = simds * 6;                       // target waves in flight
+    uint64_t S = (want + i_waves - 1) / i_waves;           // total j-split
+    const uint64_t tiles = std::max<uint64_t>(1, (j_total / std::max(1u, nseg) + 63) / 64);
+    S = std::max<uint64_t>(1, std::min<uint64_t>(S, tiles));
+    if (S <= 16) {
+        uint32_t w = 1;
+        while (w < S) w <<= 1;
+        p.waves = std::max(w, 4u);
+        p.sb = 1;
+    } else {
+        p.waves = 8;
+        p.sb = (uint32_t)((S + 7) / 8);
+        if (p.sb > 8) p.sb = (p.sb + 7) / 8 * 8;          // multiples of 8 rows: XCD-aware remap
+    }
+    p.fused = allow_fused && p.sb == 1 && nseg == 1;
+    return p;
+}
+
+int ensure_partial(mapn_ctx *c, size_t slots, size_t stride)
+{
+    const size_t need = slots * stride * sizeof(float4);
+    if (need <= c->partial_bytes) return MAPN_OK;
+    if (c->partial) HIP_TRY(hipFree(c->partial));
+    c->partial = nullptr;
+    c->partial_bytes = 0;
+    HIP_TRY(hipMalloc(&c->partial, need));
+    c->partial_bytes = need;
+    return MAPN_OK;
+}
+
+void fill_segment(mapn::StepArgs &a, int s, uint32_t first, uint32_t count, uint32_t slot, uint32_t S)
+{
+    a.seg_first[s] = first;
+    a.seg_count[s] = count;
+    a.seg_slot[s] = slot;
+    const uint32_t tiles = (count + 63u) / 64u;
+    a.seg_tiles_base[s] = tiles / S;
+    a.seg_tiles_rem[s] = tiles % S;
+}
+
+mapn::StepArgs base_args(const mapn_ctx *c, uint32_t w, uint32_t r)
+{
+    mapn::StepArgs a{};
+    a.pos_old = c->pos[r];
+    a.vel_old = c->vel[r];
+    a.pos_new = c->pos[w];
+    a.vel_new = c->vel[w];
+    a.mass = c->cfg.mass;
+    a.soft2 = c->cfg.softening_squared;
+    a.dt = c->cfg.dt;
+    a.damping = c->cfg.damping;
+    return a;
+}
+
+int wait_for_consumer(mapn_ctx *c, uint64_t wait_value)
+{
+    if (!c->consumer_enabled || wait_value == 0) return MAPN_OK;
+    const uint64_t need = wait_value - 1;                  // Compute.cpp:1012
+    if (c->consumer_value >= need) return MAPN_OK;
+    // the consumer's work for `need` is already enqueued on its own stream: wait on the device
+    hipEvent_t best = nullptr;
+    uint64_t best_v = 0;
+    for (auto &e : c->consumer_events)
+        if (e.first >= need && (!best || e.first < best_v)) { best = e.second; best_v = e.first; }
+    if (!best)
+        return fail(MAPN_ERR_STATE, "simulate(wait_value=%llu): consumer has not signalled %llu "
+                    "(last %llu); the step would overwrite a buffer still being read",
+                    (unsigned long long)wait_value, (unsigned long long)need,
+                    (unsigned long long)c->consumer_value);
+    HIP_TRY(hipStreamWaitEvent(c->compute, best, 0));
+    c->consumer_events.erase(std::remove_if(c->consumer_events.begin(), c->consumer_events.end(),
+                                            [&](const std::pair<uint64_t, hipEvent_t> &e) { return e.first <= best_v; }),
+                             c->consumer_events.end());
+    c->consumer_value = std::max(c->consumer_value, best_v);
+    return MAPN_OK;
+}
+
+// Enqueue the kernels of one step on the compute stream (no fence/flip bookkeeping).
+int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
+{
+    const uint32_t w = c->buffer_index, r = 1 - c->buffer_index;
+    // this shard's active bodies: [first, min(first+count, active))
+    const uint32_t lo = c->first, hi = std::min(c->first + c->count, active);
+    const uint32_t i_count = hi > lo ? hi - lo : 0;
+    mapn::StepArgs a = base_args(c, w, r);
+    a.i_first = lo;
+    a.i_count = i_count;
+    const bool sharded_native = c->comm != nullptr;
+
+    if (timer) HIP_TRY(hipEventRecord(timer->start, c->compute));
+
+    if (i_count > 0 && c->cfg.force_mode == MAPN_FORCE_CENTRAL_WELL) {
+        HIP_TRY(mapn::launch_central_well(a, c->compute));
+    } else if (i_count > 0 && !sharded_native) {
+        mapn::ForcePlan plan = choose_plan(c, i_count, c->n, 1, true);
+        const uint32_t S = plan.sb * plan.waves;
+        fill_segment(a, 0, 0, c->n, 0, S);
+        if (!plan.fused) {
+            a.partial_stride = (i_count + 63u) & ~63u;
+            if (int rc = ensure_partial(c, S, a.partial_stride)) return rc;
+            a.partial = c->partial;
+        }
+        HIP_TRY(mapn::launch_force(plan, a, c->compute));
+        if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
+        if (!plan.fused) HIP_TRY(mapn::launch_reduce_integrate(a, S, c->compute));
+    } else if (i_count > 0) {
+        // sharded: own slice first (needs only data this rank wrote), then the remote segments
+        // once the all-gather that filled the read buffer has finished
+        const uint32_t own_first = c->first, own_count = c->count;
+        mapn::ForcePlan own = choose_plan(c, i_count, own_count, 1, false);
+        mapn::ForcePlan rem = choose_plan(c, i_count, c->n - own_count, 2, false);
+        const uint32_t S_own = own.sb * own.waves, S_rem = rem.sb * rem.waves;
+        const uint32_t slots = S_own + 2 * S_rem;
+        a.partial_stride = (i_count + 63u) & ~63u;
+        if (int rc = ensure_partial(c, slots, a.partial_stride)) return rc;
+        a.partial = c->partial;
+        fill_segment(a, 0, own_first, own_count, 0, S_own);
+        HIP_TRY(mapn::launch_force(own, a, c->compute));
+        if (c->gather_recorded[r]) HIP_TRY(hipStreamWaitEvent(c->compute, c->gather_done[r], 0));
+        mapn::StepArgs b = a;
+        fill_segment(b, 0, 0, own_first, S_own, S_rem);
+        fill_segment(b, 1, own_first + own_count, c->n - own_first - own_count, S_own + S_rem, S_rem);
+        HIP_TRY(mapn::launch_force(rem, b, c->compute));
+        if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
+        HIP_TRY(mapn::launch_reduce_integrate(a, slots, c->compute));
+    }
+    return MAPN_OK;
+}
+
+int enqueue_gather(mapn_ctx *c)
+{
+    if (!c->comm) return MAPN_OK;
+    const uint32_t w = c->buffer_index;
+    HIP_TRY(hipEventRecord(c->integrate_done, c->compute));
+    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->integrate_done, 0));
+    // in place: every rank's slice sits at its own offset of the full buffer
+    if (int rc = mapn::comm_all_gather_inplace(c->comm, c->pos[w], (size_t)c->count * 4, c->comm_stream))
+        return fail(MAPN_ERR_COMM, "all-gather failed: %s", mapn::comm_last_error());
+    HIP_TRY(hipEventRecord(c->gather_done[w], c->comm_stream));
+    c->gather_recorded[w] = true;
+    return MAPN_OK;
+}
+
+int alloc_state(mapn_ctx *c)
+{
+    const uint64_t data = (uint64_t)c->n * sizeof(float4);
+    c->aligned_data_size = (data + kHeapAlign - 1) / kHeapAlign * kHeapAlign;   // Compute.cpp:185-194
+    HIP_TRY(hipMalloc(&c->pos_heap, 2 * c->aligned_data_size));
+    HIP_TRY(hipMemset(c->pos_heap, 0, 2 * c->aligned_data_size));
+    c->pos_own[0] = c->pos_heap;
+    c->pos_own[1] = reinterpret_cast<float4 *>(reinterpret_cast<char *>(c->pos_heap) + c->aligned_data_size);
+    c->pos[0] = c->pos_own[0];
+    c->pos[1] = c->pos_own[1];
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(hipMalloc(&c->vel[b], (size_t)c->n * 12));
+        HIP_TRY(hipMemset(c->vel[b], 0, (size_t)c->n * 12));
+    }
+    return MAPN_OK;
+}
+
+int create_common(const mapn_config *cfg, mapn_ctx **out)
+{
+    if (!cfg || !out) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
+    if (cfg->struct_size != sizeof(mapn_config))
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "mapn_config.struct_size %u != %zu", cfg->struct_size, sizeof(mapn_config));
+    if (cfg->num_particles == 0) return fail(MAPN_ERR_INVALID_ARGUMENT, "num_particles must be > 0");
+    if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size)
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "rank %d / world_size %d", cfg->rank, cfg->world_size);
+    if (cfg->num_particles % (uint32_t)cfg->world_size)
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "world_size %d must divide num_particles %u", cfg->world_size, cfg->num_particles);
+    if (cfg->force_mode != MAPN_FORCE_ALL_PAIRS && cfg->force_mode != MAPN_FORCE_CENTRAL_WELL)
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "force_mode %d", cfg->force_mode);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(MAPN_ERR_NO_DEVICE, "no HIP device visible: libmapn has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", cfg->device, ndev);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MAPN_ERR_NO_DEVICE, "device %d is %s; libmapn ships gfx950 code only", cfg->device, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    mapn_ctx *c = new mapn_ctx();
+    c->cfg = *cfg;
+    c->n = cfg->num_particles;
+    c->device = cfg->device;
+    c->cus = prop.multiProcessorCount;
+    c->count = c->n / (uint32_t)cfg->world_size;
+    c->first = c->count * (uint32_t)cfg->rank;
+    c->timers_enabled = true;
+    *out = c;
+
+    HIP_TRY(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    for (int k = 0; k < kTimerRing; k++) {
+        HIP_TRY(hipEventCreateWithFlags(&c->fence_events[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreate(&c->timers[k].start));
+        HIP_TRY(hipEventCreate(&c->timers[k].force_done));
+        HIP_TRY(hipEventCreate(&c->timers[k].stop));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&c->step_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->integrate_done, hipEventDisableTiming));
+    for (int b = 0; b < 2; b++) HIP_TRY(hipEventCreateWithFlags(&c->gather_done[b], hipEventDisableTiming));
+    // Compute.cpp:434-436: fence created with value 0, m_fenceValue++ -> 1
+    c->fence_value = 1;
+    if (int rc = alloc_state(c)) return rc;
+    // Compute.cpp:563: Initialize ends with WaitForGpu
+    return mapn_wait_idle(c);
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------
+
+extern "C" {
+
+int mapn_abi_version(void) { return MAPN_ABI_VERSION; }
+
+const char *mapn_last_error(void) { return g_last_error.c_str(); }
+
+int mapn_config_default(mapn_config *cfg)
+{
+    if (!cfg) return fail(MAPN_ERR_INVALID_ARGUMENT, "null config");
+    memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = sizeof *cfg;
+    cfg->num_particles = 4u * 1024u * 1024u;   // defines.h:45 MAX_NUM_PARTICLES (Particles.cpp default)
+    cfg->device = 0;
+    cfg->force_mode = MAPN_FORCE_ALL_PAIRS;
+    cfg->mass = 70000.0f;                      // nBodyGravityCS.hlsl:38
+    cfg->softening_squared = 25.0f;            // nBodyGravityCS.hlsl:37
+    cfg->dt = 0.1f;                            // Compute.cpp:545
+    cfg->damping = 1.0f;                       // Compute.cpp:546
+    cfg->seed = 1;
+    cfg->spread = 400.0f;                      // defines.h:42
+    cfg->initial_speed = 15.0f;                // defines.h:39
+    cfg->flags = 0;
+    cfg->kernel = MAPN_KERNEL_AUTO;
+    cfg->rank = 0;
+    cfg->world_size = 1;
+    return MAPN_OK;
+}
+
+int mapn_create(const mapn_config *cfg, mapn_ctx **out_ctx)
+{
+    mapn_ctx *c = nullptr;
+    int rc = create_common(cfg, &c);
+    if (rc) { if (c) mapn_destroy(c); if (out_ctx) *out_ctx = nullptr; return rc; }
+    if (!(cfg->flags & MAPN_FLAG_NO_INIT)) {
+        // Compute.cpp:820-923 InitializeParticles: generate, upload to both buffers, WaitForGpu
+        std::vector<float> pos((size_t)c->n * 4), vel((size_t)c->n * 3);
+        rc = mapn_generate_initial_state(cfg->seed, c->n, cfg->spread, cfg->initial_speed, pos.data(), vel.data());
+        if (!rc) rc = mapn_upload_state(c, pos.data(), vel.data());
+    }
+    if (!rc) rc = mapn_wait_idle(c);           // Compute.cpp:922
+    if (!rc) rc = mapn_wait_idle(c);           // Compute.cpp:97
+    if (rc) { std::string keep = g_last_error; mapn_destroy(c); g_last_error = keep; *out_ctx = nullptr; return rc; }
+    *out_ctx = c;
+    return MAPN_OK;
+}
+
+int mapn_create_from(const mapn_config *cfg, mapn_ctx *old, mapn_ctx **out_ctx)
+{
+    if (!old) return fail(MAPN_ERR_INVALID_ARGUMENT, "null source context");
+    if (!cfg || cfg->num_particles != old->n)
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "create_from: num_particles must match the source context");
+    // Compute.cpp:305: the source leaves async mode first; Particles.cpp:467-471 drains it
+    int rc = mapn_reset_from_async(old);
+    if (!rc) rc = mapn_wait_idle(old);
+    if (rc) return rc;
+    mapn_ctx *c = nullptr;
+    rc = create_common(cfg, &c);
+    if (rc) { if (c) mapn_destroy(c); if (out_ctx) *out_ctx = nullptr; return rc; }
+    // Compute.cpp:303-410 CopyState: both position buffers, both velocity buffers, buffer index
+    for (int b = 0; b < 2 && !rc; b++) {
+        if (hipMemcpyPeer(c->pos[b], c->device, old->pos[b], old->device, (size_t)c->n * 16) != hipSuccess ||
+            hipMemcpyPeer(c->vel[b], c->device, old->vel[b], old->device, (size_t)c->n * 12) != hipSuccess)
+            rc = fail(MAPN_ERR_HIP, "CopyState: device-to-device copy failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    c->buffer_index = old->buffer_index;
+    hipSetDevice(c->device);
+    if (!rc) rc = mapn_wait_idle(c);           // Compute.cpp:354 / :409
+    if (!rc) rc = mapn_wait_idle(c);           // Compute.cpp:97
+    if (rc) { std::string keep = g_last_error; mapn_destroy(c); g_last_error = keep; *out_ctx = nullptr; return rc; }
+    *out_ctx = c;
+    return MAPN_OK;
+}
+
+int mapn_destroy(mapn_ctx *c)
+{
+    if (!c) return MAPN_OK;
+    hipSetDevice(c->device);
+    if (c->compute) hipStreamSynchronize(c->compute);          // Compute.cpp:104 WaitForGpu first
+    if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
+    if (c->comm) mapn::comm_destroy(c->comm);
+    for (int b = 0; b < 2; b++) {
+        if (c->graph_exec[b]) hipGraphExecDestroy(c->graph_exec[b]);
+        if (c->vel[b]) hipFree(c->vel[b]);
+        if (c->gather_done[b]) hipEventDestroy(c->gather_done[b]);
+    }
+    if (c->pos_heap) hipFree(c->pos_heap);
+    if (c->partial) hipFree(c->partial);
+    for (int k = 0; k < kTimerRing; k++) {
+        if (c->fence_events[k]) hipEventDestroy(c->fence_events[k]);
+        if (c->timers[k].start) hipEventDestroy(c->timers[k].start);
+        if (c->timers[k].force_done) hipEventDestroy(c->timers[k].force_done);
+        if (c->timers[k].stop) hipEventDestroy(c->timers[k].stop);
+    }
+    if (c->step_done) hipEventDestroy(c->step_done);
+    if (c->integrate_done) hipEventDestroy(c->integrate_done);
+    if (c->compute) hipStreamDestroy(c->compute);
+    if (c->comm_stream) hipStreamDestroy(c->comm_stream);
+    delete c;
+    return MAPN_OK;
+}
+
+int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->cfg.world_size > 1 && !c->comm && !c->external_gather)
+        return fail(MAPN_ERR_STATE, "sharded context (world_size %d): call mapn_comm_init or "
+                    "mapn_set_external_gather before simulate", c->cfg.world_size);
+    if (int rc = wait_for_consumer(c, wait_value)) return rc;          // Compute.cpp:1012
+    const uint32_t active = active_bodies(num_active, c->n);
+
+    StepTimer *timer = nullptr;
+    if (c->timers_enabled) {
+        timer = &c->timers[c->timer_head];
+        if (timer->pending) { if (int rc = resolve_timers(c, true)) return rc; }
+        timer->has_force = false;
+    }
+    if (int rc = enqueue_step(c, active, timer)) return rc;
+    if (timer) {
+        HIP_TRY(hipEventRecord(timer->stop, c->compute));              // Compute.cpp:1046-1047
+        timer->pending = true;
+        c->timer_head = (c->timer_head + 1) % kTimerRing;
+    }
+    if (int rc = enqueue_gather(c)) return rc;
+    // MoveToNextFrame, Compute.cpp:993-1004: Signal(fence, v); v++; index = 1 - index
+    HIP_TRY(hipEventRecord(c->step_done, c->compute));
+    if (int rc = signal_fence(c, c->fence_value)) return rc;
+    c->fence_value++;
+    c->buffer_index = 1 - c->buffer_index;
+    if (c->timers_enabled && (c->timer_head % 16) == 0) resolve_timers(c, false);
+    return MAPN_OK;
+}
+
+uint64_t mapn_fence_value(const mapn_ctx *c) { return c ? c->fence_value : 0; }
+
+uint64_t mapn_completed_value(mapn_ctx *c)
+{
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    update_completed(c);
+    return c->completed;
+}
+
+int mapn_wait_idle(mapn_ctx *c)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    // Compute.cpp:928-940: Signal(fence, v); v++; wait
+    if (int rc = signal_fence(c, c->fence_value)) return rc;
+    const uint64_t v = c->fence_value++;
+    HIP_TRY(hipStreamSynchronize(c->compute));
+    HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    c->completed = std::max(c->completed, v);
+    return resolve_timers(c, true);
+}
+
+uint32_t mapn_buffer_index(const mapn_ctx *c) { return c ? c->buffer_index : 0; }
+uint32_t mapn_num_particles(const mapn_ctx *c) { return c ? c->n : 0; }
+
+int mapn_get_shared_handles(mapn_ctx *c, mapn_shared_handles *out)
+{
+    if (!c || !out) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
+    out->positions[0] = c->pos[0];
+    out->positions[1] = c->pos[1];
+    out->step_done_event = c->step_done;
+    out->aligned_data_size = c->aligned_data_size;
+    out->buffer_index = c->buffer_index;                               // Compute.cpp:948
+    out->reserved = 0;
+    return MAPN_OK;
+}
+
+int mapn_set_consumer(mapn_ctx *c, int enabled)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    c->consumer_enabled = enabled != 0;
+    return MAPN_OK;
+}
+
+int mapn_consumer_signal(mapn_ctx *c, uint64_t value)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    c->consumer_value = std::max(c->consumer_value, value);
+    return MAPN_OK;
+}
+
+int mapn_consumer_signal_event(mapn_ctx *c, uint64_t value, void *hip_event)
+{
+    if (!c || !hip_event) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
+    c->consumer_events.emplace_back(value, static_cast<hipEvent_t>(hip_event));
+    return MAPN_OK;
+}
+
+int mapn_adopt_position_buffers(mapn_ctx *c, void *buffers[2], uint32_t buffer_index)
+{
+    if (!c || !buffers || !buffers[0] || !buffers[1] || buffer_index > 1)
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "adopt_position_buffers: bad argument");
+    if (c->comm) return fail(MAPN_ERR_STATE, "adopt_position_buffers is not available in sharded mode");
+    if (int rc = mapn_wait_idle(c)) return rc;
+    // Compute.cpp:956-987 SetAsync: take the consumer's two buffers; next write = 1 - its index
+    c->pos[0] = static_cast<float4 *>(buffers[0]);
+    c->pos[1] = static_cast<float4 *>(buffers[1]);
+    c->adopted = true;
+    c->buffer_index = 1 - buffer_index;
+    return MAPN_OK;
+}
+
+int mapn_reset_from_async(mapn_ctx *c)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    if (!c->adopted) return MAPN_OK;                                   // Compute.cpp:262-265
+    if (int rc = mapn_wait_idle(c)) return rc;
+    // Compute.cpp:260-298: copy the state back into our own buffers and use those again
+    for (int b = 0; b < 2; b++)
+        HIP_TRY(hipMemcpy(c->pos_own[b], c->pos[b], (size_t)c->n * 16, hipMemcpyDeviceToDevice));
+    c->pos[0] = c->pos_own[0];
+    c->pos[1] = c->pos_own[1];
+    c->adopted = false;
+    return MAPN_OK;
+}
+
+float mapn_last_step_seconds(mapn_ctx *c)
+{
+    if (!c) return 0.f;
+    hipSetDevice(c->device);
+    resolve_timers(c, false);
+    return c->ema_seconds;
+}
+
+const char *mapn_timer_name(void) { return "simulate ms"; }              // Compute.cpp:446
+
+int mapn_set_use_intel_command_queue_extension(mapn_ctx *, int) { return MAPN_OK; }
+int mapn_get_using_intel_command_queue_extension(const mapn_ctx *) { return 0; }
+int mapn_get_is_uma(const mapn_ctx *) { return 0; }
+
+int mapn_upload_state(mapn_ctx *c, const float *pos4, const float *vel3)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->compute));
+    HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    for (int b = 0; b < 2; b++) {                                      // Compute.cpp:881-882,903-904
+        if (pos4) HIP_TRY(hipMemcpy(c->pos[b], pos4, (size_t)c->n * 16, hipMemcpyHostToDevice));
+        if (vel3) HIP_TRY(hipMemcpy(c->vel[b], vel3, (size_t)c->n * 12, hipMemcpyHostToDevice));
+    }
+    c->gather_recorded[0] = c->gather_recorded[1] = false;
+    return MAPN_OK;
+}
+
+int mapn_download_buffer(mapn_ctx *c, uint32_t index, float *pos4, float *vel3)
+{
+    if (!c || index > 1) return fail(MAPN_ERR_INVALID_ARGUMENT, "download_buffer: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->compute));
+    HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    if (pos4) HIP_TRY(hipMemcpy(pos4, c->pos[index], (size_t)c->n * 16, hipMemcpyDeviceToHost));
+    if (vel3) HIP_TRY(hipMemcpy(vel3, c->vel[index], (size_t)c->n * 12, hipMemcpyDeviceToHost));
+    return MAPN_OK;
+}
+
+int mapn_download_state(mapn_ctx *c, float *pos4, float *vel3)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    return mapn_download_buffer(c, 1 - c->buffer_index, pos4, vel3);
+}
+
+int mapn_get_cbuffer(const mapn_ctx *c, uint32_t out_param[4], float out_paramf[4])
+{
+    if (!c || !out_param || !out_paramf) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
+    out_param[0] = c->n;                                               // Compute.cpp:543
+    out_param[1] = (c->n + kBlock - 1) / kBlock;                       // Compute.cpp:544
+    out_param[2] = out_param[3] = 0;
+    out_paramf[0] = c->cfg.dt;                                         // Compute.cpp:545
+    out_paramf[1] = c->cfg.damping;                                    // Compute.cpp:546
+    out_paramf[2] = out_paramf[3] = 0.f;
+    return MAPN_OK;
+}
+
+// ---- sharded mode ------------------------------------------------------------------------------
+
+int mapn_comm_get_unique_id(void *out_id128)
+{
+    if (!out_id128) return fail(MAPN_ERR_INVALID_ARGUMENT, "null id");
+    if (mapn::comm_get_unique_id(out_id128)) return fail(MAPN_ERR_COMM, "%s", mapn::comm_last_error());
+    return MAPN_OK;
+}
+
+int mapn_comm_init(mapn_ctx *c, const void *id128)
+{
+    if (!c || !id128) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
+    if (c->adopted) return fail(MAPN_ERR_STATE, "comm_init: context is in adopted-buffer (async) mode");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->comm) return MAPN_OK;
+    c->comm = mapn::comm_create(id128, c->cfg.rank, c->cfg.world_size);
+    if (!c->comm) return fail(MAPN_ERR_COMM, "%s", mapn::comm_last_error());
+    return MAPN_OK;
+}
+
+int mapn_set_external_gather(mapn_ctx *c, int enabled)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    c->external_gather = enabled != 0;
+    return MAPN_OK;
+}
+
+int mapn_shard_range(const mapn_ctx *c, uint32_t *first, uint32_t *count)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    if (first) *first = c->first;
+    if (count) *count = c->count;
+    return MAPN_OK;
+}
+
+void *mapn_compute_stream(mapn_ctx *c) { return c ? c->compute : nullptr; }
+
+// ---- introspection -----------------------------------------------------------------------------
+
+int mapn_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mapn_get_device_info(int device, mapn_device_info *out)
+{
+    if (!out) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", p.name);
+    snprintf(out->arch, sizeof out->arch, "%s", p.gcnArchName);
+    out->compute_units = p.multiProcessorCount;
+    out->clock_khz = p.clockRate;
+    out->wavefront_size = p.warpSize;
+    out->peak_fp32_flops = (double)p.multiProcessorCount * (double)p.clockRate * 1e3 * 256.0;
+    out->total_memory_bytes = p.totalGlobalMem;
+    return MAPN_OK;
+}
+
+int mapn_set_force_plan(mapn_ctx *c, int kernel, uint32_t bodies_per_lane, uint32_t waves, uint32_t sb, int fused)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    if (kernel == MAPN_KERNEL_AUTO) { c->plan_forced = false; return MAPN_OK; }
+    mapn::ForcePlan p{};
+    p.kind = kernel == MAPN_KERNEL_SCALAR ? mapn::KERNEL_SGPR : mapn::KERNEL_LDS;
+    p.k = bodies_per_lane; p.waves = waves; p.sb = sb; p.nseg = 1; p.fused = fused != 0 && sb == 1;
+    if (!mapn::force_plan_supported(p))
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "unsupported force plan kernel=%d k=%u waves=%u sb=%u", kernel, bodies_per_lane, waves, sb);
+    c->forced_plan = p;
+    c->plan_forced = true;
+    return MAPN_OK;
+}
+
+int mapn_set_timers(mapn_ctx *c, int enabled)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    if (int rc = mapn_wait_idle(c)) return rc;
+    c->timers_enabled = enabled != 0;
+    return MAPN_OK;
+}
+
+int mapn_get_kernel_stats(mapn_ctx *c, int reset, mapn_kernel_stats *out)
+{
+    if (!c || !out) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = resolve_timers(c, true)) return rc;
+    memset(out, 0, sizeof *out);
+    const uint32_t lo = c->first, hi = c->first + c->count;
+    mapn::ForcePlan p = choose_plan(c, hi - lo, c->n, 1, c->comm == nullptr);
+    snprintf(out->kernel_name, sizeof out->kernel_name, "%s", mapn::force_kernel_name(p));
+    out->launches = c->force_launches;
+    out->avg_seconds = c->force_launches ? c->force_seconds_sum / (double)c->force_launches : 0.0;
+    out->grid_x = (hi - lo + 64 * p.k - 1) / (64 * p.k);
+    out->grid_y = p.sb;
+    out->block_x = 64 * p.waves;
+    out->bodies_per_lane = p.k;
+    out->j_splits = p.sb * p.waves;
+    out->fused = p.fused ? 1u : 0u;
+    if (reset) { c->force_launches = 0; c->force_seconds_sum = 0.0; }
+    return MAPN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// mapn_kernels.h -- launch interface between the host context (mapn_context.cpp) and the
+// gfx950 kernels (mapn_kernels.hip).  Internal; the public boundary is include/mapn.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mapn {
+
+enum { KERNEL_LDS = 1, KERNEL_SGPR = 2, KERNEL_MFMA = 3 };
+enum { MAX_SEGMENTS = 3 };
+
+// One launch's view of the state.  Passed by value (kernarg segment, read through s_load).
+struct StepArgs {
+    const float4 *pos_old;    // float4[N]  read buffer  (oldPosition, hlsl:77 u1)
+    const float  *vel_old;    // float3[N]  packed, 12 B stride (oldVelocity, u4)
+    float4       *pos_new;    // write buffer (newPosition, u0)
+    float        *vel_new;    // (newVelocity, u3)
+    float4       *partial;    // [slots][partial_stride] chunk sums of the non-fused path
+    uint32_t      partial_stride;
+    uint32_t      i_first;    // bodies [i_first, i_first + i_count) advance in this launch
+    uint32_t      i_count;
+    uint32_t      seg_first[MAX_SEGMENTS];  // j-segments of pos_old this launch sums over
+    uint32_t      seg_count[MAX_SEGMENTS];
+    uint32_t      seg_slot[MAX_SEGMENTS];   // first partial slot of each segment
+    uint32_t      seg_tiles_base[MAX_SEGMENTS];  // 64-body tiles per chunk ...
+    uint32_t      seg_tiles_rem[MAX_SEGMENTS];   // ... the first `rem` chunks take one more
+    float         mass, soft2, dt, damping; // hlsl:37-38, Compute.cpp:545-546
+};
+
+// How the j-range is cut: S = sb * waves chunks per segment.
+struct ForcePlan {
+    int      kind;     // KERNEL_*
+    uint32_t k;        // bodies per lane (2, 4 or 8: packed fp32 handles them in pairs)
+    uint32_t waves;    // waves per workgroup (j-split inside the workgroup)
+    uint32_t sb;       // j-split across workgroups (gridDim.y)
+    uint32_t nseg;     // gridDim.z
+    bool     fused;    // integrator fused (requires sb == 1, nseg == 1)
+};
+
+bool force_plan_supported(const ForcePlan &plan);
+hipError_t launch_force(const ForcePlan &plan, const StepArgs &a, hipStream_t st);
+hipError_t launch_reduce_integrate(const StepArgs &a, uint32_t slots, hipStream_t st);
+hipError_t launch_central_well(const StepArgs &a, hipStream_t st);
+const char *force_kernel_name(const ForcePlan &plan);
+
+}  // namespace mapn

@@ -1,0 +1,392 @@
+// mapn_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the n-body step.
+//
+// What the reference dispatches: CSMain, reference/Particles/nBodyGravityCS.hlsl:85-109, one
+// thread per body in groups of 64 (Compute.cpp:1041).  The all-pairs force is that kernel's
+// integrator (:103-108) fed by the sum of bodyBodyInteraction (:44-57) over all bodies of the
+// old position buffer.
+//
+// Design (see DESIGN.md "Kernels"):
+//   * a lane owns K bodies i (registers), a wave walks a contiguous j-chunk; the j-range of a
+//     launch is split S = gridDim.y * WAVES ways so that N = 65 536 still fills 1024 SIMDs
+//     with several waves each;
+//   * j-bodies reach the lanes either through a wave-private, double-buffered LDS tile
+//     (coalesced global_load_dwordx4 -> ds_write_b128, then broadcast ds_read_b128), or
+//     through the scalar cache (s_load_dwordx8/x16 -> SGPR operands of the VALU ops);
+//   * per pair: 3 sub, 3 fma, v_rsq_f32, 2 mul, 3 fma  (mass hoisted out of the sum);
+//   * the S partial sums of a body are combined in FIXED ascending chunk order (LDS inside a
+//     workgroup, a scratch buffer across workgroups) -- no float atomics, so a run is
+//     bit-reproducible;
+//   * the kick-drift integrator is fused into the force kernel when one workgroup sees all of
+//     a body's chunks, else it runs as a small second kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mapn_kernels.h"
+
+namespace mapn {
+
+// ---------------------------------------------------------------------------------------------
+// shared device helpers
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// accumulators of TWO bodies i, one per half of a 64-bit register pair, so that every VALU op of
+// the pair term except v_rsq_f32 is a packed-fp32 instruction (v_pk_add/mul/fma_f32).
+// Measured on MI355X (tools/ubench.hip, profiles/r01_ubench.txt): the packed form of the
+// 12-op pair term sustains 4.9e12 pairs/s against 3.8e12 for scalar fp32 ops.
+struct Acc2 { v2f x, y, z; };
+
+// one softened pair term for two bodies i against one body j, without the mass factor:
+//   acc += r * (|r|^2 + soft2)^(-3/2)         (nBodyGravityCS.hlsl:46-56)
+// mass * particles (hlsl:54) is applied once after the sum.  13 VALU instructions per 2 pairs:
+// 3 v_pk_add (x_j broadcast by op_sel), 3 v_pk_fma, 2 v_rsq, 2 v_pk_mul, 3 v_pk_fma.
+__device__ __forceinline__ void pair_term2(Acc2 &a, v2f xi, v2f yi, v2f zi, float xj, float yj,
+                                           float zj, v2f soft2)
+{
+    const v2f dx = xj - xi;
+    const v2f dy = yj - yi;
+    const v2f dz = zj - zi;
+    v2f d = __builtin_elementwise_fma(dx, dx, soft2);
+    d = __builtin_elementwise_fma(dy, dy, d);
+    d = __builtin_elementwise_fma(dz, dz, d);
+    v2f inv;
+    inv.x = __builtin_amdgcn_rsqf(d.x);
+    inv.y = __builtin_amdgcn_rsqf(d.y);
+    const v2f inv3 = inv * inv * inv;
+    a.x = __builtin_elementwise_fma(dx, inv3, a.x);
+    a.y = __builtin_elementwise_fma(dy, inv3, a.y);
+    a.z = __builtin_elementwise_fma(dz, inv3, a.z);
+}
+
+// nBodyGravityCS.hlsl:103-108: kick, damp, drift; w = |accel|
+__device__ __forceinline__ void integrate_store(const StepArgs &p, uint32_t i, float4 pos,
+                                                float ax, float ay, float az)
+{
+    const float *v = p.vel_old + 3 * (size_t)i;
+    float vx = v[0], vy = v[1], vz = v[2];
+    vx = __builtin_fmaf(ax, p.dt, vx) * p.damping;
+    vy = __builtin_fmaf(ay, p.dt, vy) * p.damping;
+    vz = __builtin_fmaf(az, p.dt, vz) * p.damping;
+    float4 o;
+    o.x = __builtin_fmaf(vx, p.dt, pos.x);
+    o.y = __builtin_fmaf(vy, p.dt, pos.y);
+    o.z = __builtin_fmaf(vz, p.dt, pos.z);
+    o.w = __builtin_sqrtf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)));
+    p.pos_new[i] = o;
+    float *vo = p.vel_new + 3 * (size_t)i;
+    vo[0] = vx; vo[1] = vy; vo[2] = vz;
+}
+
+// Blocks are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an L2).  Remap the linear
+// block id so that the blocks sharing an XCD walk the SAME j-chunk rows: each XCD's 4 MiB L2
+// then holds 1/8 of the j-range instead of all of it (matters from N = 262 144 up, where the
+// position buffer no longer fits one L2).  Speed only, never correctness.
+__device__ __forceinline__ void xcd_remap(uint32_t &bx, uint32_t &by)
+{
+    const uint32_t gx = gridDim.x, gy = gridDim.y;
+    if ((gy & 7u) == 0u) {
+        const uint32_t lin = blockIdx.y * gx + blockIdx.x;
+        const uint32_t xcd = lin & 7u, slot = lin >> 3;
+        const uint32_t rows_per_xcd = gy >> 3;
+        bx = slot / rows_per_xcd;
+        by = xcd * rows_per_xcd + (slot - bx * rows_per_xcd);
+    } else {
+        bx = blockIdx.x; by = blockIdx.y;
+    }
+}
+
+// tiles of 64 j-bodies [t0, t1) that chunk c owns: the host splits the segment's tiles into S
+// chunks of seg_tiles_base tiles, the first seg_tiles_rem chunks taking one more.
+__device__ __forceinline__ void chunk_tiles(const StepArgs &p, uint32_t seg, uint32_t c, uint32_t &t0,
+                                            uint32_t &t1)
+{
+    const uint32_t base = p.seg_tiles_base[seg], rem = p.seg_tiles_rem[seg];
+    t0 = c * base + min(c, rem);
+    t1 = t0 + base + (c < rem ? 1u : 0u);
+}
+
+template <int K2>
+struct Bodies {
+    v2f xi[K2], yi[K2], zi[K2];
+    Acc2 acc[K2];
+};
+
+// lane's 2*K2 bodies: element e of pair k is local body (bx*2*K2 + 2*k + e)*64 + lane
+template <int K2>
+__device__ __forceinline__ void load_bodies(Bodies<K2> &b, const StepArgs &p, uint32_t bx, uint32_t lane)
+{
+#pragma unroll
+    for (int k = 0; k < K2; k++) {
+        uint32_t l0 = (bx * (2 * K2) + 2 * k) * 64u + lane, l1 = l0 + 64u;
+        l0 = l0 < p.i_count ? l0 : (p.i_count - 1u);      // clamp: tail lanes redo a valid body
+        l1 = l1 < p.i_count ? l1 : (p.i_count - 1u);
+        const float4 b0 = p.pos_old[p.i_first + l0], b1 = p.pos_old[p.i_first + l1];
+        b.xi[k] = v2f{b0.x, b1.x}; b.yi[k] = v2f{b0.y, b1.y}; b.zi[k] = v2f{b0.z, b1.z};
+        b.acc[k] = Acc2{v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+    }
+}
+
+// epilogue shared by both force kernels
+template <int K2, int WAVES, bool FUSED>
+__device__ __forceinline__ void finish(const Bodies<K2> &b, const StepArgs &p, uint32_t bx, uint32_t w,
+                                       uint32_t lane, uint32_t seg, uint32_t c,
+                                       float (*red)[3][128 * K2])
+{
+    if constexpr (FUSED) {
+        // fixed-order combine of the WAVES chunk sums in LDS, then integrate in place
+#pragma unroll
+        for (int k = 0; k < K2; k++) {
+            red[w][0][(2 * k) * 64 + lane] = b.acc[k].x.x; red[w][0][(2 * k + 1) * 64 + lane] = b.acc[k].x.y;
+            red[w][1][(2 * k) * 64 + lane] = b.acc[k].y.x; red[w][1][(2 * k + 1) * 64 + lane] = b.acc[k].y.y;
+            red[w][2][(2 * k) * 64 + lane] = b.acc[k].z.x; red[w][2][(2 * k + 1) * 64 + lane] = b.acc[k].z.y;
+        }
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < 128u * K2; e += 64u * WAVES) {
+            const uint32_t li = bx * (128u * K2) + e;
+            if (li < p.i_count) {
+                float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < WAVES; ww++) { ax += red[ww][0][e]; ay += red[ww][1][e]; az += red[ww][2][e]; }
+                const uint32_t i = p.i_first + li;
+                integrate_store(p, i, p.pos_old[i], ax * p.mass, ay * p.mass, az * p.mass);
+            }
+        }
+    } else {
+        // partial[slot][i_local], slot = seg_slot[seg] + c ; coalesced float4 stores
+        float4 *out = p.partial + (size_t)(p.seg_slot[seg] + c) * p.partial_stride;
+#pragma unroll
+        for (int k = 0; k < K2; k++) {
+            const uint32_t l0 = (bx * (2 * K2) + 2 * k) * 64u + lane, l1 = l0 + 64u;
+            if (l0 < p.i_count) out[l0] = make_float4(b.acc[k].x.x, b.acc[k].y.x, b.acc[k].z.x, 0.f);
+            if (l1 < p.i_count) out[l1] = make_float4(b.acc[k].x.y, b.acc[k].y.y, b.acc[k].z.y, 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// all-pairs force, LDS-tiled
+//
+// grid  = (ceil(i_count / (128*K2)), SB, nseg)      block = 64 * WAVES
+// wave w of block (bx, by, z) accumulates its lanes' 2*K2 bodies against chunk c = by*WAVES + w
+// of segment z.  A tile of 64 j-bodies is fetched with one coalesced global_load_dwordx4 per
+// lane and written to a WAVE-PRIVATE LDS slot (no s_barrier in the loop), split as
+//   xy[32] = (x0,y0,x1,y1) per two bodies,  zz[16] = (z0,z1,z2,z3) per four bodies,
+// so that four j-bodies cost three broadcast ds_read_b128 (3 LDS cycles per j per wave instead
+// of 8 for the ds_read_b96 the float4 layout compiles to) and x_j / y_j / z_j always sit in
+// the low or high half of an aligned register pair, which v_pk_*_f32 selects with op_sel for
+// free.  The next tile's global load is in flight while the current tile is consumed.
+template <int K2, int WAVES, bool FUSED>
+__global__ __launch_bounds__(64 * WAVES) void force_lds_kernel(const StepArgs p)
+{
+    __shared__ float4 tile_xy[WAVES][2][32];
+    __shared__ float4 tile_zz[WAVES][2][16];
+    __shared__ float red[FUSED ? WAVES : 1][3][128 * K2];
+
+    uint32_t bx, by;
+    xcd_remap(bx, by);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t seg = blockIdx.z;
+    const uint32_t c = by * WAVES + w;
+    const uint32_t j_first = p.seg_first[seg], j_count = p.seg_count[seg];
+    const float4 *__restrict__ pos = p.pos_old;
+
+    Bodies<K2> b;
+    load_bodies<K2>(b, p, bx, lane);
+
+    uint32_t t0, t1;
+    chunk_tiles(p, seg, c, t0, t1);
+    const v2f soft2 = v2f{p.soft2, p.soft2};
+
+    if (t0 < t1) {
+        float4 cur;
+        {
+            uint32_t j = t0 * 64u + lane;
+            j = j < j_count ? j : (j_count - 1u);
+            cur = pos[j_first + j];
+        }
+        for (uint32_t t = t0; t < t1; t++) {
+            const uint32_t buf = (t - t0) & 1u;
+            float2 *wxy = reinterpret_cast<float2 *>(tile_xy[w][buf]);
+            float *wz = reinterpret_cast<float *>(tile_zz[w][buf]);
+            wxy[lane] = make_float2(cur.x, cur.y);             // ds_write_b64
+            wz[lane] = cur.z;                                  // ds_write_b32
+            // prefetch the next tile into registers while this one is consumed
+            if (t + 1u < t1) {
+                uint32_t j = (t + 1u) * 64u + lane;
+                j = j < j_count ? j : (j_count - 1u);
+                cur = pos[j_first + j];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t nj = min(64u, j_count - t * 64u);   // wave-uniform; < 64 only on a segment's last tile
+            const float4 *txy = tile_xy[w][buf];
+            const float4 *tzz = tile_zz[w][buf];
+            if (nj == 64u) {
+#pragma unroll 2
+                for (int q = 0; q < 16; q++) {
+                    const float4 zz = tzz[q];                  // ds_read_b128, every lane the same address
+                    const float4 xa = txy[2 * q], xb = txy[2 * q + 1];
+#pragma unroll
+                    for (int k = 0; k < K2; k++) pair_term2(b.acc[k], b.xi[k], b.yi[k], b.zi[k], xa.x, xa.y, zz.x, soft2);
+#pragma unroll
+                    for (int k = 0; k < K2; k++) pair_term2(b.acc[k], b.xi[k], b.yi[k], b.zi[k], xa.z, xa.w, zz.y, soft2);
+#pragma unroll
+                    for (int k = 0; k < K2; k++) pair_term2(b.acc[k], b.xi[k], b.yi[k], b.zi[k], xb.x, xb.y, zz.z, soft2);
+#pragma unroll
+                    for (int k = 0; k < K2; k++) pair_term2(b.acc[k], b.xi[k], b.yi[k], b.zi[k], xb.z, xb.w, zz.w, soft2);
+                }
+            } else {
+                const float2 *sxy = reinterpret_cast<const float2 *>(txy);
+                const float *sz = reinterpret_cast<const float *>(tzz);
+                for (uint32_t jj = 0; jj < nj; jj++) {
+                    const float2 xy = sxy[jj];
+                    const float z = sz[jj];
+#pragma unroll
+                    for (int k = 0; k < K2; k++) pair_term2(b.acc[k], b.xi[k], b.yi[k], b.zi[k], xy.x, xy.y, z, soft2);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    finish<K2, WAVES, FUSED>(b, p, bx, w, lane, seg, c, red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// all-pairs force, j-bodies through the scalar cache (no LDS, no VGPRs for j)
+//
+// Same decomposition as force_lds_kernel.  pos[j] with a wave-uniform j compiles to
+// s_load_dwordx8/x16 and the packed VALU ops take (x_j,y_j) / (z_j,w_j) as their one SGPR-pair
+// source, op_sel picking the half.  A/B alternative to the LDS path.
+template <int K2, int WAVES, bool FUSED>
+__global__ __launch_bounds__(64 * WAVES) void force_sgpr_kernel(const StepArgs p)
+{
+    __shared__ float red[FUSED ? WAVES : 1][3][128 * K2];
+
+    uint32_t bx, by;
+    xcd_remap(bx, by);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t seg = blockIdx.z;
+    const uint32_t c = by * WAVES + w;
+    const uint32_t j_first = p.seg_first[seg], j_count = p.seg_count[seg];
+
+    Bodies<K2> b;
+    load_bodies<K2>(b, p, bx, lane);
+
+    uint32_t t0, t1;
+    chunk_tiles(p, seg, c, t0, t1);
+    const v2f soft2 = v2f{p.soft2, p.soft2};
+    const uint32_t j1 = min(t1 * 64u, j_count);
+    const float4 *__restrict__ pj = p.pos_old + j_first;
+
+    uint32_t j = t0 * 64u;
+    for (; j + 8u <= j1; j += 8u) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float4 bj = pj[j + u];                       // uniform address -> s_load
+#pragma unroll
+            for (int k = 0; k < K2; k++) pair_term2(b.acc[k], b.xi[k], b.yi[k], b.zi[k], bj.x, bj.y, bj.z, soft2);
+        }
+    }
+    for (; j < j1; j++) {
+        const float4 bj = pj[j];
+#pragma unroll
+        for (int k = 0; k < K2; k++) pair_term2(b.acc[k], b.xi[k], b.yi[k], b.zi[k], bj.x, bj.y, bj.z, soft2);
+    }
+    finish<K2, WAVES, FUSED>(b, p, bx, w, lane, seg, c, red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// combine the partial sums of a body in ascending slot order, then integrate (second kernel of
+// the non-fused path).  HBM-bound: (16*slots + 28) B read + 28 B written per body.
+__global__ __launch_bounds__(256) void reduce_integrate_kernel(const StepArgs p, uint32_t slots)
+{
+    const uint32_t li = blockIdx.x * 256u + threadIdx.x;
+    if (li >= p.i_count) return;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    const float4 *in = p.partial + li;
+    for (uint32_t s = 0; s < slots; s++) {
+        const float4 a = in[(size_t)s * p.partial_stride];
+        ax += a.x; ay += a.y; az += a.z;
+    }
+    const uint32_t i = p.i_first + li;
+    integrate_store(p, i, p.pos_old[i], ax * p.mass, ay * p.mass, az * p.mass);
+}
+
+// ---------------------------------------------------------------------------------------------
+// CSMain exactly as shipped (nBodyGravityCS.hlsl:86-109): one gravity well at the origin.
+// HBM-bound, 56 B per body.  One thread per body like the reference.
+__global__ __launch_bounds__(256) void central_well_kernel(const StepArgs p)
+{
+    const uint32_t li = blockIdx.x * 256u + threadIdx.x;
+    if (li >= p.i_count) return;
+    const uint32_t i = p.i_first + li;
+    const float4 pos = p.pos_old[i];
+    float d = __builtin_fmaf(pos.x, pos.x, p.soft2);     // :94-95
+    d = __builtin_fmaf(pos.y, pos.y, d);
+    d = __builtin_fmaf(pos.z, pos.z, d);
+    const float inv = -__builtin_amdgcn_rsqf(d);         // :97
+    const float s = p.mass * (inv * inv * inv);          // :98-99
+    integrate_store(p, i, pos, pos.x * s, pos.y * s, pos.z * s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launch table
+
+template <int K2, int WAVES>
+static hipError_t launch_force_variant(int kind, bool fused, dim3 grid, const StepArgs &a, hipStream_t st)
+{
+    const dim3 block(64 * WAVES);
+    if (kind == KERNEL_LDS) {
+        if (fused) hipLaunchKernelGGL((force_lds_kernel<K2, WAVES, true>), grid, block, 0, st, a);
+        else       hipLaunchKernelGGL((force_lds_kernel<K2, WAVES, false>), grid, block, 0, st, a);
+    } else {
+        if (fused) hipLaunchKernelGGL((force_sgpr_kernel<K2, WAVES, true>), grid, block, 0, st, a);
+        else       hipLaunchKernelGGL((force_sgpr_kernel<K2, WAVES, false>), grid, block, 0, st, a);
+    }
+    return hipGetLastError();
+}
+
+bool force_plan_supported(const ForcePlan &plan)
+{
+    if (plan.kind != KERNEL_LDS && plan.kind != KERNEL_SGPR) return false;
+    if (plan.k != 2 && plan.k != 4 && plan.k != 8) return false;
+    if (plan.waves != 1 && plan.waves != 2 && plan.waves != 4 && plan.waves != 8 && plan.waves != 16) return false;
+    if (plan.k == 8 && plan.waves == 16) return false;
+    if (plan.fused && (plan.sb != 1 || plan.nseg != 1)) return false;
+    return plan.sb >= 1 && plan.nseg >= 1 && plan.nseg <= MAX_SEGMENTS;
+}
+
+hipError_t launch_force(const ForcePlan &plan, const StepArgs &a, hipStream_t st)
+{
+    if (!force_plan_supported(plan)) return hipErrorInvalidConfiguration;
+    const uint32_t per_block = 64u * plan.k;
+    const dim3 grid((a.i_count + per_block - 1) / per_block, plan.sb, plan.nseg);
+    const bool fused = plan.fused;
+#define MAPN_CASE(KK, WW) \
+    if (plan.k == 2 * KK && plan.waves == WW) return launch_force_variant<KK, WW>(plan.kind, fused, grid, a, st);
+    MAPN_CASE(1, 1) MAPN_CASE(1, 2) MAPN_CASE(1, 4) MAPN_CASE(1, 8) MAPN_CASE(1, 16)
+    MAPN_CASE(2, 1) MAPN_CASE(2, 2) MAPN_CASE(2, 4) MAPN_CASE(2, 8) MAPN_CASE(2, 16)
+    MAPN_CASE(4, 1) MAPN_CASE(4, 2) MAPN_CASE(4, 4) MAPN_CASE(4, 8)
+#undef MAPN_CASE
+    return hipErrorInvalidConfiguration;
+}
+
+hipError_t launch_reduce_integrate(const StepArgs &a, uint32_t slots, hipStream_t st)
+{
+    hipLaunchKernelGGL(reduce_integrate_kernel, dim3((a.i_count + 255u) / 256u), dim3(256), 0, st, a, slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_central_well(const StepArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(central_well_kernel, dim3((a.i_count + 255u) / 256u), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+const char *force_kernel_name(const ForcePlan &plan)
+{
+    return plan.kind == KERNEL_LDS ? "force_lds_kernel" : "force_sgpr_kernel";
+}
+
+}  // namespace mapn

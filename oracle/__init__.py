@@ -1,0 +1,155 @@
+"""CPU oracle for the n-body step.  TEST INFRASTRUCTURE ONLY -- the checker, never the product.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package.  Parity is UNPINNED by the reference (it has no tests or golden vectors, and cannot
+be built here); see ``mapn_oracle.c`` for the line-by-line citations this restatement follows.
+
+``Oracle`` wraps ``_build/libmapn_oracle.so`` (fp32, exact op order of the HLSL);
+``model_fp64`` is an independent numpy float64 model used as a second opinion on small N.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libmapn_oracle.so")
+_SRC = os.path.join(_HERE, "mapn_oracle.c")
+
+MODE_ALL_PAIRS = 0
+MODE_CENTRAL_WELL = 1
+
+
+class Params(C.Structure):
+    """nBodyGravityCS.hlsl:37-38 and Compute.cpp:545-546 defaults."""
+
+    _fields_ = [("mass", C.c_float), ("soft2", C.c_float), ("dt", C.c_float), ("damping", C.c_float)]
+
+    def __init__(self, mass=70000.0, soft2=25.0, dt=0.1, damping=1.0):
+        super().__init__(mass, soft2, dt, damping)
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement (gcc is in the image on both the CPU and the GPU box)."""
+    stale = (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(_SRC)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
+    return _SO
+
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = lib = C.CDLL(build())
+        lib.mapn_oracle_pair_term.argtypes = [_f32p, _f32p, _f32p, C.c_float, C.c_int, C.c_float]
+        lib.mapn_oracle_pair_term.restype = None
+        lib.mapn_oracle_step_central_well.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.POINTER(Params)]
+        lib.mapn_oracle_step_central_well.restype = None
+        lib.mapn_oracle_step_all_pairs.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int]
+        lib.mapn_oracle_step_all_pairs.restype = C.c_int
+        lib.mapn_oracle_accel_all_pairs.argtypes = [_f32p, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
+        lib.mapn_oracle_accel_all_pairs.restype = C.c_int
+        lib.mapn_oracle_simulate.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(Params), C.c_int]
+        lib.mapn_oracle_simulate.restype = C.c_uint32
+        lib.mapn_oracle_active_bodies.argtypes = [C.c_int, C.c_uint32]
+        lib.mapn_oracle_active_bodies.restype = C.c_uint32
+        lib.mapn_oracle_fast_rand.argtypes = [C.POINTER(C.c_uint32)]
+        lib.mapn_oracle_fast_rand.restype = C.c_int
+        lib.mapn_oracle_srand_sse.argtypes = [C.POINTER(C.c_uint32 * 4), C.c_uint32]
+        lib.mapn_oracle_srand_sse.restype = None
+        lib.mapn_oracle_rand_sse.argtypes = [C.POINTER(C.c_uint32 * 4), C.POINTER(C.c_int * 4)]
+        lib.mapn_oracle_rand_sse.restype = None
+        lib.mapn_oracle_initial_state.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.c_float, _f32p, _f32p]
+        lib.mapn_oracle_initial_state.restype = None
+        lib.mapn_oracle_cbuffer.argtypes = [C.c_uint32, C.POINTER(C.c_uint32 * 4), C.POINTER(C.c_float * 4)]
+        lib.mapn_oracle_cbuffer.restype = None
+        lib.mapn_oracle_hardware_threads.restype = C.c_int
+
+    # -- scalar pieces -------------------------------------------------------------------
+    def pair_term(self, ai, bj, bi, mass=70000.0, particles=1, soft2=25.0):
+        ai = np.array(ai, dtype=np.float32)
+        self.lib.mapn_oracle_pair_term(ai, np.asarray(bj, np.float32), np.asarray(bi, np.float32), mass, particles, soft2)
+        return ai
+
+    def active_bodies(self, num_active, n):
+        return int(self.lib.mapn_oracle_active_bodies(int(num_active), int(n)))
+
+    def fast_rand(self, seed, count):
+        st = C.c_uint32(seed)
+        return [self.lib.mapn_oracle_fast_rand(C.byref(st)) for _ in range(count)]
+
+    def rand_sse(self, seed, calls):
+        st = (C.c_uint32 * 4)()
+        self.lib.mapn_oracle_srand_sse(C.byref(st), seed)
+        out = []
+        for _ in range(calls):
+            o = (C.c_int * 4)()
+            self.lib.mapn_oracle_rand_sse(C.byref(st), C.byref(o))
+            out.append(list(o))
+        return out
+
+    def cbuffer(self, n):
+        p, f = (C.c_uint32 * 4)(), (C.c_float * 4)()
+        self.lib.mapn_oracle_cbuffer(n, C.byref(p), C.byref(f))
+        return list(p), np.array(list(f), np.float32)
+
+    def hardware_threads(self):
+        return int(self.lib.mapn_oracle_hardware_threads())
+
+    # -- state ---------------------------------------------------------------------------
+    def initial_state(self, n, seed=1, spread=400.0, speed=15.0):
+        pos = np.zeros((n, 4), np.float32)
+        vel = np.zeros((n, 3), np.float32)
+        self.lib.mapn_oracle_initial_state(seed, n, spread, speed, pos, vel)
+        return pos, vel
+
+    def accel_all_pairs(self, pos, first=0, count=None, mass=70000.0, soft2=25.0):
+        n = pos.shape[0]
+        count = n - first if count is None else count
+        out = np.zeros((count, 3), np.float32)
+        self.lib.mapn_oracle_accel_all_pairs(np.ascontiguousarray(pos, np.float32), out, n, first, count, mass, soft2)
+        return out
+
+    def step_slice(self, pos, vel, first, count, mode=MODE_ALL_PAIRS, params=None, threads=0):
+        """Advance bodies [first, first+count) only; returns (new_pos_slice, new_vel_slice)."""
+        params = params or Params()
+        pos = np.ascontiguousarray(pos, np.float32)
+        vel = np.ascontiguousarray(vel, np.float32)
+        npos, nvel = pos.copy(), vel.copy()
+        if count:
+            if mode == MODE_CENTRAL_WELL:
+                self.lib.mapn_oracle_step_central_well(pos, vel, npos, nvel, first, count, C.byref(params))
+            else:
+                self.lib.mapn_oracle_step_all_pairs(pos, vel, npos, nvel, pos.shape[0], first, count, C.byref(params), threads)
+        return npos[first:first + count].copy(), nvel[first:first + count].copy()
+
+
+class OracleSim:
+    """Host-array twin of the reference's ``Compute`` object: two ping-pong buffer pairs, a
+    buffer index and ``simulate(num_active)`` with Compute.cpp:1009-1055 semantics."""
+
+    def __init__(self, oracle: Oracle, pos, vel, mode=MODE_ALL_PAIRS, params=None, threads=0):
+        self.o = oracle
+        self.n = pos.shape[0]
+        self.pos = [np.array(pos, np.float32, order="C"), np.array(pos, np.float32, order="C")]   # Compute.cpp:881-882
+        self.vel = [np.array(vel, np.float32, order="C"), np.array(vel, np.float32, order="C")]   # Compute.cpp:903-904
+        self.buffer_index = 0                                                                     # Compute.cpp:80
+        self.mode, self.params, self.threads = mode, params or Params(), threads
+
+    def simulate(self, num_active=None, steps=1):
+        num_active = self.n if num_active is None else num_active
+        for _ in range(steps):
+            self.buffer_index = int(self.o.lib.mapn_oracle_simulate(
+                self.pos[0], self.pos[1], self.vel[0], self.vel[1], self.buffer_index, self.n,
+                num_active, self.mode, C.byref(self.params), self.threads))
+
+    @property
+    def latest(self):
+        """(pos, vel) most recently written = buffer 1 - buffer_index after the flip."""
+        r = 1 - self.buffer_index
+        return self.pos[r], self.vel[r]

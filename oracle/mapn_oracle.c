@@ -1,0 +1,379 @@
+/*
+ * mapn_oracle.c -- CPU restatement of the n-body compute step.   TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the checker, never the product.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  The shipped library (libmapn.so) does not link,
+ * load or call anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference tree (/root/reference) holds no tests, golden vectors or
+ * fixtures for this path, has no CPU simulation path, and cannot be compiled here (Compute.cpp:31
+ * needs <ppl.h>, D3D12, DirectXMath; the step itself exists only as HLSL).  This restatement
+ * follows the reference text line by line instead; the known answers it is checked against
+ * (tests/test_oracle_kat.py) are derived from that text by hand.
+ *
+ * What is restated, with the reference lines each function follows (paths relative to
+ * /root/reference/Particles/):
+ *   pair term                nBodyGravityCS.hlsl:44-57   (bodyBodyInteraction)
+ *   central-well force       nBodyGravityCS.hlsl:92-101  (CSMain as shipped)
+ *   integrator + outputs     nBodyGravityCS.hlsl:103-108
+ *   constants                nBodyGravityCS.hlsl:37-38, Compute.cpp:542-546, defines.h:37,39,42
+ *   active-count rounding    Compute.cpp:1041            (groups of 64, no in-shader bound)
+ *   initial state            Compute.cpp:820-844 (two halves), :711-749 (LCG variant), :599-609
+ *   LCG known answers        Compute.cpp:599-609 (fast_rand), :622-661 (rand_sse)
+ *
+ * Arithmetic contract: every operation is a separately rounded IEEE-754 binary32 operation in
+ * the order the HLSL source writes it (build with -ffp-contract=off, no -ffast-math).  The
+ * all-pairs sum runs over j = 0..N-1 ascending into ONE accumulator per component.  The code is
+ * vectorised across i (16 bodies per block), never across j, so the result is bit-identical to
+ * a scalar loop on any x86-64 CPU.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#define MAPN_ORACLE_BLOCK 64 /* defines.h:37 BLOCK_SIZE */
+#define IB 16                /* i-bodies per vector block */
+
+typedef struct {
+    float mass;     /* nBodyGravityCS.hlsl:38 g_fParticleMass (default 70000) */
+    float soft2;    /* nBodyGravityCS.hlsl:37 softeningSquared (default 25)  */
+    float dt;       /* Compute.cpp:545 paramf[0] = 0.1f */
+    float damping;  /* Compute.cpp:546 paramf[1] = 1.0f */
+} mapn_oracle_params;
+
+void mapn_oracle_default_params(mapn_oracle_params *p)
+{
+    p->mass = 70000.0f;
+    p->soft2 = 25.0f;
+    p->dt = 0.1f;
+    p->damping = 1.0f;
+}
+
+/* Compute.cpp:542-546 -- the 32-byte constant block uploaded at init (K8). */
+void mapn_oracle_cbuffer(uint32_t num_particles, uint32_t out_param[4], float out_paramf[4])
+{
+    out_param[0] = num_particles;
+    out_param[1] = (uint32_t)(int)ceilf((float)num_particles / (float)MAPN_ORACLE_BLOCK);
+    out_param[2] = 0;
+    out_param[3] = 0;
+    out_paramf[0] = 0.1f;
+    out_paramf[1] = 1.0f;
+    out_paramf[2] = 0.0f;
+    out_paramf[3] = 0.0f;
+}
+
+/* Compute.cpp:1041 -- Dispatch(ceil(numActive/64)) x 64 threads, D3D drops out-of-range writes. */
+uint32_t mapn_oracle_active_bodies(int num_active, uint32_t num_particles)
+{
+    if (num_active <= 0) return 0;
+    uint64_t groups = ((uint64_t)num_active + MAPN_ORACLE_BLOCK - 1) / MAPN_ORACLE_BLOCK;
+    uint64_t n = groups * MAPN_ORACLE_BLOCK;
+    return (uint32_t)(n < num_particles ? n : num_particles);
+}
+
+/* nBodyGravityCS.hlsl:44-57 -- one softened pair term; bj.w / bi.w ignored; no i != j test. */
+void mapn_oracle_pair_term(float ai[3], const float bj[4], const float bi[4], float mass,
+                           int particles, float soft2)
+{
+    float rx = bj[0] - bi[0];                       /* :46 */
+    float ry = bj[1] - bi[1];
+    float rz = bj[2] - bi[2];
+    float d = rx * rx + ry * ry;                    /* :48 dot(r,r) */
+    d = d + rz * rz;
+    d = d + soft2;                                  /* :49 */
+    float inv = 1.0f / sqrtf(d);                    /* :51 */
+    float inv3 = inv * inv * inv;                   /* :52 */
+    float s = mass * inv3 * (float)particles;       /* :54 */
+    ai[0] = ai[0] + rx * s;                         /* :56 */
+    ai[1] = ai[1] + ry * s;
+    ai[2] = ai[2] + rz * s;
+}
+
+/* nBodyGravityCS.hlsl:103-108 -- kick, damp, drift; w = |accel|. */
+static inline void integrate(const float *pos, const float *vel, float ax, float ay, float az,
+                             const mapn_oracle_params *p, float *npos, float *nvel)
+{
+    float vx = vel[0] + ax * p->dt;                 /* :103 */
+    float vy = vel[1] + ay * p->dt;
+    float vz = vel[2] + az * p->dt;
+    vx = vx * p->damping;                           /* :104 */
+    vy = vy * p->damping;
+    vz = vz * p->damping;
+    float px = pos[0] + vx * p->dt;                 /* :105 */
+    float py = pos[1] + vy * p->dt;
+    float pz = pos[2] + vz * p->dt;
+    float l = ax * ax + ay * ay;
+    l = l + az * az;
+    npos[0] = px;                                   /* :107 float4(pos.xyz, length(accel)) */
+    npos[1] = py;
+    npos[2] = pz;
+    npos[3] = sqrtf(l);
+    nvel[0] = vx;                                   /* :108 */
+    nvel[1] = vy;
+    nvel[2] = vz;
+}
+
+/*
+ * CSMain exactly as shipped (nBodyGravityCS.hlsl:86-109): one gravity well at the origin.
+ * Advances bodies [first, first+count) from (old_pos, old_vel) into (new_pos, new_vel).
+ * pos: float4 stride 16 (Render.h:85-88); vel: packed float3 stride 12 (Compute.h:66-69).
+ */
+void mapn_oracle_step_central_well(const float *old_pos, const float *old_vel, float *new_pos,
+                                   float *new_vel, uint32_t first, uint32_t count,
+                                   const mapn_oracle_params *p)
+{
+    for (uint32_t i = first; i < first + count; i++) {
+        const float *pos = old_pos + 4 * (size_t)i;
+        float rx = pos[0], ry = pos[1], rz = pos[2];    /* :92 */
+        float d = rx * rx + ry * ry;                    /* :94 */
+        d = d + rz * rz;
+        d = d + p->soft2;                               /* :95 */
+        float inv = -1.0f / sqrtf(d);                   /* :97 */
+        float inv3 = inv * inv * inv;                   /* :98 */
+        float s = p->mass * inv3;                       /* :99 */
+        integrate(pos, old_vel + 3 * (size_t)i, rx * s, ry * s, rz * s, p,
+                  new_pos + 4 * (size_t)i, new_vel + 3 * (size_t)i);
+    }
+}
+
+typedef struct {
+    const float *old_pos, *old_vel;
+    float *new_pos, *new_vel;
+    uint32_t n_total, first, count;
+    const mapn_oracle_params *p;
+    uint32_t tid, nthreads;
+} ap_job;
+
+/* bodies [b0, b0+nb) (nb <= IB) against j = 0..n_total-1 ascending, one accumulator each */
+static void all_pairs_block(const ap_job *J, uint32_t b0, uint32_t nb)
+{
+    float xi[IB], yi[IB], zi[IB], ax[IB], ay[IB], az[IB];
+    const float mass = J->p->mass, soft2 = J->p->soft2;
+    for (uint32_t k = 0; k < IB; k++) {
+        uint32_t i = b0 + (k < nb ? k : 0);
+        xi[k] = J->old_pos[4 * (size_t)i + 0];
+        yi[k] = J->old_pos[4 * (size_t)i + 1];
+        zi[k] = J->old_pos[4 * (size_t)i + 2];
+        ax[k] = ay[k] = az[k] = 0.0f;
+    }
+    const float *pj = J->old_pos;
+    for (uint32_t j = 0; j < J->n_total; j++, pj += 4) {
+        const float xj = pj[0], yj = pj[1], zj = pj[2];
+#pragma GCC ivdep
+        for (int k = 0; k < IB; k++) {             /* the pair term, hlsl:44-57, particles = 1 */
+            float rx = xj - xi[k];
+            float ry = yj - yi[k];
+            float rz = zj - zi[k];
+            float d = rx * rx + ry * ry;
+            d = d + rz * rz;
+            d = d + soft2;
+            float inv = 1.0f / sqrtf(d);
+            float inv3 = inv * inv * inv;
+            float s = mass * inv3 * 1.0f;
+            ax[k] = ax[k] + rx * s;
+            ay[k] = ay[k] + ry * s;
+            az[k] = az[k] + rz * s;
+        }
+    }
+    for (uint32_t k = 0; k < nb; k++) {
+        uint32_t i = b0 + k;
+        integrate(J->old_pos + 4 * (size_t)i, J->old_vel + 3 * (size_t)i, ax[k], ay[k], az[k],
+                  J->p, J->new_pos + 4 * (size_t)i, J->new_vel + 3 * (size_t)i);
+    }
+}
+
+static void *all_pairs_worker(void *arg)
+{
+    const ap_job *J = (const ap_job *)arg;
+    uint32_t nblocks = (J->count + IB - 1) / IB;
+    for (uint32_t b = J->tid; b < nblocks; b += J->nthreads) {
+        uint32_t b0 = J->first + b * IB;
+        uint32_t nb = J->first + J->count - b0;
+        all_pairs_block(J, b0, nb < IB ? nb : IB);
+    }
+    return NULL;
+}
+
+int mapn_oracle_hardware_threads(void)
+{
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    return n > 0 ? (int)n : 1;
+}
+
+/*
+ * All-pairs step: CSMain's integrator (hlsl:103-108) with lines :92-101 replaced by
+ *   accel = sum_{j=0}^{n_total-1} bodyBodyInteraction(accel, oldPosition[j], pos, mass, 1)
+ * Advances bodies [first, first+count); j always runs over all n_total old positions (the
+ * reference uploads param[0] = N, Compute.cpp:543).  Parallel over i like the reference's only
+ * host loop (concurrency::parallel_for over i, Compute.cpp:684).  threads <= 0: all cores.
+ * The result does not depend on the thread count.
+ */
+int mapn_oracle_step_all_pairs(const float *old_pos, const float *old_vel, float *new_pos,
+                               float *new_vel, uint32_t n_total, uint32_t first, uint32_t count,
+                               const mapn_oracle_params *p, int threads)
+{
+    if (threads <= 0) threads = mapn_oracle_hardware_threads();
+    uint32_t nblocks = (count + IB - 1) / IB;
+    if ((uint32_t)threads > nblocks) threads = nblocks ? (int)nblocks : 1;
+    ap_job *jobs = (ap_job *)calloc((size_t)threads, sizeof(ap_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); return -1; }
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = (ap_job){old_pos, old_vel, new_pos, new_vel, n_total, first, count, p,
+                           (uint32_t)t, (uint32_t)threads};
+        if (t > 0 && pthread_create(&th[t], NULL, all_pairs_worker, &jobs[t]) != 0) {
+            all_pairs_worker(&jobs[t]);
+            th[t] = 0;
+        }
+    }
+    all_pairs_worker(&jobs[0]);
+    for (int t = 1; t < threads; t++)
+        if (th[t]) pthread_join(th[t], NULL);
+    free(jobs);
+    free(th);
+    return 0;
+}
+
+/* Per-body accelerations only (no integration): the quantity the 1-step tables compare. */
+int mapn_oracle_accel_all_pairs(const float *pos, float *out_acc3, uint32_t n_total,
+                                uint32_t first, uint32_t count, float mass, float soft2)
+{
+    for (uint32_t i = first; i < first + count; i++) {
+        float a[3] = {0.0f, 0.0f, 0.0f};
+        for (uint32_t j = 0; j < n_total; j++)
+            mapn_oracle_pair_term(a, pos + 4 * (size_t)j, pos + 4 * (size_t)i, mass, 1, soft2);
+        memcpy(out_acc3 + 3 * (size_t)(i - first), a, sizeof a);
+    }
+    return 0;
+}
+
+/*
+ * One Compute::Simulate call on host arrays (Compute.cpp:1009-1055): reads buffer 1-idx, writes
+ * buffer idx for bodies [0, active), leaves the rest of buffer idx untouched, flips idx
+ * (Compute.cpp:1022,1034-1035,1003; nBodyGravityCS.hlsl:77-81).  mode 0 = all pairs,
+ * 1 = central well.  pos[2], vel[2] are the two ping-pong buffers.  Returns the new index.
+ */
+uint32_t mapn_oracle_simulate(float *pos0, float *pos1, float *vel0, float *vel1,
+                              uint32_t buffer_index, uint32_t num_particles, int num_active,
+                              int mode, const mapn_oracle_params *p, int threads)
+{
+    float *pos[2] = {pos0, pos1}, *vel[2] = {vel0, vel1};
+    uint32_t w = buffer_index, r = 1 - buffer_index;
+    uint32_t active = mapn_oracle_active_bodies(num_active, num_particles);
+    if (active) {
+        if (mode == 1)
+            mapn_oracle_step_central_well(pos[r], vel[r], pos[w], vel[w], 0, active, p);
+        else
+            mapn_oracle_step_all_pairs(pos[r], vel[r], pos[w], vel[w], num_particles, 0, active, p,
+                                       threads);
+    }
+    return 1 - buffer_index;                        /* Compute.cpp:1003 */
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* LCGs of the initial-condition generator                                                     */
+
+/* Compute.cpp:605-609 fast_rand: MSVC rand() LCG.  K5. */
+int mapn_oracle_fast_rand(uint32_t *state)
+{
+    *state = 214013u * *state + 2531011u;
+    return (int)((*state >> 16) & 0x7FFF);
+}
+
+/*
+ * Compute.cpp:622-661 rand_sse restated without SSE: four independent 32-bit LCG lanes.
+ * _mm_set_epi32(seed, seed+1, seed, seed+1) puts seed+1 in lanes 0 and 2, seed in lanes 1 and 3
+ * (:619); lane multipliers {214013,17405,214013,69069}, adders {2531011,10395331,13737667,1};
+ * the 64-bit products are masked back to 32 bits (:648-649) and the result is
+ * (state >> 16) & 0x7FFF per lane (:655-657).  K6.
+ */
+void mapn_oracle_srand_sse(uint32_t state[4], uint32_t seed)
+{
+    state[0] = seed + 1; state[1] = seed; state[2] = seed + 1; state[3] = seed;
+}
+
+void mapn_oracle_rand_sse(uint32_t state[4], int out[4])
+{
+    static const uint32_t mult[4] = {214013u, 17405u, 214013u, 69069u};
+    static const uint32_t gadd[4] = {2531011u, 10395331u, 13737667u, 1u};
+    for (int l = 0; l < 4; l++) {
+        state[l] = state[l] * mult[l] + gadd[l];
+        out[l] = (int)(((int32_t)state[l] >> 16) & 0x7FFF);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Seeded initial state                                                                        */
+
+static uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+
+/*
+ * Deterministic replacement for LoadParticles (Compute.cpp:667-812).  The reference seeds
+ * mt19937 from random_device and shares it unsynchronised across threads (:678-684), so it is
+ * not reproducible; this generator keeps its distribution and replaces the randomness source
+ * by the file's own LCG (fast_rand, :599-609, scaled as in :721-725 with MSVC RAND_MAX = 32767)
+ * seeded PER BODY, so the state is independent of thread count and generation order:
+ *     lcg_state(i) = fmix32(seed * 0x9E3779B9 + i + 1)         (i = global body index)
+ * XMVector3NormalizeEst (:703-704, an rsqrtps approximation) is replaced by an exact normalize.
+ * Bodies [0, N/2) surround (+0.75*spread, 0, 0), [N/2, 2*(N/2)) surround (-0.75*spread, 0, 0)
+ * (:831-844).  pos.w = 0.
+ */
+void mapn_oracle_initial_state(uint32_t seed, uint32_t n, float spread, float speed, float *pos4,
+                               float *vel3)
+{
+    const float k_scale = (1.0f / 32767.0f) * 2.0f;             /* :721 */
+    const uint32_t half = n / 2;
+    const float center_spread = spread * 0.750f;                /* :831 */
+    memset(pos4, 0, (size_t)n * 16);
+    memset(vel3, 0, (size_t)n * 12);
+    for (uint32_t i = 0; i < 2 * half; i++) {
+        uint32_t st = fmix32(seed * 0x9E3779B9u + i + 1u);
+        const float cx = i < half ? center_spread : -center_spread;
+        float x = (float)mapn_oracle_fast_rand(&st) * k_scale - 1.0f;   /* :723-725 */
+        float y = (float)mapn_oracle_fast_rand(&st) * k_scale - 1.0f;
+        float z = (float)mapn_oracle_fast_rand(&st) * k_scale - 1.0f;
+        float dx = x, dy = y, dz = z;
+        for (;;) {
+            float l = dx * dx + dy * dy;
+            l = l + dz * dz;
+            if (!(l < 10.0f)) break;                                    /* :728 */
+            x = (float)mapn_oracle_fast_rand(&st) * k_scale - 1.0f;
+            y = (float)mapn_oracle_fast_rand(&st) * k_scale - 1.0f;
+            z = (float)mapn_oracle_fast_rand(&st) * k_scale - 1.0f;
+            dx = dx + x; dy = dy + y; dz = dz + z;                      /* :735 */
+        }
+        float l = dx * dx + dy * dy;
+        l = l + dz * dz;
+        float len = sqrtf(l);
+        dx = dx / len * spread;                                         /* :738-739 */
+        dy = dy / len * spread;
+        dz = dz / len * spread;
+        float px = cx + dx, py = 0.0f + dy, pz = 0.0f + dz;             /* :742 */
+        pos4[4 * (size_t)i + 0] = px;
+        pos4[4 * (size_t)i + 1] = py;
+        pos4[4 * (size_t)i + 2] = pz;
+        pos4[4 * (size_t)i + 3] = 0.0f;
+        l = px * px + py * py;
+        l = l + pz * pz;
+        len = sqrtf(l);
+        float ux = px / len, uy = py / len, uz = pz / len;              /* :746 direction */
+        float qx = 1.0f - ux, qy = 1.0f - uy, qz = 1.0f - uz;           /* :747 */
+        l = qx * qx + qy * qy;
+        l = l + qz * qz;
+        len = sqrtf(l);
+        qx = qx / len; qy = qy / len; qz = qz / len;                    /* perp */
+        float c0 = uy * qz - uz * qy;                                   /* :748 cross(dir, perp) */
+        float c1 = uz * qx - ux * qz;
+        float c2 = ux * qy - uy * qx;
+        vel3[3 * (size_t)i + 0] = c0 * speed;
+        vel3[3 * (size_t)i + 1] = c1 * speed;
+        vel3[3 * (size_t)i + 2] = c2 * speed;
+    }
+}

@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) device; run with -m gpu")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def lib():
+    import mapn
+    return mapn.load_library()
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")

@@ -1,0 +1,92 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/mapn.h declares, and its host-only pieces (config defaults, initial-state generator,
+error path without a device) behave.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mapn
+from mapn import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "mapn.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(mapn_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = _declared()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"libmapn.so does not export {n}"
+    assert sorted(_lib.SIGNATURES) == names, "python binding and header disagree"
+
+
+def test_abi_version_and_timer_name(lib):
+    assert lib.mapn_abi_version() == 1
+    assert lib.mapn_timer_name() == b"simulate ms"          # Compute.cpp:446
+
+
+def test_config_defaults_are_the_reference_constants(lib):
+    cfg = mapn.Config()
+    assert lib.mapn_config_default(C.byref(cfg)) == 0
+    assert cfg.struct_size == C.sizeof(mapn.Config) == 80
+    assert cfg.num_particles == 4 * 1024 * 1024             # defines.h:45
+    assert (cfg.mass, cfg.softening_squared) == (70000.0, 25.0)   # hlsl:37-38
+    assert np.float32(cfg.dt).view(np.uint32) == 0x3DCCCCCD and cfg.damping == 1.0   # Compute.cpp:545-546
+    assert (cfg.spread, cfg.initial_speed) == (400.0, 15.0) # defines.h:42,39
+    assert (cfg.force_mode, cfg.world_size, cfg.rank, cfg.seed) == (mapn.FORCE_ALL_PAIRS, 1, 0, 1)
+
+
+@pytest.mark.parametrize("n,seed", [(256, 1), (4096, 1), (1000, 3), (70001, 11)])
+def test_product_generator_matches_oracle_bit_exact(oracle, n, seed):
+    pos, vel = mapn.generate_initial_state(n, seed=seed)
+    op, ov = oracle.initial_state(n, seed=seed)
+    np.testing.assert_array_equal(pos, op)
+    np.testing.assert_array_equal(vel, ov)
+
+
+def test_generator_checksums(golden_dir):
+    g = np.load(os.path.join(golden_dir, "init_checksums.npz"))
+    for n in (1000, 65536):
+        pos, vel = mapn.generate_initial_state(n, seed=1)
+        sums = [np.frombuffer(pos.tobytes(), np.uint32).sum(dtype=np.uint64), np.frombuffer(vel.tobytes(), np.uint32).sum(dtype=np.uint64)]
+        assert sums == g[str(n)].tolist()
+
+
+def test_bad_arguments_return_status_not_crash(lib):
+    assert lib.mapn_config_default(None) == -1
+    cfg = mapn.Config(); lib.mapn_config_default(C.byref(cfg))
+    ctx = C.c_void_p()
+    cfg.struct_size = 12
+    assert lib.mapn_create(C.byref(cfg), C.byref(ctx)) == -1 and b"struct_size" in lib.mapn_last_error()
+    lib.mapn_config_default(C.byref(cfg)); cfg.num_particles = 100; cfg.world_size = 3
+    assert lib.mapn_create(C.byref(cfg), C.byref(ctx)) == -1 and b"divide" in lib.mapn_last_error()
+    assert lib.mapn_simulate(None, 1, 0) == -1
+    assert lib.mapn_destroy(None) == 0
+
+
+def test_no_device_fails_loudly_no_cpu_fallback():
+    if mapn.compute.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(mapn.MapnError) as e:
+        mapn.Compute(4096)
+    assert e.value.status == -3 and "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_link_or_reference_the_oracle():
+    """The shipped library and package must not route through oracle/ (or any CPU step)."""
+    so = open(mapn.library_path(), "rb").read()
+    assert b"mapn_oracle" not in so
+    pkg = os.path.join(ROOT, "multi-adapter-particles_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "mapn_oracle" not in text, f

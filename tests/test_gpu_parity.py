@@ -1,0 +1,358 @@
+"""GPU parity tests: the HIP path, called through the C ABI exactly like the reference's caller
+(Particles.cpp:446-448: fence = GetFenceValue(); Simulate(n, fence)), against the CPU oracle on
+identical seeded inputs.
+
+Tolerances (fp32; stated per SURVEY.md F4).  The device kernel differs from the oracle in three
+documented ways: v_rsq_f32 (1 ulp) instead of 1/sqrt, fused multiply-adds, and a different
+summation grouping (S chunk sums combined in ascending order instead of one running sum).
+  * central well: same op sequence up to fma/rsq -> 1-step positions within 2e-6 of |x| scale;
+  * all pairs, 1 step teacher-forced: positions within 1e-6 * 400 (PARTICLE_SPREAD), velocities
+    within 2e-5 * 15, w = |a| within 1e-4 relative to max |a|;
+  * all pairs, 100 steps free-running, mass = 70000/N: max ||dx|| / 400 <= 1e-4, median <= 1e-6.
+"""
+import numpy as np
+import pytest
+
+import mapn
+from oracle import MODE_ALL_PAIRS, MODE_CENTRAL_WELL, OracleSim, Params
+from oracle import model_np
+
+pytestmark = pytest.mark.gpu
+
+SPREAD, SPEED = 400.0, 15.0
+
+
+def draw(compute, steps, num_active=None):
+    """Particles::Draw's compute half (Particles.cpp:446-448), `steps` frames."""
+    n = compute.num_particles if num_active is None else num_active
+    for _ in range(steps):
+        fence = compute.GetFenceValue()
+        compute.Simulate(n, fence)
+
+
+def errs(a, b, scale):
+    d = np.linalg.norm(a.astype(np.float64) - b.astype(np.float64), axis=1) / scale
+    return d.max(), np.median(d)
+
+
+# ---------------------------------------------------------------------------------------------
+# central well (what the reference actually dispatches)
+
+@pytest.mark.parametrize("n", [64, 1000, 4096, 65536])
+def test_central_well_one_step(oracle, n):
+    pos, vel = oracle.initial_state(n, seed=1)
+    sim = OracleSim(oracle, pos, vel, mode=MODE_CENTRAL_WELL); sim.simulate()
+    with mapn.Compute(n, force_mode=mapn.FORCE_CENTRAL_WELL) as c:
+        np.testing.assert_array_equal(c.download_state()[0], pos)        # product init == oracle init
+        draw(c, 1)
+        p, v = c.download_state()
+    assert errs(p[:, :3], sim.latest[0][:, :3], 700.0)[0] < 2e-6
+    assert errs(v, sim.latest[1], SPEED)[0] < 2e-5
+    np.testing.assert_allclose(p[:, 3], sim.latest[0][:, 3], rtol=2e-6)   # w = |accel|
+
+
+def test_central_well_golden_100_steps(oracle, golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "golden_n256.npz"))
+    with mapn.Compute(256, force_mode=mapn.FORCE_CENTRAL_WELL) as c:
+        draw(c, 100)
+        p, v = c.download_state()
+    assert errs(p[:, :3], g["cw_pos_100"][:, :3], SPREAD)[0] < 1e-3      # orbits around a fixed well
+    assert errs(v, g["cw_vel_100"], SPEED)[0] < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# all pairs
+
+def one_step_check(oracle, c, n, mass, pos, vel):
+    sim = OracleSim(oracle, pos, vel, params=Params(mass=mass)); sim.simulate()
+    draw(c, 1)
+    p, v = c.download_state()
+    rp, rv = sim.latest
+    assert errs(p[:, :3], rp[:, :3], SPREAD)[0] < 1e-6
+    assert errs(v, rv, SPEED)[0] < 2e-5
+    assert np.abs(p[:, 3] - rp[:, 3]).max() / rp[:, 3].max() < 1e-4
+    return p, v
+
+
+@pytest.mark.parametrize("n", [2, 63, 64, 65, 1000, 4096, 8192])
+def test_all_pairs_one_step_auto_plan(oracle, n):
+    """Teacher-forced single step, including ragged N (not a multiple of 64) and tiny N."""
+    pos, vel = oracle.initial_state(n, seed=1)
+    if n == 2:
+        pos = np.zeros((2, 4), np.float32); pos[1, :3] = [3, 4, 0]; vel = np.zeros((2, 3), np.float32)
+    mass = 70000.0 / n
+    with mapn.Compute(n, mass=mass, flags=mapn.FLAG_NO_INIT) as c:
+        c.upload_state(pos, vel)
+        one_step_check(oracle, c, n, mass, pos, vel)
+
+
+def test_k4_two_body_on_device():
+    """SURVEY K4 through the ABI: equal and opposite kicks."""
+    pos = np.zeros((2, 4), np.float32); pos[1, :3] = [3, 4, 0]
+    with mapn.Compute(2, mass=1.0, flags=mapn.FLAG_NO_INIT) as c:
+        c.upload_state(pos, np.zeros((2, 3), np.float32))
+        draw(c, 1, num_active=2)
+        p, v = c.download_state()
+    np.testing.assert_allclose(v[0] / np.float32(0.1), [0.0084852814, 0.011313708, 0.0], rtol=1e-6)
+    np.testing.assert_allclose(v[0], -v[1], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(p[0, 3], 0.014142136, rtol=1e-6)
+
+
+VARIANTS = [(mapn.KERNEL_LDS, k, w, sb, fused)
+            for k in (2, 4, 8) for (w, sb, fused) in ((1, 1, True), (4, 1, True), (8, 1, True), (8, 1, False), (4, 3, False), (8, 8, False))
+            ] + [(mapn.KERNEL_SCALAR, k, w, sb, fused)
+                 for k in (2, 4) for (w, sb, fused) in ((4, 1, True), (8, 2, False), (16, 1, True))] + [
+                (mapn.KERNEL_LDS, 2, 16, 1, True), (mapn.KERNEL_LDS, 4, 16, 1, True), (mapn.KERNEL_LDS, 4, 2, 16, False)]
+
+
+@pytest.mark.parametrize("kernel,k,waves,sb,fused", VARIANTS)
+def test_all_pairs_every_kernel_variant(oracle, kernel, k, waves, sb, fused):
+    """Every template instantiation, on a ragged N so that tail tiles and clamped lanes run."""
+    n = 3000
+    pos, vel = oracle.initial_state(n, seed=3)
+    mass = 70000.0 / n
+    with mapn.Compute(n, mass=mass, flags=mapn.FLAG_NO_INIT) as c:
+        c.upload_state(pos, vel)
+        c.set_force_plan(kernel, k, waves, sb, fused)
+        one_step_check(oracle, c, n, mass, pos, vel)
+
+
+def test_variants_agree_bitwise_when_split_is_equal():
+    """Fixed-order reduction: the same j-split gives the same bits whether the chunk sums are
+    combined in LDS (fused) or through the scratch buffer (two kernels); and a run is
+    reproducible."""
+    n = 4096
+    res = []
+    for fused in (True, False, True):
+        with mapn.Compute(n, mass=70000.0 / n) as c:
+            c.set_force_plan(mapn.KERNEL_LDS, 4, 8, 1, fused)
+            draw(c, 3)
+            res.append(c.download_state())
+    np.testing.assert_array_equal(res[0][0], res[1][0]); np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][0], res[2][0])
+
+
+def test_all_pairs_golden_config1_100_steps(oracle, golden_dir):
+    """BASELINE config #1 (4 096 bodies, 100 steps) against the committed oracle state."""
+    import os
+    g = np.load(os.path.join(golden_dir, "golden_n4096.npz"))
+    n = 4096
+    with mapn.Compute(n, mass=70000.0 / n) as c:
+        draw(c, 1)
+        p1, _ = c.download_state()
+        draw(c, 99)
+        p, v = c.download_state()
+    assert errs(p1[:, :3], g["pos_1"][:, :3], SPREAD)[0] < 1e-6
+    mx, med = errs(p[:, :3], g["pos_100"][:, :3], SPREAD)
+    print(f"100-step free run N=4096: max |dx|/400 = {mx:.3e}, median = {med:.3e}")
+    assert mx < 1e-4 and med < 1e-6
+    assert errs(v, g["vel_100"], SPEED)[0] < 1e-3
+
+
+def test_all_pairs_literal_mass_10_steps(golden_dir):
+    """The reference's literal per-body mass 70000 (chaotic regime): only the first
+    steps are comparable; 1 step tight, 10 steps loose."""
+    import os
+    g = np.load(os.path.join(golden_dir, "golden_n256.npz"))
+    with mapn.Compute(256) as c:                               # defaults = literal constants
+        draw(c, 1)
+        p1, _ = c.download_state()
+        draw(c, 9)
+        p10, _ = c.download_state()
+    assert errs(p1[:, :3], g["aplit_pos_1"][:, :3], SPREAD)[0] < 1e-5
+    assert errs(p10[:, :3], g["aplit_pos_10"][:, :3], SPREAD)[0] < 5e-2
+
+
+def test_accel_against_fp64_table(golden_dir):
+    """w = |accel| written by the device vs the float64 per-body table (mass 1)."""
+    import os
+    g = np.load(os.path.join(golden_dir, "golden_n256.npz"))
+    with mapn.Compute(256, mass=1.0) as c:
+        draw(c, 1)
+        p, _ = c.download_state()
+    ref = np.linalg.norm(g["acc_fp64_unit_mass"], axis=1)
+    assert np.abs(p[:, 3] - ref).max() / ref.max() < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size properties (BASELINE sizes): subset teacher-forced check + invariants
+
+@pytest.mark.parametrize("n", [65536, 262144])
+def test_full_size_subset_and_invariants(oracle, n):
+    mass = 70000.0 / n
+    pos, vel = oracle.initial_state(n, seed=1)
+    rng = np.random.default_rng(0)
+    first = int(rng.integers(0, n - 4096)) // 64 * 64
+    rp, rv = oracle.step_slice(pos, vel, first, 4096, params=Params(mass=mass))      # O(k*N) oracle work
+    with mapn.Compute(n, mass=mass) as c:
+        np.testing.assert_array_equal(c.download_state()[0], pos)
+        draw(c, 1)
+        p, v = c.download_state()
+        assert errs(p[first:first + 4096, :3], rp[:, :3], SPREAD)[0] < 1e-6
+        assert errs(v[first:first + 4096], rv, SPEED)[0] < 2e-5
+        assert np.abs(p[first:first + 4096, 3] - rp[:, 3]).max() / rp[:, 3].max() < 2e-4
+        # momentum: pair terms are antisymmetric, so sum(m*v) changes only by rounding
+        p0 = vel.astype(np.float64).sum(0)
+        draw(c, 4)
+        _, v5 = c.download_state()
+        drift = np.abs(v5.astype(np.float64).sum(0) - p0).max() / (n * SPEED)
+        print(f"N={n}: relative momentum drift after 5 steps {drift:.2e}")
+        assert drift < 1e-6
+        assert np.isfinite(v5).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# Compute's call semantics
+
+def test_fence_values_follow_the_reference():
+    """Compute.cpp:434-436 (fence starts at 0, value -> 1), three WaitForGpu during fresh
+    construction (:563, :922, :97) -> GetFenceValue() == 4; +1 per Simulate and per WaitForGpu."""
+    with mapn.Compute(1024, force_mode=mapn.FORCE_CENTRAL_WELL) as c:
+        assert c.GetFenceValue() == 4
+        assert c.buffer_index == 0
+        c.Simulate(1024, c.GetFenceValue())
+        assert c.GetFenceValue() == 5 and c.buffer_index == 1
+        c.WaitForGpu()
+        assert c.GetFenceValue() == 6
+        assert c.GetCompletedValue() >= 5
+        t, name = c.GetGpuTimes()[0]
+        assert name == "simulate ms" and 0 < t < 1.0
+        assert c.GetIsUMA() is False and c.GetUsingIntelCommandQueueExtension() is False
+        prm, prf = c.cbuffer()
+        assert prm == [1024, 16, 0, 0] and prf.view(np.uint32).tolist()[:2] == [0x3DCCCCCD, 0x3F800000]
+
+
+def test_num_active_rounding_and_frozen_tail(oracle):
+    """Compute.cpp:1041: bodies [0, roundup64(numActive)) advance; the rest of the WRITTEN buffer
+    keeps what it held; j still runs over all N bodies."""
+    n = 1024
+    pos, vel = oracle.initial_state(n, seed=4)
+    prm = Params(mass=70000.0 / n)
+    sim = OracleSim(oracle, pos, vel, params=prm)
+    with mapn.Compute(n, mass=70000.0 / n, flags=mapn.FLAG_NO_INIT) as c:
+        c.upload_state(pos, vel)
+        for na in (100, 100, 700, 1):
+            sim.simulate(num_active=na)
+            draw(c, 1, num_active=na)
+            for b in (0, 1):
+                p, v = c.download_buffer(b)
+                assert errs(p[:, :3], sim.pos[b][:, :3], SPREAD)[0] < 1e-6
+                assert errs(v, sim.vel[b], SPEED)[0] < 2e-5
+            assert c.buffer_index == sim.buffer_index
+        # frozen region is bit-identical to the initial state in both buffers
+        for b in (0, 1):
+            p, _ = c.download_buffer(b)
+            np.testing.assert_array_equal(p[704:], pos[704:])
+
+
+def test_zero_active_is_a_no_op_that_still_flips():
+    with mapn.Compute(256, mass=1.0) as c:
+        before = c.download_buffer(0)[0].copy()
+        f = c.GetFenceValue()
+        c.Simulate(0, f)
+        c.WaitForGpu()
+        assert c.buffer_index == 1 and c.GetFenceValue() == f + 2
+        np.testing.assert_array_equal(c.download_buffer(0)[0], before)
+
+
+def test_create_from_copies_state_and_continues_identically():
+    """Compute(..., old) -> CopyState (Compute.cpp:303-410): the migrated context continues
+    bit-identically."""
+    n = 2048
+    with mapn.Compute(n, mass=70000.0 / n) as a:
+        draw(a, 3)
+        with mapn.Compute(n, mass=70000.0 / n, old=a) as b:
+            assert b.buffer_index == a.buffer_index
+            for i in (0, 1):
+                np.testing.assert_array_equal(a.download_buffer(i)[0], b.download_buffer(i)[0])
+                np.testing.assert_array_equal(a.download_buffer(i)[1], b.download_buffer(i)[1])
+            draw(a, 2); draw(b, 2)
+            np.testing.assert_array_equal(a.download_state()[0], b.download_state()[0])
+
+
+def test_consumer_fence_protocol():
+    """Compute.cpp:1012: Simulate(n, v) may not overwrite a buffer before the consumer signalled
+    v-1.  Unsignalled -> loud error instead of a race; host signal -> proceeds."""
+    with mapn.Compute(512, mass=1.0) as c:
+        h = c.GetSharedHandles()                      # attaches the consumer's fence
+        assert h.positions[0] and h.positions[1] and h.buffer_index == 0
+        assert h.aligned_data_size == 65536           # 512*16 B rounded up to 64 KiB (Compute.cpp:185-194)
+        fence = c.GetFenceValue()
+        with pytest.raises(mapn.MapnError):
+            c.Simulate(512, fence)
+        c.ConsumerSignal(fence - 1)
+        c.Simulate(512, fence)
+        c.WaitForGpu()
+        assert c.buffer_index == 1
+
+
+def test_set_async_computes_into_caller_buffers():
+    """SetAsync / ResetFromAsyncHelper (Compute.cpp:956-987, 260-298) using a second context's
+    exported position buffers as the 'render' buffers."""
+    n = 1024
+    with mapn.Compute(n, mass=70000.0 / n) as ref, mapn.Compute(n, mass=70000.0 / n) as c, \
+            mapn.Compute(n, mass=70000.0 / n) as owner:
+        draw(ref, 2)
+        h = owner.GetSharedHandles(consumer_fence=False)
+        c.SetAsync([h.positions[0], h.positions[1]], 1)       # consumer shows buffer 1 -> we write 0 next
+        assert c.buffer_index == 0
+        draw(c, 2)
+        c.WaitForGpu()
+        # results landed in the owner's buffers
+        np.testing.assert_array_equal(owner.download_buffer(1)[0], ref.download_state()[0])
+        c.ResetFromAsyncHelper()
+        np.testing.assert_array_equal(c.download_state()[0], ref.download_state()[0])
+        draw(c, 1); draw(ref, 1)
+        np.testing.assert_array_equal(c.download_state()[0], ref.download_state()[0])
+
+
+def test_sharded_context_requires_transport_and_single_rank_comm_works():
+    """world_size > 1 without a transport is an error; a 1-rank RCCL communicator exercises the
+    native all-gather path (own-slice kernel, remote kernel with empty segments, reduce+integrate,
+    ncclAllGather) and must match the unsharded step."""
+    n = 2048
+    with mapn.Compute(n, mass=70000.0 / n, rank=1, world_size=2) as c:
+        assert c.shard_range() == (1024, 1024)
+        with pytest.raises(mapn.MapnError):
+            c.Simulate(n, 0)
+    with mapn.Compute(n, mass=70000.0 / n) as ref, mapn.Compute(n, mass=70000.0 / n) as c:
+        c.comm_init(mapn.Compute.comm_unique_id())
+        draw(ref, 3); draw(c, 3)
+        a, b = ref.download_state(), c.download_state()
+        assert errs(a[0][:, :3], b[0][:, :3], SPREAD)[0] < 1e-6
+        assert errs(a[1], b[1], SPEED)[0] < 2e-5
+
+
+def test_external_gather_slices_compose_to_the_full_step(oracle):
+    """Two shard contexts on one GPU with the caller doing the all-gather (numpy here): the
+    composed step equals the unsharded device step to the 1-step tolerance."""
+    n = 2048
+    mass = 70000.0 / n
+    pos, vel = oracle.initial_state(n, seed=1)
+    sim = OracleSim(oracle, pos, vel, params=Params(mass=mass)); sim.simulate(steps=2)
+    shards = [mapn.Compute(n, mass=mass, rank=r, world_size=2) for r in range(2)]
+    try:
+        for s in shards:
+            s.set_external_gather(True)
+        for _ in range(2):
+            for s in shards:
+                draw(s, 1)
+            parts = [s.download_state() for s in shards]
+            gp = np.concatenate([parts[0][0][:1024], parts[1][0][1024:]])
+            gv = np.concatenate([parts[0][1][:1024], parts[1][1][1024:]])
+            # all-gather: every replica's freshly written buffer receives the other slice
+            for s in shards:
+                w = 1 - s.buffer_index
+                other = s.download_buffer(1 - w)
+                s_pos = [None, None]; s_vel = [None, None]
+                s_pos[w], s_vel[w] = gp, gv
+                s_pos[1 - w], s_vel[1 - w] = other
+                # upload writes both buffers: emulate by uploading the gathered state (both
+                # buffers equal is fine for a teacher-forced continuation with num_active = N)
+                s.upload_state(gp, gv)
+        assert errs(gp[:, :3], sim.latest[0][:, :3], SPREAD)[0] < 2e-6
+        assert errs(gv, sim.latest[1], SPEED)[0] < 4e-5
+    finally:
+        for s in shards:
+            s.close()

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Kernel-variant sweep on the GPU box (development tool): times the force kernel for a list of
+plans at a given N and prints interactions/s from the in-library event timers."""
+import argparse
+import itertools
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mapn  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--bodies", type=int, default=65536)
+ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--kernels", default="lds,sgpr")
+ap.add_argument("--ks", default="2,4,8")
+ap.add_argument("--waves", default="4,8,16")
+ap.add_argument("--sbs", default="1,2,4")
+a = ap.parse_args()
+n = a.bodies
+KN = {"lds": mapn.KERNEL_LDS, "sgpr": mapn.KERNEL_SCALAR}
+with mapn.Compute(n, mass=70000.0 / n) as c:
+    rows = []
+    for kn, k, w, sb in itertools.product(a.kernels.split(","), map(int, a.ks.split(",")), map(int, a.waves.split(",")), map(int, a.sbs.split(","))):
+        try:
+            c.set_force_plan(KN[kn], k, w, sb, sb == 1)
+        except mapn.MapnError:
+            continue
+        for _ in range(3):
+            c.Simulate(n, c.GetFenceValue())
+        c.WaitForGpu(); c.kernel_stats(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            c.Simulate(n, c.GetFenceValue())
+        c.WaitForGpu()
+        wall = (time.perf_counter() - t0) / a.steps
+        st = c.kernel_stats()
+        rate = n * n / st.avg_seconds
+        rows.append((rate, kn, k, w, sb, st.avg_seconds * 1e3, wall * 1e3))
+        print(f"{kn:5s} k={k} waves={w:2d} sb={sb:2d}  kernel {st.avg_seconds*1e3:8.3f} ms  step {wall*1e3:8.3f} ms  {rate:.3e} pairs/s  {20*rate/157.3e12*100:5.1f}% fp32 peak", flush=True)
+    rows.sort(reverse=True)
+    print("best:", rows[:5])

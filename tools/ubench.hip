@@ -1,0 +1,143 @@
+// ubench.hip -- gfx950 VALU issue-rate microbenchmarks that decide the force kernel's shape.
+// Development tool (not part of libmapn.so).  Build: hipcc --offload-arch=gfx950 -O3 ubench.hip -o ubench
+//
+// For each instruction mix it reports wave-instructions per cycle per SIMD (from s_memtime) at
+// 1, 2, 4 and 8 waves per SIMD, plus the clock the chip held (s_memtime / s_memrealtime).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e)); exit(1); } } while (0)
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+enum Mix { FMA = 0, PKFMA, RSQ, PAIR_SCALAR, PAIR_PK, FMA_SGPR, PKFMA_BCAST, MIXES };
+static const char *mix_name[MIXES] = {"v_fma_f32 x16", "v_pk_fma_f32 x16", "v_rsq_f32 x16", "pair scalar (12 ops)", "pair packed (2 bodies)", "v_fma_f32 sgpr-src x16", "v_pk_fma_f32 op_sel bcast x16"};
+static const int mix_insts[MIXES] = {16, 16, 16, 12 * 4, 13 * 2, 16, 16};      // wave-instructions per loop body
+static const double mix_pairs[MIXES] = {0, 0, 0, 4, 4, 0, 0};                  // pairs per lane per loop body
+
+template <int MIX>
+__global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, unsigned long long *rt, int iters, float seed)
+{
+    float a[16];
+    for (int i = 0; i < 16; i++) a[i] = seed + i * 0.001f + threadIdx.x * 1e-6f;
+    float2v p[16];
+    for (int i = 0; i < 16; i++) p[i] = float2v{a[i], a[i] * 0.5f};
+    const float m = 0.999f, c = 0.0001f;
+    float sx = seed * 3.f, sy = seed * 5.f, sz = seed * 7.f, soft2 = 25.f;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sx) : "v"(seed * 3.f));
+    unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+        if (MIX == FMA) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+        } else if (MIX == FMA_SGPR) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "s"(sx));
+        } else if (MIX == PKFMA) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(p[(i + 1) & 15]), "v"(p[(i + 2) & 15]));
+        } else if (MIX == PKFMA_BCAST) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,1]" : "+v"(p[i]) : "v"(p[(i + 1) & 15]), "v"(p[(i + 2) & 15]));
+        } else if (MIX == RSQ) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i]));
+        } else if (MIX == PAIR_SCALAR) {
+            // 4 bodies i per lane, one j: 12 ops each, all-VGPR scalar f32
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float dx, dy, dz, d, inv, i3;
+                asm volatile(
+                    "v_sub_f32 %0, %9, %6\n v_sub_f32 %1, %10, %7\n v_sub_f32 %2, %11, %8\n"
+                    "v_fma_f32 %3, %0, %0, %12\n v_fma_f32 %3, %1, %1, %3\n v_fma_f32 %3, %2, %2, %3\n"
+                    "v_rsq_f32 %4, %3\n v_mul_f32 %5, %4, %4\n v_mul_f32 %5, %5, %4\n"
+                    : "=&v"(dx), "=&v"(dy), "=&v"(dz), "=&v"(d), "=&v"(inv), "=&v"(i3)
+                    : "v"(a[3 * k]), "v"(a[3 * k + 1]), "v"(a[3 * k + 2]), "v"(sx), "v"(sy), "v"(sz), "v"(soft2));
+                asm volatile("v_fma_f32 %0, %3, %6, %0\n v_fma_f32 %1, %4, %6, %1\n v_fma_f32 %2, %5, %6, %2"
+                             : "+v"(p[k].x), "+v"(p[k].y), "+v"(p[k + 4].x) : "v"(dx), "v"(dy), "v"(dz), "v"(i3));
+            }
+        } else if (MIX == PAIR_PK) {
+            // 2 bodies per packed op, one j, x2 -> 4 pairs: 3 pk_add, 3 pk_fma, 2 rsq, 2 pk_mul, 3 pk_fma = 13
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                float2v dx, dy, dz, d, inv, i3;
+                asm volatile(
+                    "v_pk_add_f32 %0, %9, %6 neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %1, %10, %7 neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %2, %11, %8 neg_lo:[0,1] neg_hi:[0,1]\n"
+                    "v_pk_fma_f32 %3, %0, %0, %12\n v_pk_fma_f32 %3, %1, %1, %3\n v_pk_fma_f32 %3, %2, %2, %3\n"
+                    : "=&v"(dx), "=&v"(dy), "=&v"(dz), "=&v"(d), "=&v"(inv), "=&v"(i3)
+                    : "v"(p[3 * k]), "v"(p[3 * k + 1]), "v"(p[3 * k + 2]), "v"(p[12]), "v"(p[13]), "v"(p[14]), "v"(p[15]));
+                asm volatile("v_rsq_f32 %0, %2\n v_rsq_f32 %1, %3" : "=&v"(inv.x), "=&v"(inv.y) : "v"(d.x), "v"(d.y));
+                asm volatile("v_pk_mul_f32 %0, %1, %1\n v_pk_mul_f32 %0, %0, %1" : "=&v"(i3) : "v"(inv));
+                asm volatile("v_pk_fma_f32 %0, %3, %6, %0\n v_pk_fma_f32 %1, %4, %6, %1\n v_pk_fma_f32 %2, %5, %6, %2"
+                             : "+v"(p[6 + k]), "+v"(p[8 + k]), "+v"(p[10 + k]) : "v"(dx), "v"(dy), "v"(dz), "v"(i3));
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0;
+    for (int i = 0; i < 16; i++) s += a[i] + p[i].x + p[i].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) {
+        int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        cyc[w] = t1 - t0;
+        rt[w] = r1 - r0;
+    }
+}
+
+template <int MIX>
+static void run(int waves_per_simd, int iters)
+{
+    int dev; CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t pr; CHECK(hipGetDeviceProperties(&pr, dev));
+    const int cus = pr.multiProcessorCount;
+    const int blocks = cus * waves_per_simd;      // 256 threads = 4 waves = one wave per SIMD
+    const int waves = blocks * 4;
+    float *out; unsigned long long *cyc, *rt;
+    CHECK(hipMalloc(&out, sizeof(float) * blocks * 256));
+    CHECK(hipMalloc(&cyc, 8 * waves)); CHECK(hipMalloc(&rt, 8 * waves));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; rep++) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(ub<MIX>, dim3(blocks), dim3(256), 0, 0, out, cyc, rt, iters, 1.0f + rep);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+    }
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> hc(waves), hr(waves);
+    CHECK(hipMemcpy(hc.data(), cyc, 8 * waves, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(hr.data(), rt, 8 * waves, hipMemcpyDeviceToHost));
+    std::sort(hc.begin(), hc.end()); std::sort(hr.begin(), hr.end());
+    const double cmed = (double)hc[waves / 2], rmed = (double)hr[waves / 2];
+    const double insts = (double)iters * mix_insts[MIX];
+    // per SIMD: waves_per_simd waves, each issuing `insts` wave-instructions in cmed cycles
+    const double ipc = insts * waves_per_simd / cmed;
+    const double ghz = cmed / rmed * 0.1;
+    printf("%-32s waves/SIMD=%d  cyc/inst/SIMD=%6.3f  inst/cyc/SIMD=%5.3f  clk=%.2f GHz  wall=%.3f ms", mix_name[MIX], waves_per_simd, 1.0 / ipc, ipc, ghz, ms);
+    if (mix_pairs[MIX] > 0) {
+        const double pairs = (double)iters * mix_pairs[MIX] * 64.0 * waves;
+        printf("  pairs/s=%.3e (%.1f%% of %0.1f TF @20flop)", pairs / (ms * 1e-3), 100.0 * 20.0 * pairs / (ms * 1e-3) / (cus * 2.4e9 * 256), cus * 2.4e9 * 256 / 1e12);
+    }
+    printf("\n");
+    CHECK(hipFree(out)); CHECK(hipFree(cyc)); CHECK(hipFree(rt));
+}
+
+template <int MIX>
+static void sweep(int iters)
+{
+    for (int w : {1, 2, 4, 8}) run<MIX>(w, iters);
+}
+
+int main(int argc, char **argv)
+{
+    int iters = argc > 1 ? atoi(argv[1]) : 20000;
+    hipDeviceProp_t pr; CHECK(hipGetDeviceProperties(&pr, 0));
+    printf("device: %s  arch=%s  CUs=%d  clock=%d kHz  wave=%d\n", pr.name, pr.gcnArchName, pr.multiProcessorCount, pr.clockRate, pr.warpSize);
+    sweep<FMA>(iters); sweep<FMA_SGPR>(iters); sweep<PKFMA>(iters); sweep<PKFMA_BCAST>(iters); sweep<RSQ>(iters);
+    sweep<PAIR_SCALAR>(iters); sweep<PAIR_PK>(iters);
+    return 0;
+}

@@ -244,8 +244,10 @@ int mapn_get_kernel_stats(mapn_ctx *ctx, int reset, mapn_kernel_stats *out);
  * bodies_per_lane in {2,4,8}, waves in {1,2,4,8,16}, sb >= 1 (j-split across workgroups). */
 int mapn_set_force_plan(mapn_ctx *ctx, int kernel, uint32_t bodies_per_lane, uint32_t waves,
                         uint32_t sb, int fused);
-/* Per-step event timers on/off (on by default, like the reference's D3D12GpuTimer). */
-int mapn_set_timers(mapn_ctx *ctx, int enabled);
+/* Step timers: 0 = off, T >= 1 = record the event pair on every T-th step (default 1: every
+ * step, like the reference's D3D12GpuTimer).  Each hipEventRecord costs a few microseconds of
+ * queue time, which matters once a sharded step is ~0.1 ms. */
+int mapn_set_timers(mapn_ctx *ctx, int interval);
 /* The compute stream (hipStream_t) steps are enqueued on, for callers that record events. */
 void *mapn_compute_stream(mapn_ctx *ctx);
 

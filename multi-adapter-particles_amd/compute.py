@@ -191,8 +191,9 @@ class Compute:
     def set_force_plan(self, kernel: int, bodies_per_lane: int = 4, waves: int = 8, sb: int = 1, fused: bool = True):
         check(self._lib.mapn_set_force_plan(self._ctx, kernel, bodies_per_lane, waves, sb, int(bool(fused))))
 
-    def set_timers(self, enabled: bool):
-        check(self._lib.mapn_set_timers(self._ctx, int(bool(enabled))))
+    def set_timers(self, interval: int):
+        """0 = off, T >= 1 = time every T-th step."""
+        check(self._lib.mapn_set_timers(self._ctx, int(interval)))
 
     def kernel_stats(self, reset: bool = False) -> KernelStats:
         st = KernelStats()

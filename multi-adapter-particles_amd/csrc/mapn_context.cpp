@@ -78,7 +78,7 @@ struct mapn_ctx {
     uint64_t completed = 0;
     hipEvent_t fence_events[kTimerRing] = {};
     uint64_t fence_event_value[kTimerRing] = {};
-    hipEvent_t step_done = nullptr;           // exported: recorded after every step
+    hipEvent_t step_done = nullptr;           // exported: the fence event of the latest step
 
     // consumer fence (the render adapter's shared fence, Compute.cpp:1012)
     bool consumer_enabled = false;
@@ -90,6 +90,8 @@ struct mapn_ctx {
     uint32_t timer_head = 0;
     float ema_seconds = 0.f;
     bool timers_enabled = true;
+    uint32_t timer_interval = 1;             // record step timers on every T-th step
+    uint64_t steps_enqueued = 0;
     double force_seconds_sum = 0.0;
     uint64_t force_launches = 0;
 
@@ -99,7 +101,6 @@ struct mapn_ctx {
 
     // sharded mode
     mapn::Comm *comm = nullptr;
-    hipEvent_t integrate_done = nullptr;
     hipEvent_t gather_done[2] = {nullptr, nullptr};
     bool gather_recorded[2] = {false, false};
     bool external_gather = false;
@@ -154,6 +155,7 @@ int signal_fence(mapn_ctx *c, uint64_t value)
     const int slot = (int)(value % kTimerRing);
     HIP_TRY(hipEventRecord(c->fence_events[slot], c->compute));
     c->fence_event_value[slot] = value;
+    c->step_done = c->fence_events[slot];
     return MAPN_OK;
 }
 
@@ -164,7 +166,11 @@ uint32_t active_bodies(int num_active, uint32_t n)
     return (uint32_t)std::min<uint64_t>(groups * kBlock, n);
 }
 
-// Pick the j-split so that the launch puts >= ~6 waves on each of the 4*CUs SIMDs.
+// Plan of the all-pairs launch.  Measured on MI355X (profiles/r01_sweep*.txt): the scalar-cache
+// kernel beats the LDS-tiled one by ~5 % at every size; 2 bodies per lane win up to ~128 Ki
+// bodies and 4 above; 8 waves per workgroup; and the j-range wants to be cut S = 64..128 ways
+// (several rounds of workgroups per CU balance the tail better than one fully resident round:
+// at 65 536 bodies S = 64 runs the force kernel in 0.884 ms against 1.018 ms for S = 8).
 mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_total, uint32_t nseg, bool allow_fused)
 {
     mapn::ForcePlan p{};
@@ -174,13 +180,12 @@ mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_tota
         if (!allow_fused || p.sb != 1 || nseg != 1) p.fused = false;
         return p;
     }
-    p.kind = c->cfg.kernel == MAPN_KERNEL_SCALAR ? mapn::KERNEL_SGPR : mapn::KERNEL_LDS;
-    p.k = 4;
+    p.kind = c->cfg.kernel == MAPN_KERNEL_LDS ? mapn::KERNEL_LDS : mapn::KERNEL_SGPR;
+    p.k = i_count >= 196608u ? 4 : 2;
     p.nseg = nseg;
-    const uint64_t simds = (uint64_t)c->cus * 4;
     const uint64_t i_waves = (i_count + 64ull * p.k - 1) / (64ull * p.k);
-    const uint64_t want = simds * 6;                       // target waves in flight
-    uint64_t S = (want + i_waves - 1) / i_waves;           // total j-split
+    const uint64_t target = (uint64_t)c->cus * 4 * 32;     // 32768 waves on 256 CUs
+    uint64_t S = std::min<uint64_t>(128, std::max<uint64_t>(64, (target + i_waves - 1) / i_waves));
     const uint64_t tiles = std::max<uint64_t>(1, (j_total / std::max(1u, nseg) + 63) / 64);
     S = std::max<uint64_t>(1, std::min<uint64_t>(S, tiles));
     if (S <= 16) {
@@ -189,8 +194,9 @@ mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_tota
         p.waves = std::max(w, 4u);
         p.sb = 1;
     } else {
-        p.waves = 8;
-        p.sb = (uint32_t)((S + 7) / 8);
+        p.waves = i_waves <= 128 ? 16 : 8;                 // few i-tiles (a shard): 16-wave workgroups
+        if (i_waves <= 128) S = std::min<uint64_t>(256, tiles);
+        p.sb = (uint32_t)((S + p.waves - 1) / p.waves);
         if (p.sb > 8) p.sb = (p.sb + 7) / 8 * 8;          // multiples of 8 rows: XCD-aware remap
     }
     p.fused = allow_fused && p.sb == 1 && nseg == 1;
@@ -278,12 +284,12 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
         fill_segment(a, 0, 0, c->n, 0, S);
         if (!plan.fused) {
             a.partial_stride = (i_count + 63u) & ~63u;
-            if (int rc = ensure_partial(c, S, a.partial_stride)) return rc;
+            if (int rc = ensure_partial(c, plan.sb, a.partial_stride)) return rc;   // one row per block row
             a.partial = c->partial;
         }
         HIP_TRY(mapn::launch_force(plan, a, c->compute));
         if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
-        if (!plan.fused) HIP_TRY(mapn::launch_reduce_integrate(a, S, c->compute));
+        if (!plan.fused) HIP_TRY(mapn::launch_reduce_integrate(a, plan.sb, c->compute));
     } else if (i_count > 0) {
         // sharded: own slice first (needs only data this rank wrote), then the remote segments
         // once the all-gather that filled the read buffer has finished
@@ -291,7 +297,7 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
         mapn::ForcePlan own = choose_plan(c, i_count, own_count, 1, false);
         mapn::ForcePlan rem = choose_plan(c, i_count, c->n - own_count, 2, false);
         const uint32_t S_own = own.sb * own.waves, S_rem = rem.sb * rem.waves;
-        const uint32_t slots = S_own + 2 * S_rem;
+        const uint32_t slots = own.sb + 2 * rem.sb;        // partial rows: one per block row per segment
         a.partial_stride = (i_count + 63u) & ~63u;
         if (int rc = ensure_partial(c, slots, a.partial_stride)) return rc;
         a.partial = c->partial;
@@ -299,8 +305,8 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
         HIP_TRY(mapn::launch_force(own, a, c->compute));
         if (c->gather_recorded[r]) HIP_TRY(hipStreamWaitEvent(c->compute, c->gather_done[r], 0));
         mapn::StepArgs b = a;
-        fill_segment(b, 0, 0, own_first, S_own, S_rem);
-        fill_segment(b, 1, own_first + own_count, c->n - own_first - own_count, S_own + S_rem, S_rem);
+        fill_segment(b, 0, 0, own_first, own.sb, S_rem);
+        fill_segment(b, 1, own_first + own_count, c->n - own_first - own_count, own.sb + rem.sb, S_rem);
         HIP_TRY(mapn::launch_force(rem, b, c->compute));
         if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
         HIP_TRY(mapn::launch_reduce_integrate(a, slots, c->compute));
@@ -312,8 +318,7 @@ int enqueue_gather(mapn_ctx *c)
 {
     if (!c->comm) return MAPN_OK;
     const uint32_t w = c->buffer_index;
-    HIP_TRY(hipEventRecord(c->integrate_done, c->compute));
-    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->integrate_done, 0));
+    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->step_done, 0));   // = this step's fence event
     // in place: every rank's slice sits at its own offset of the full buffer
     if (int rc = mapn::comm_all_gather_inplace(c->comm, c->pos[w], (size_t)c->count * 4, c->comm_stream))
         return fail(MAPN_ERR_COMM, "all-gather failed: %s", mapn::comm_last_error());
@@ -380,8 +385,6 @@ int create_common(const mapn_config *cfg, mapn_ctx **out)
         HIP_TRY(hipEventCreate(&c->timers[k].force_done));
         HIP_TRY(hipEventCreate(&c->timers[k].stop));
     }
-    HIP_TRY(hipEventCreateWithFlags(&c->step_done, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->integrate_done, hipEventDisableTiming));
     for (int b = 0; b < 2; b++) HIP_TRY(hipEventCreateWithFlags(&c->gather_done[b], hipEventDisableTiming));
     // Compute.cpp:434-436: fence created with value 0, m_fenceValue++ -> 1
     c->fence_value = 1;
@@ -487,8 +490,6 @@ int mapn_destroy(mapn_ctx *c)
         if (c->timers[k].force_done) hipEventDestroy(c->timers[k].force_done);
         if (c->timers[k].stop) hipEventDestroy(c->timers[k].stop);
     }
-    if (c->step_done) hipEventDestroy(c->step_done);
-    if (c->integrate_done) hipEventDestroy(c->integrate_done);
     if (c->compute) hipStreamDestroy(c->compute);
     if (c->comm_stream) hipStreamDestroy(c->comm_stream);
     delete c;
@@ -506,7 +507,7 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
     const uint32_t active = active_bodies(num_active, c->n);
 
     StepTimer *timer = nullptr;
-    if (c->timers_enabled) {
+    if (c->timers_enabled && (c->steps_enqueued++ % c->timer_interval) == 0) {
         timer = &c->timers[c->timer_head];
         if (timer->pending) { if (int rc = resolve_timers(c, true)) return rc; }
         timer->has_force = false;
@@ -517,13 +518,12 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
         timer->pending = true;
         c->timer_head = (c->timer_head + 1) % kTimerRing;
     }
-    if (int rc = enqueue_gather(c)) return rc;
     // MoveToNextFrame, Compute.cpp:993-1004: Signal(fence, v); v++; index = 1 - index
-    HIP_TRY(hipEventRecord(c->step_done, c->compute));
     if (int rc = signal_fence(c, c->fence_value)) return rc;
+    if (int rc = enqueue_gather(c)) return rc;            // sharded: all-gather behind the fence event
     c->fence_value++;
     c->buffer_index = 1 - c->buffer_index;
-    if (c->timers_enabled && (c->timer_head % 16) == 0) resolve_timers(c, false);
+    if (timer && (c->timer_head % 16) == 0) resolve_timers(c, false);
     return MAPN_OK;
 }
 
@@ -747,11 +747,13 @@ int mapn_set_force_plan(mapn_ctx *c, int kernel, uint32_t bodies_per_lane, uint3
     return MAPN_OK;
 }
 
-int mapn_set_timers(mapn_ctx *c, int enabled)
+int mapn_set_timers(mapn_ctx *c, int interval)
 {
-    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    if (!c || interval < 0) return fail(MAPN_ERR_INVALID_ARGUMENT, "set_timers: bad argument");
     if (int rc = mapn_wait_idle(c)) return rc;
-    c->timers_enabled = enabled != 0;
+    c->timers_enabled = interval != 0;
+    c->timer_interval = interval > 0 ? (uint32_t)interval : 1;
+    c->steps_enqueued = 0;
     return MAPN_OK;
 }
 

@@ -126,39 +126,34 @@ __device__ __forceinline__ void load_bodies(Bodies<K2> &b, const StepArgs &p, ui
     }
 }
 
-// epilogue shared by both force kernels
+// epilogue shared by both force kernels: the WAVES chunk sums of a workgroup are combined in LDS
+// in ascending wave order (fixed order, no atomics); the workgroup then either integrates its
+// bodies in place (FUSED: it has seen every chunk of them) or stores ONE partial sum per body
+// into row seg_slot[seg] + by of the scratch buffer for reduce_integrate_kernel.
 template <int K2, int WAVES, bool FUSED>
-__device__ __forceinline__ void finish(const Bodies<K2> &b, const StepArgs &p, uint32_t bx, uint32_t w,
-                                       uint32_t lane, uint32_t seg, uint32_t c,
+__device__ __forceinline__ void finish(const Bodies<K2> &b, const StepArgs &p, uint32_t bx, uint32_t by,
+                                       uint32_t w, uint32_t lane, uint32_t seg,
                                        float (*red)[3][128 * K2])
 {
-    if constexpr (FUSED) {
-        // fixed-order combine of the WAVES chunk sums in LDS, then integrate in place
 #pragma unroll
-        for (int k = 0; k < K2; k++) {
-            red[w][0][(2 * k) * 64 + lane] = b.acc[k].x.x; red[w][0][(2 * k + 1) * 64 + lane] = b.acc[k].x.y;
-            red[w][1][(2 * k) * 64 + lane] = b.acc[k].y.x; red[w][1][(2 * k + 1) * 64 + lane] = b.acc[k].y.y;
-            red[w][2][(2 * k) * 64 + lane] = b.acc[k].z.x; red[w][2][(2 * k + 1) * 64 + lane] = b.acc[k].z.y;
-        }
-        __syncthreads();
-        for (uint32_t e = threadIdx.x; e < 128u * K2; e += 64u * WAVES) {
-            const uint32_t li = bx * (128u * K2) + e;
-            if (li < p.i_count) {
-                float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int k = 0; k < K2; k++) {
+        red[w][0][(2 * k) * 64 + lane] = b.acc[k].x.x; red[w][0][(2 * k + 1) * 64 + lane] = b.acc[k].x.y;
+        red[w][1][(2 * k) * 64 + lane] = b.acc[k].y.x; red[w][1][(2 * k + 1) * 64 + lane] = b.acc[k].y.y;
+        red[w][2][(2 * k) * 64 + lane] = b.acc[k].z.x; red[w][2][(2 * k + 1) * 64 + lane] = b.acc[k].z.y;
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < 128u * K2; e += 64u * WAVES) {
+        const uint32_t li = bx * (128u * K2) + e;
+        if (li < p.i_count) {
+            float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
-                for (int ww = 0; ww < WAVES; ww++) { ax += red[ww][0][e]; ay += red[ww][1][e]; az += red[ww][2][e]; }
+            for (int ww = 0; ww < WAVES; ww++) { ax += red[ww][0][e]; ay += red[ww][1][e]; az += red[ww][2][e]; }
+            if constexpr (FUSED) {
                 const uint32_t i = p.i_first + li;
                 integrate_store(p, i, p.pos_old[i], ax * p.mass, ay * p.mass, az * p.mass);
+            } else {
+                p.partial[(size_t)(p.seg_slot[seg] + by) * p.partial_stride + li] = make_float4(ax, ay, az, 0.f);
             }
-        }
-    } else {
-        // partial[slot][i_local], slot = seg_slot[seg] + c ; coalesced float4 stores
-        float4 *out = p.partial + (size_t)(p.seg_slot[seg] + c) * p.partial_stride;
-#pragma unroll
-        for (int k = 0; k < K2; k++) {
-            const uint32_t l0 = (bx * (2 * K2) + 2 * k) * 64u + lane, l1 = l0 + 64u;
-            if (l0 < p.i_count) out[l0] = make_float4(b.acc[k].x.x, b.acc[k].y.x, b.acc[k].z.x, 0.f);
-            if (l1 < p.i_count) out[l1] = make_float4(b.acc[k].x.y, b.acc[k].y.y, b.acc[k].z.y, 0.f);
         }
     }
 }
@@ -180,7 +175,7 @@ __global__ __launch_bounds__(64 * WAVES) void force_lds_kernel(const StepArgs p)
 {
     __shared__ float4 tile_xy[WAVES][2][32];
     __shared__ float4 tile_zz[WAVES][2][16];
-    __shared__ float red[FUSED ? WAVES : 1][3][128 * K2];
+    __shared__ float red[WAVES][3][128 * K2];
 
     uint32_t bx, by;
     xcd_remap(bx, by);
@@ -248,7 +243,7 @@ __global__ __launch_bounds__(64 * WAVES) void force_lds_kernel(const StepArgs p)
             __builtin_amdgcn_wave_barrier();
         }
     }
-    finish<K2, WAVES, FUSED>(b, p, bx, w, lane, seg, c, red);
+    finish<K2, WAVES, FUSED>(b, p, bx, by, w, lane, seg, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -260,7 +255,7 @@ __global__ __launch_bounds__(64 * WAVES) void force_lds_kernel(const StepArgs p)
 template <int K2, int WAVES, bool FUSED>
 __global__ __launch_bounds__(64 * WAVES) void force_sgpr_kernel(const StepArgs p)
 {
-    __shared__ float red[FUSED ? WAVES : 1][3][128 * K2];
+    __shared__ float red[WAVES][3][128 * K2];
 
     uint32_t bx, by;
     xcd_remap(bx, by);
@@ -293,7 +288,7 @@ __global__ __launch_bounds__(64 * WAVES) void force_sgpr_kernel(const StepArgs p
 #pragma unroll
         for (int k = 0; k < K2; k++) pair_term2(b.acc[k], b.xi[k], b.yi[k], b.zi[k], bj.x, bj.y, bj.z, soft2);
     }
-    finish<K2, WAVES, FUSED>(b, p, bx, w, lane, seg, c, red);
+    finish<K2, WAVES, FUSED>(b, p, bx, by, w, lane, seg, red);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -83,6 +83,27 @@ def cpu_baseline(n, seed, target_seconds):
             "cpu": model}
 
 
+def pmc_traffic(kernel_name, n, world):
+    """HBM bytes per force launch from the committed PMC passes (profiles/*_pmc_summary.json,
+    collected with separate rocprofv3 --pmc runs of this same command and corrected as the
+    MI355X guide prescribes: 2 x FETCH_SIZE + WRITE_SIZE).  PMC counters cannot be read from
+    inside an un-profiled run, so this is the profiled value for the default 65 536-body
+    single-GPU workload, or None for any other configuration."""
+    if n != 65536 or world != 1:
+        return None, None
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        for k, v in d.items():
+            if kernel_name in k and "hbm_bytes_per_launch" in v:
+                return v["hbm_bytes_per_launch"], os.path.relpath(f, here)
+    return None, None
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -185,8 +206,10 @@ def main():
             if st.launches and st.avg_seconds > 0:
                 pairs_per_launch = float(count) * float(n)
                 ach = FLOP_PER_PAIR * pairs_per_launch / st.avg_seconds / 1e12
+                traffic, traffic_src = pmc_traffic(st.kernel_name.decode(), n, world)
                 out["roofline"] = {"bound": "valu_fp32", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                                   "traffic": None, "kernel": st.kernel_name.decode(), "launches_timed": int(st.launches),
+                                   "traffic": traffic, "traffic_unit": "HBM bytes per force launch (2*FETCH_SIZE+WRITE_SIZE, PMC)",
+                                   "traffic_source": traffic_src, "kernel": st.kernel_name.decode(), "launches_timed": int(st.launches),
                                    "avg_launch_ms": st.avg_seconds * 1e3, "flop_per_pair": FLOP_PER_PAIR,
                                    "pairs_per_launch": pairs_per_launch,
                                    "algorithmic_hbm_GBps": HBM_BYTES_PER_BODY * count / st.avg_seconds / 1e9,

@@ -1,0 +1,71 @@
+// particles_draw.cpp -- the reference caller's sequence (Particles.cpp:131, 446-448, 470,
+// 515-517) written against compat/Compute.hpp; built with plain g++ and linked to libmapn.so.
+// Exit code 0 = every check held.  Prints one line per check.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "Compute.hpp"
+
+using mapn::Compute;
+
+static int g_fail = 0;
+#define CHECK(cond)                                                      \
+    do {                                                                 \
+        const bool ok_ = (cond);                                         \
+        std::printf("%s  %s\n", ok_ ? "ok  " : "FAIL", #cond);           \
+        if (!ok_) g_fail++;                                              \
+    } while (0)
+
+int main(int argc, char **argv)
+{
+    const bool compile_only = argc > 1 && std::strcmp(argv[1], "--no-device") == 0;
+    if (compile_only || mapn_device_count() == 0) {
+        // no device: constructing must throw, never fall back to a CPU path
+        bool threw = false;
+        try { Compute c(4096, 0, false); } catch (const mapn::MapnException &e) { threw = e.Error() == MAPN_ERR_NO_DEVICE; }
+        CHECK(threw || mapn_device_count() > 0);
+        return g_fail;
+    }
+    const uint32_t n = 4096;
+    mapn_config cfg;
+    mapn_config_default(&cfg);
+    cfg.mass = 70000.0f / n;
+    std::unique_ptr<Compute> pCompute(new Compute(n, 0, false, nullptr, &cfg));    // Particles.cpp:131
+    CHECK(pCompute->GetFenceValue() == 4);
+    std::vector<Compute::Particle> p0(n), p1(n);
+    std::vector<Compute::ParticleVelocity> v0(n), v1(n);
+    pCompute->DownloadState(p0.data(), v0.data());
+    for (int frame = 0; frame < 10; frame++) {                                       // Particles::Draw
+        const uint64_t renderSharedFenceValue = pCompute->GetFenceValue();           // :446
+        pCompute->Simulate((int)n, renderSharedFenceValue);                          // :448
+    }
+    pCompute->WaitForGpu();                                                           // :470
+    CHECK(pCompute->GetFenceValue() == 4 + 10 + 1);
+    pCompute->DownloadState(p1.data(), v1.data());
+    double moved = 0, wsum = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        moved += std::fabs(p1[i].position[0] - p0[i].position[0]);
+        wsum += p1[i].position[3];
+    }
+    CHECK(moved > 0 && std::isfinite(moved));
+    CHECK(wsum > 0);                                                                  // w = |accel| (hlsl:107)
+    auto times = pCompute->GetGpuTimes();
+    CHECK(times.size() == 1 && times[0].second == "simulate ms" && times[0].first > 0);
+    // live adapter switch (Particles.cpp:511-517): new Compute(..., pOldCompute) then delete old
+    Compute *pOld = pCompute.release();
+    pCompute.reset(new Compute(n, 0, false, pOld, &cfg));
+    delete pOld;
+    std::vector<Compute::Particle> p2(n);
+    std::vector<Compute::ParticleVelocity> v2(n);
+    pCompute->DownloadState(p2.data(), v2.data());
+    CHECK(std::memcmp(p1.data(), p2.data(), n * sizeof(Compute::Particle)) == 0);
+    CHECK(std::memcmp(v1.data(), v2.data(), n * sizeof(Compute::ParticleVelocity)) == 0);
+    bool threw = false;
+    try { pCompute->GetSharedHandles(true); pCompute->Simulate((int)n, pCompute->GetFenceValue()); }
+    catch (const mapn::MapnException &e) { threw = e.Error() == MAPN_ERR_STATE; }
+    CHECK(threw);                                                                     // consumer never signalled
+    return g_fail;
+}

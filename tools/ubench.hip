@@ -13,10 +13,10 @@
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-enum Mix { FMA = 0, PKFMA, RSQ, PAIR_SCALAR, PAIR_PK, FMA_SGPR, PKFMA_BCAST, MIXES };
-static const char *mix_name[MIXES] = {"v_fma_f32 x16", "v_pk_fma_f32 x16", "v_rsq_f32 x16", "pair scalar (12 ops)", "pair packed (2 bodies)", "v_fma_f32 sgpr-src x16", "v_pk_fma_f32 op_sel bcast x16"};
-static const int mix_insts[MIXES] = {16, 16, 16, 12 * 4, 13 * 2, 16, 16};      // wave-instructions per loop body
-static const double mix_pairs[MIXES] = {0, 0, 0, 4, 4, 0, 0};                  // pairs per lane per loop body
+enum Mix { FMA = 0, PKFMA, RSQ, PAIR_SCALAR, PAIR_PK, FMA_SGPR, PKFMA_BCAST, PAIR_MFMA, MFMA4, PAIR_PK8, MIXES };
+static const char *mix_name[MIXES] = {"v_fma_f32 x16", "v_pk_fma_f32 x16", "v_rsq_f32 x16", "pair scalar (12 ops)", "pair packed (2 bodies)", "v_fma_f32 sgpr-src x16", "v_pk_fma_f32 op_sel bcast x16", "pair packed, accumulate on mfma 4x4x1", "v_mfma_f32_4x4x1_16b x8", "8 pk + 2 rsq (no accumulate)"};
+static const int mix_insts[MIXES] = {16, 16, 16, 12 * 4, 13 * 2, 16, 16, 12 * 2, 8, 10 * 2};      // wave-instructions per loop body
+static const double mix_pairs[MIXES] = {0, 0, 0, 4, 4, 0, 0, 4, 0, 4};                  // pairs per lane per loop body
 
 template <int MIX>
 __global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, unsigned long long *rt, int iters, float seed)
@@ -28,6 +28,9 @@ __global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, u
     const float m = 0.999f, c = 0.0001f;
     float sx = seed * 3.f, sy = seed * 5.f, sz = seed * 7.f, soft2 = 25.f;
     asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sx) : "v"(seed * 3.f));
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v macc[4];
+    for (int i = 0; i < 4; i++) macc[i] = f4v{0.f, 0.f, 0.f, 0.f};
     unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; it++) {
@@ -76,11 +79,37 @@ __global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, u
                              : "+v"(p[6 + k]), "+v"(p[8 + k]), "+v"(p[10 + k]) : "v"(dx), "v"(dy), "v"(dz), "v"(i3));
             }
         }
+        if (MIX == PAIR_MFMA || MIX == PAIR_PK8) {
+            // 2 bodies per packed op, one j, x2: 3 pk_add, 3 pk_fma, 2 rsq, 2 pk_mul, then the
+            // accumulation as one v_mfma_f32_4x4x1_16b per body (A = s of the 64 lanes' bodies,
+            // B = (x_j, y_j, z_j, 1) by lane % 4) instead of 3 pk_fma
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                float2v dx, dy, dz, d, inv, i3;
+                asm volatile(
+                    "v_pk_add_f32 %0, %9, %6 neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %1, %10, %7 neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %2, %11, %8 neg_lo:[0,1] neg_hi:[0,1]\n"
+                    "v_pk_fma_f32 %3, %0, %0, %12\n v_pk_fma_f32 %3, %1, %1, %3\n v_pk_fma_f32 %3, %2, %2, %3\n"
+                    : "=&v"(dx), "=&v"(dy), "=&v"(dz), "=&v"(d), "=&v"(inv), "=&v"(i3)
+                    : "v"(p[3 * k]), "v"(p[3 * k + 1]), "v"(p[3 * k + 2]), "v"(p[12]), "v"(p[13]), "v"(p[14]), "v"(p[15]));
+                asm volatile("v_rsq_f32 %0, %2\n v_rsq_f32 %1, %3" : "=&v"(inv.x), "=&v"(inv.y) : "v"(d.x), "v"(d.y));
+                asm volatile("v_pk_mul_f32 %0, %1, %1\n v_pk_mul_f32 %0, %0, %1" : "=&v"(i3) : "v"(inv));
+                if (MIX == PAIR_MFMA) {
+                    macc[2 * k] = __builtin_amdgcn_mfma_f32_4x4x1f32(i3.x, a[15], macc[2 * k], 0, 0, 0);
+                    macc[2 * k + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(i3.y, a[15], macc[2 * k + 1], 0, 0, 0);
+                } else {
+                    asm volatile("" :: "v"(i3));
+                }
+            }
+        } else if (MIX == MFMA4) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) macc[i & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[i], a[15], macc[i & 3], 0, 0, 0);
+        }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0;
     for (int i = 0; i < 16; i++) s += a[i] + p[i].x + p[i].y;
+    for (int i = 0; i < 4; i++) s += macc[i].x + macc[i].y + macc[i].z + macc[i].w;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) {
         int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -138,6 +167,6 @@ int main(int argc, char **argv)
     hipDeviceProp_t pr; CHECK(hipGetDeviceProperties(&pr, 0));
     printf("device: %s  arch=%s  CUs=%d  clock=%d kHz  wave=%d\n", pr.name, pr.gcnArchName, pr.multiProcessorCount, pr.clockRate, pr.warpSize);
     sweep<FMA>(iters); sweep<FMA_SGPR>(iters); sweep<PKFMA>(iters); sweep<PKFMA_BCAST>(iters); sweep<RSQ>(iters);
-    sweep<PAIR_SCALAR>(iters); sweep<PAIR_PK>(iters);
+    sweep<PAIR_SCALAR>(iters); sweep<PAIR_PK>(iters); sweep<PAIR_PK8>(iters); sweep<PAIR_MFMA>(iters); sweep<MFMA4>(iters);
     return 0;
 }

@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--overlap", action="store_true", help="sharded mode: own-segment launch overlapped with the all-gather")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="create the torch.distributed group and the in-library RCCL communicator even for one rank (exercises the sharded code path on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -115,7 +118,8 @@ def main():
         a.gpus = world
     dist = None
     torch = None
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or (a.force_comm and under_launcher):
         import torch            # first: its HIP runtime is then the one libmapn binds to
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -127,13 +131,13 @@ def main():
 
     n = a.bodies
     mode = mapn.FORCE_ALL_PAIRS if a.mode == "all_pairs" else mapn.FORCE_CENTRAL_WELL
-    flags = mapn.FLAG_USE_GRAPH if a.graph else 0
+    flags = (mapn.FLAG_USE_GRAPH if a.graph else 0) | (mapn.FLAG_SHARD_OVERLAP if a.overlap else 0)
     c = mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed,
                      rank=rank, world_size=world, flags=flags)
     info = device_info(local_rank)
     transport = "none"
     gather_fn = None
-    if world > 1:
+    if dist is not None:
         transport = a.transport
         if transport == "rccl":
             try:

@@ -58,6 +58,7 @@ typedef enum mapn_kernel {
 
 #define MAPN_FLAG_USE_GRAPH   0x1u  /* replay the step from a captured hipGraph */
 #define MAPN_FLAG_NO_INIT     0x2u  /* leave state zeroed; caller will mapn_upload_state() */
+#define MAPN_FLAG_SHARD_OVERLAP 0x4u /* sharded mode: own-segment launch overlapped with the all-gather */
 
 /*
  * Everything `Compute::Compute(numParticles, adapter, useIntelExt, old)` (Compute.h:36-39)

@@ -15,6 +15,7 @@ FORCE_CENTRAL_WELL = 1     # CSMain as shipped, nBodyGravityCS.hlsl:92-101
 KERNEL_AUTO, KERNEL_LDS, KERNEL_SCALAR, KERNEL_MFMA = 0, 1, 2, 3
 FLAG_USE_GRAPH = 0x1
 FLAG_NO_INIT = 0x2
+FLAG_SHARD_OVERLAP = 0x4
 UNIQUE_ID_BYTES = 128
 
 

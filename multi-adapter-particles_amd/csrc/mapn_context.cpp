@@ -203,6 +203,19 @@ mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_tota
     return p;
 }
 
+// MAPN_OWN_PLAN / MAPN_REM_PLAN = "k,waves,sb": tuning override of the two sharded launches
+bool env_plan(const char *name, mapn::ForcePlan &p)
+{
+    const char *e = getenv(name);
+    unsigned k = 0, w = 0, sb = 0;
+    if (!e || sscanf(e, "%u,%u,%u", &k, &w, &sb) != 3) return false;
+    mapn::ForcePlan q = p;
+    q.k = k; q.waves = w; q.sb = sb; q.fused = false;
+    if (!mapn::force_plan_supported(q)) return false;
+    p = q;
+    return true;
+}
+
 int ensure_partial(mapn_ctx *c, size_t slots, size_t stride)
 {
     const size_t need = slots * stride * sizeof(float4);
@@ -273,12 +286,16 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
     a.i_first = lo;
     a.i_count = i_count;
     const bool sharded_native = c->comm != nullptr;
+    const bool overlap = sharded_native && (c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP);
 
     if (timer) HIP_TRY(hipEventRecord(timer->start, c->compute));
 
     if (i_count > 0 && c->cfg.force_mode == MAPN_FORCE_CENTRAL_WELL) {
         HIP_TRY(mapn::launch_central_well(a, c->compute));
-    } else if (i_count > 0 && !sharded_native) {
+    } else if (i_count > 0 && !overlap) {
+        // one force launch over all j.  Sharded: the read buffer is complete once the all-gather
+        // that filled it has finished (event recorded on the comm stream).
+        if (sharded_native && c->gather_recorded[r]) HIP_TRY(hipStreamWaitEvent(c->compute, c->gather_done[r], 0));
         mapn::ForcePlan plan = choose_plan(c, i_count, c->n, 1, true);
         const uint32_t S = plan.sb * plan.waves;
         fill_segment(a, 0, 0, c->n, 0, S);
@@ -291,11 +308,17 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
         if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
         if (!plan.fused) HIP_TRY(mapn::launch_reduce_integrate(a, plan.sb, c->compute));
     } else if (i_count > 0) {
-        // sharded: own slice first (needs only data this rank wrote), then the remote segments
-        // once the all-gather that filled the read buffer has finished
+        // sharded with MAPN_FLAG_SHARD_OVERLAP: own slice first (needs only data this rank wrote),
+        // then the remote segments once the all-gather that filled the read buffer has finished.
+        // Measured on MI355X at the 8-way shard size of the 65 536-body job (8192 x 65536 pairs,
+        // profiles/r01_shard_structure.txt): 0.154 ms per step against 0.126 ms for the single
+        // launch above -- the split costs more (two under-filled launches, one more boundary,
+        // more partial rows) than the ~20 us of all-gather it can hide, so it is opt-in.
         const uint32_t own_first = c->first, own_count = c->count;
         mapn::ForcePlan own = choose_plan(c, i_count, own_count, 1, false);
         mapn::ForcePlan rem = choose_plan(c, i_count, c->n - own_count, 2, false);
+        env_plan("MAPN_OWN_PLAN", own);
+        env_plan("MAPN_REM_PLAN", rem);
         const uint32_t S_own = own.sb * own.waves, S_rem = rem.sb * rem.waves;
         const uint32_t slots = own.sb + 2 * rem.sb;        // partial rows: one per block row per segment
         a.partial_stride = (i_count + 63u) & ~63u;
@@ -318,12 +341,21 @@ int enqueue_gather(mapn_ctx *c)
 {
     if (!c->comm) return MAPN_OK;
     const uint32_t w = c->buffer_index;
-    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->step_done, 0));   // = this step's fence event
-    // in place: every rank's slice sits at its own offset of the full buffer
-    if (int rc = mapn::comm_all_gather_inplace(c->comm, c->pos[w], (size_t)c->count * 4, c->comm_stream))
+    const bool overlap = (c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP) != 0;
+    // in place: every rank's slice sits at its own offset of the full buffer.
+    // Default structure: the collective is enqueued on the COMPUTE stream right behind the
+    // integrate kernel -- plain stream order, no cross-stream event hops (each costs 5-10 us of
+    // queue latency, which matters when a sharded step is ~0.12 ms).  Overlap structure: on the
+    // comm stream, behind this step's fence event, so that the next step's own-segment launch
+    // runs beside it.
+    hipStream_t st = overlap ? c->comm_stream : c->compute;
+    if (overlap) HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->step_done, 0));   // = this step's fence event
+    if (int rc = mapn::comm_all_gather_inplace(c->comm, c->pos[w], (size_t)c->count * 4, st))
         return fail(MAPN_ERR_COMM, "all-gather failed: %s", mapn::comm_last_error());
-    HIP_TRY(hipEventRecord(c->gather_done[w], c->comm_stream));
-    c->gather_recorded[w] = true;
+    if (overlap) {
+        HIP_TRY(hipEventRecord(c->gather_done[w], c->comm_stream));
+        c->gather_recorded[w] = true;
+    }
     return MAPN_OK;
 }
 
@@ -519,8 +551,10 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
         c->timer_head = (c->timer_head + 1) % kTimerRing;
     }
     // MoveToNextFrame, Compute.cpp:993-1004: Signal(fence, v); v++; index = 1 - index
+    const bool gather_first = c->comm && !(c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP);
+    if (gather_first) { if (int rc = enqueue_gather(c)) return rc; }   // same stream: the fence then covers the gather
     if (int rc = signal_fence(c, c->fence_value)) return rc;
-    if (int rc = enqueue_gather(c)) return rc;            // sharded: all-gather behind the fence event
+    if (c->comm && !gather_first) { if (int rc = enqueue_gather(c)) return rc; }   // overlap: behind the fence event
     c->fence_value++;
     c->buffer_index = 1 - c->buffer_index;
     if (timer && (c->timer_head % 16) == 0) resolve_timers(c, false);
@@ -686,7 +720,15 @@ int mapn_comm_init(mapn_ctx *c, const void *id128)
     if (c->adopted) return fail(MAPN_ERR_STATE, "comm_init: context is in adopted-buffer (async) mode");
     HIP_TRY(hipSetDevice(c->device));
     if (c->comm) return MAPN_OK;
-    c->comm = mapn::comm_create(id128, c->cfg.rank, c->cfg.world_size);
+    // MAPN_COMM_LOOPBACK=1 (timing experiments on a 1-GPU box only): rank 0 of a P-way sharded
+    // context joins a ONE-rank communicator, so the step runs its real structure (own-segment
+    // kernel, remote-segment kernel, reduce, ncclAllGather launch) at the true shard size; the
+    // other ranks' slices are then never refreshed, so results are not a simulation.
+    const char *loop = getenv("MAPN_COMM_LOOPBACK");
+    if (loop && loop[0] == '1' && c->cfg.rank == 0)
+        c->comm = mapn::comm_create(id128, 0, 1);
+    else
+        c->comm = mapn::comm_create(id128, c->cfg.rank, c->cfg.world_size);
     if (!c->comm) return fail(MAPN_ERR_COMM, "%s", mapn::comm_last_error());
     return MAPN_OK;
 }

@@ -324,12 +324,13 @@ def test_sharded_context_requires_transport_and_single_rank_comm_works():
         assert c.shard_range() == (1024, 1024)
         with pytest.raises(mapn.MapnError):
             c.Simulate(n, 0)
-    with mapn.Compute(n, mass=70000.0 / n) as ref, mapn.Compute(n, mass=70000.0 / n) as c:
-        c.comm_init(mapn.Compute.comm_unique_id())
-        draw(ref, 3); draw(c, 3)
-        a, b = ref.download_state(), c.download_state()
-        assert errs(a[0][:, :3], b[0][:, :3], SPREAD)[0] < 1e-6
-        assert errs(a[1], b[1], SPEED)[0] < 2e-5
+    for flags in (0, mapn.FLAG_SHARD_OVERLAP):
+        with mapn.Compute(n, mass=70000.0 / n) as ref, mapn.Compute(n, mass=70000.0 / n, flags=flags) as c:
+            c.comm_init(mapn.Compute.comm_unique_id())
+            draw(ref, 3); draw(c, 3)
+            a, b = ref.download_state(), c.download_state()
+            assert errs(a[0][:, :3], b[0][:, :3], SPREAD)[0] < 1e-6
+            assert errs(a[1], b[1], SPEED)[0] < 2e-5
 
 
 def test_external_gather_slices_compose_to_the_full_step(oracle):

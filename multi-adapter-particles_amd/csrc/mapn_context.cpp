@@ -337,6 +337,44 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
     return MAPN_OK;
 }
 
+void drop_graphs(mapn_ctx *c)
+{
+    for (int b = 0; b < 2; b++) {
+        if (c->graph_exec[b]) hipGraphExecDestroy(c->graph_exec[b]);
+        c->graph_exec[b] = nullptr;
+        c->graph_active[b] = -1;
+    }
+}
+
+// MAPN_FLAG_USE_GRAPH: the step's launches (force [+ reduce/integrate]) are captured once per
+// ping-pong parity and replayed with one hipGraphLaunch.  Scratch memory is sized before the
+// capture (no allocation inside it).  A step that carries timer events runs eagerly.
+int enqueue_step_graph(mapn_ctx *c, uint32_t active)
+{
+    const uint32_t w = c->buffer_index;
+    if (!c->graph_exec[w] || c->graph_active[w] != (int)active) {
+        if (c->graph_exec[w]) { hipGraphExecDestroy(c->graph_exec[w]); c->graph_exec[w] = nullptr; }
+        const uint32_t lo = c->first, hi = std::min(c->first + c->count, active);
+        if (hi > lo && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS) {
+            mapn::ForcePlan plan = choose_plan(c, hi - lo, c->n, 1, true);
+            if (!plan.fused)
+                if (int rc = ensure_partial(c, plan.sb, ((hi - lo) + 63u) & ~63u)) return rc;
+        }
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(c->compute, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_step(c, active, nullptr);
+        hipError_t e = hipStreamEndCapture(c->compute, &graph);
+        if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) return fail(MAPN_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&c->graph_exec[w], graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e != hipSuccess) { c->graph_exec[w] = nullptr; return fail(MAPN_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+        c->graph_active[w] = (int)active;
+    }
+    HIP_TRY(hipGraphLaunch(c->graph_exec[w], c->compute));
+    return MAPN_OK;
+}
+
 int enqueue_gather(mapn_ctx *c)
 {
     if (!c->comm) return MAPN_OK;
@@ -544,7 +582,8 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
         if (timer->pending) { if (int rc = resolve_timers(c, true)) return rc; }
         timer->has_force = false;
     }
-    if (int rc = enqueue_step(c, active, timer)) return rc;
+    const bool use_graph = (c->cfg.flags & MAPN_FLAG_USE_GRAPH) && !c->comm && !timer && active > 0;
+    if (int rc = use_graph ? enqueue_step_graph(c, active) : enqueue_step(c, active, timer)) return rc;
     if (timer) {
         HIP_TRY(hipEventRecord(timer->stop, c->compute));              // Compute.cpp:1046-1047
         timer->pending = true;
@@ -631,6 +670,7 @@ int mapn_adopt_position_buffers(mapn_ctx *c, void *buffers[2], uint32_t buffer_i
     c->pos[1] = static_cast<float4 *>(buffers[1]);
     c->adopted = true;
     c->buffer_index = 1 - buffer_index;
+    drop_graphs(c);
     return MAPN_OK;
 }
 
@@ -645,6 +685,7 @@ int mapn_reset_from_async(mapn_ctx *c)
     c->pos[0] = c->pos_own[0];
     c->pos[1] = c->pos_own[1];
     c->adopted = false;
+    drop_graphs(c);
     return MAPN_OK;
 }
 
@@ -778,7 +819,7 @@ int mapn_get_device_info(int device, mapn_device_info *out)
 int mapn_set_force_plan(mapn_ctx *c, int kernel, uint32_t bodies_per_lane, uint32_t waves, uint32_t sb, int fused)
 {
     if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
-    if (kernel == MAPN_KERNEL_AUTO) { c->plan_forced = false; return MAPN_OK; }
+    if (kernel == MAPN_KERNEL_AUTO) { c->plan_forced = false; drop_graphs(c); return MAPN_OK; }
     mapn::ForcePlan p{};
     p.kind = kernel == MAPN_KERNEL_SCALAR ? mapn::KERNEL_SGPR : mapn::KERNEL_LDS;
     p.k = bodies_per_lane; p.waves = waves; p.sb = sb; p.nseg = 1; p.fused = fused != 0 && sb == 1;
@@ -786,6 +827,7 @@ int mapn_set_force_plan(mapn_ctx *c, int kernel, uint32_t bodies_per_lane, uint3
         return fail(MAPN_ERR_INVALID_ARGUMENT, "unsupported force plan kernel=%d k=%u waves=%u sb=%u", kernel, bodies_per_lane, waves, sb);
     c->forced_plan = p;
     c->plan_forced = true;
+    drop_graphs(c);
     return MAPN_OK;
 }
 

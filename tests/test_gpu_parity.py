@@ -141,6 +141,24 @@ def test_variants_agree_bitwise_when_split_is_equal():
     np.testing.assert_array_equal(res[0][0], res[2][0])
 
 
+def test_graph_replay_is_bit_identical_to_eager():
+    """MAPN_FLAG_USE_GRAPH (BASELINE config #3: hipGraph-captured step): same bits as eager
+    launches, including a change of num_active (re-capture) and timer-sampled steps."""
+    n = 8192
+    out = []
+    for flags in (0, mapn.FLAG_USE_GRAPH):
+        with mapn.Compute(n, mass=70000.0 / n, flags=flags) as c:
+            c.set_timers(4)
+            draw(c, 9)
+            draw(c, 3, num_active=5000)
+            draw(c, 4)
+            out.append((c.download_buffer(0), c.download_buffer(1), c.GetFenceValue()))
+    for b in (0, 1):
+        np.testing.assert_array_equal(out[0][b][0], out[1][b][0])
+        np.testing.assert_array_equal(out[0][b][1], out[1][b][1])
+    assert out[0][2] == out[1][2]
+
+
 def test_all_pairs_golden_config1_100_steps(oracle, golden_dir):
     """BASELINE config #1 (4 096 bodies, 100 steps) against the committed oracle state."""
     import os

@@ -191,6 +191,26 @@ int mapn_download_state(mapn_ctx *ctx, float *pos4, float *vel3);
 int mapn_download_buffer(mapn_ctx *ctx, uint32_t index, float *pos4, float *vel3);
 
 /*
+ * Consumer hand-off, what Render::CopySimulationResults does (Render.cpp:789-831): on the
+ * CONSUMER's stream (hipStream_t), wait for the latest step's completion event, then copy the
+ * first num_copied positions (num_copied * 16 bytes, Render.cpp:814) of the latest buffer to
+ * `dst` (device or pinned host memory).  Asynchronous; the consumer then records an event on its
+ * stream and reports it with mapn_consumer_signal_event(value = the fence value it waited for),
+ * which is what lets the next mapn_simulate overwrite that buffer (Compute.cpp:1012).
+ */
+int mapn_copy_positions_async(mapn_ctx *ctx, uint32_t num_copied, void *dst, void *consumer_stream);
+
+/*
+ * On-disk snapshot (the reference has only the in-memory CopyState, Compute.cpp:303-410):
+ * little-endian, 32-byte header {"MAPNSNAP", u32 version = 1, u32 N, u32 buffer_index,
+ * u32 reserved, u64 fence_value}, then for buffer 0 and 1: float4[N] positions, float3[N]
+ * velocities.  Both ping-pong buffers are stored so that a restored context continues
+ * bit-identically (including bodies frozen by num_active < N).
+ */
+int mapn_save_snapshot(mapn_ctx *ctx, const char *path);
+int mapn_load_snapshot(mapn_ctx *ctx, const char *path);
+
+/*
  * LoadParticles / InitializeParticles (Compute.cpp:667-812, 820-844), made deterministic:
  * host-side generator, no device needed.  See csrc/mapn_init.cpp for the specification.
  */

@@ -90,6 +90,9 @@ SIGNATURES = {
     "mapn_upload_state": (C.c_int, [_ctx, _fp, _fp]),
     "mapn_download_state": (C.c_int, [_ctx, _fp, _fp]),
     "mapn_download_buffer": (C.c_int, [_ctx, C.c_uint32, _fp, _fp]),
+    "mapn_copy_positions_async": (C.c_int, [_ctx, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "mapn_save_snapshot": (C.c_int, [_ctx, C.c_char_p]),
+    "mapn_load_snapshot": (C.c_int, [_ctx, C.c_char_p]),
     "mapn_generate_initial_state": (C.c_int, [C.c_uint32, C.c_uint32, C.c_float, C.c_float, _fp, _fp]),
     "mapn_get_cbuffer": (C.c_int, [_ctx, C.POINTER(C.c_uint32 * 4), C.POINTER(C.c_float * 4)]),
     "mapn_comm_get_unique_id": (C.c_int, [C.c_void_p]),

@@ -153,6 +153,16 @@ class Compute:
         check(self._lib.mapn_download_buffer(self._ctx, index, pos.ctypes.data_as(_lib._fp), vel.ctypes.data_as(_lib._fp)))
         return pos, vel
 
+    def copy_positions_async(self, num_copied: int, dst: int, consumer_stream: int = 0):
+        """Render::CopySimulationResults (Render.cpp:789-831) on the consumer's stream."""
+        check(self._lib.mapn_copy_positions_async(self._ctx, int(num_copied), C.c_void_p(dst), C.c_void_p(consumer_stream)))
+
+    def save_snapshot(self, path: str):
+        check(self._lib.mapn_save_snapshot(self._ctx, str(path).encode()))
+
+    def load_snapshot(self, path: str):
+        check(self._lib.mapn_load_snapshot(self._ctx, str(path).encode()))
+
     def cbuffer(self):
         p, f = (C.c_uint32 * 4)(), (C.c_float * 4)()
         check(self._lib.mapn_get_cbuffer(self._ctx, C.byref(p), C.byref(f)))

@@ -79,6 +79,7 @@ struct mapn_ctx {
     hipEvent_t fence_events[kTimerRing] = {};
     uint64_t fence_event_value[kTimerRing] = {};
     hipEvent_t step_done = nullptr;           // exported: the fence event of the latest step
+    bool fence_every_step = false;            // set once a consumer can observe step_done
 
     // consumer fence (the render adapter's shared fence, Compute.cpp:1012)
     bool consumer_enabled = false;
@@ -340,7 +341,7 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
 void drop_graphs(mapn_ctx *c)
 {
     for (int b = 0; b < 2; b++) {
-        if (c->graph_exec[b]) hipGraphExecDestroy(c->graph_exec[b]);
+        if (c->graph_exec[b]) (void)hipGraphExecDestroy(c->graph_exec[b]);
         c->graph_exec[b] = nullptr;
         c->graph_active[b] = -1;
     }
@@ -353,7 +354,7 @@ int enqueue_step_graph(mapn_ctx *c, uint32_t active)
 {
     const uint32_t w = c->buffer_index;
     if (!c->graph_exec[w] || c->graph_active[w] != (int)active) {
-        if (c->graph_exec[w]) { hipGraphExecDestroy(c->graph_exec[w]); c->graph_exec[w] = nullptr; }
+        if (c->graph_exec[w]) { (void)hipGraphExecDestroy(c->graph_exec[w]); c->graph_exec[w] = nullptr; }
         const uint32_t lo = c->first, hi = std::min(c->first + c->count, active);
         if (hi > lo && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS) {
             mapn::ForcePlan plan = choose_plan(c, hi - lo, c->n, 1, true);
@@ -364,10 +365,10 @@ int enqueue_step_graph(mapn_ctx *c, uint32_t active)
         HIP_TRY(hipStreamBeginCapture(c->compute, hipStreamCaptureModeThreadLocal));
         int rc = enqueue_step(c, active, nullptr);
         hipError_t e = hipStreamEndCapture(c->compute, &graph);
-        if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess) return fail(MAPN_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
         e = hipGraphInstantiate(&c->graph_exec[w], graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
+        (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { c->graph_exec[w] = nullptr; return fail(MAPN_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
         c->graph_active[w] = (int)active;
     }
@@ -388,7 +389,7 @@ int enqueue_gather(mapn_ctx *c)
     // runs beside it.
     hipStream_t st = overlap ? c->comm_stream : c->compute;
     if (overlap) HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->step_done, 0));   // = this step's fence event
-    if (int rc = mapn::comm_all_gather_inplace(c->comm, c->pos[w], (size_t)c->count * 4, st))
+    if (mapn::comm_all_gather_inplace(c->comm, c->pos[w], (size_t)c->count * 4, st))
         return fail(MAPN_ERR_COMM, "all-gather failed: %s", mapn::comm_last_error());
     if (overlap) {
         HIP_TRY(hipEventRecord(c->gather_done[w], c->comm_stream));
@@ -532,7 +533,7 @@ int mapn_create_from(const mapn_config *cfg, mapn_ctx *old, mapn_ctx **out_ctx)
             rc = fail(MAPN_ERR_HIP, "CopyState: device-to-device copy failed: %s", hipGetErrorString(hipGetLastError()));
     }
     c->buffer_index = old->buffer_index;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     if (!rc) rc = mapn_wait_idle(c);           // Compute.cpp:354 / :409
     if (!rc) rc = mapn_wait_idle(c);           // Compute.cpp:97
     if (rc) { std::string keep = g_last_error; mapn_destroy(c); g_last_error = keep; *out_ctx = nullptr; return rc; }
@@ -543,25 +544,25 @@ int mapn_create_from(const mapn_config *cfg, mapn_ctx *old, mapn_ctx **out_ctx)
 int mapn_destroy(mapn_ctx *c)
 {
     if (!c) return MAPN_OK;
-    hipSetDevice(c->device);
-    if (c->compute) hipStreamSynchronize(c->compute);          // Compute.cpp:104 WaitForGpu first
-    if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
+    (void)hipSetDevice(c->device);
+    if (c->compute) (void)hipStreamSynchronize(c->compute);          // Compute.cpp:104 WaitForGpu first
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm) mapn::comm_destroy(c->comm);
     for (int b = 0; b < 2; b++) {
-        if (c->graph_exec[b]) hipGraphExecDestroy(c->graph_exec[b]);
-        if (c->vel[b]) hipFree(c->vel[b]);
-        if (c->gather_done[b]) hipEventDestroy(c->gather_done[b]);
+        if (c->graph_exec[b]) (void)hipGraphExecDestroy(c->graph_exec[b]);
+        if (c->vel[b]) (void)hipFree(c->vel[b]);
+        if (c->gather_done[b]) (void)hipEventDestroy(c->gather_done[b]);
     }
-    if (c->pos_heap) hipFree(c->pos_heap);
-    if (c->partial) hipFree(c->partial);
+    if (c->pos_heap) (void)hipFree(c->pos_heap);
+    if (c->partial) (void)hipFree(c->partial);
     for (int k = 0; k < kTimerRing; k++) {
-        if (c->fence_events[k]) hipEventDestroy(c->fence_events[k]);
-        if (c->timers[k].start) hipEventDestroy(c->timers[k].start);
-        if (c->timers[k].force_done) hipEventDestroy(c->timers[k].force_done);
-        if (c->timers[k].stop) hipEventDestroy(c->timers[k].stop);
+        if (c->fence_events[k]) (void)hipEventDestroy(c->fence_events[k]);
+        if (c->timers[k].start) (void)hipEventDestroy(c->timers[k].start);
+        if (c->timers[k].force_done) (void)hipEventDestroy(c->timers[k].force_done);
+        if (c->timers[k].stop) (void)hipEventDestroy(c->timers[k].stop);
     }
-    if (c->compute) hipStreamDestroy(c->compute);
-    if (c->comm_stream) hipStreamDestroy(c->comm_stream);
+    if (c->compute) (void)hipStreamDestroy(c->compute);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     delete c;
     return MAPN_OK;
 }
@@ -592,11 +593,17 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
     // MoveToNextFrame, Compute.cpp:993-1004: Signal(fence, v); v++; index = 1 - index
     const bool gather_first = c->comm && !(c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP);
     if (gather_first) { if (int rc = enqueue_gather(c)) return rc; }   // same stream: the fence then covers the gather
-    if (int rc = signal_fence(c, c->fence_value)) return rc;
+    // The fence value always advances; the hipEvent behind it (a few us of queue time each) is
+    // recorded on every step only while somebody can observe it -- an attached consumer, exported
+    // handles, the overlap structure -- and otherwise on every 16th step, which only makes
+    // mapn_completed_value() conservative.  mapn_wait_idle() always records.
+    const bool record = c->fence_every_step || c->consumer_enabled || (c->comm && !gather_first) ||
+                        (c->fence_value % 16) == 0;
+    if (record) { if (int rc = signal_fence(c, c->fence_value)) return rc; }
     if (c->comm && !gather_first) { if (int rc = enqueue_gather(c)) return rc; }   // overlap: behind the fence event
     c->fence_value++;
     c->buffer_index = 1 - c->buffer_index;
-    if (timer && (c->timer_head % 16) == 0) resolve_timers(c, false);
+    if (timer && (c->timer_head % 16) == 0) (void)resolve_timers(c, false);
     return MAPN_OK;
 }
 
@@ -605,7 +612,7 @@ uint64_t mapn_fence_value(const mapn_ctx *c) { return c ? c->fence_value : 0; }
 uint64_t mapn_completed_value(mapn_ctx *c)
 {
     if (!c) return 0;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     update_completed(c);
     return c->completed;
 }
@@ -629,6 +636,12 @@ uint32_t mapn_num_particles(const mapn_ctx *c) { return c ? c->n : 0; }
 int mapn_get_shared_handles(mapn_ctx *c, mapn_shared_handles *out)
 {
     if (!c || !out) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
+    if (!c->fence_every_step) {
+        // from now on every step records its completion event; make the exported one current
+        c->fence_every_step = true;
+        HIP_TRY(hipSetDevice(c->device));
+        if (int rc = signal_fence(c, c->fence_value - 1)) return rc;   // covers everything enqueued so far
+    }
     out->positions[0] = c->pos[0];
     out->positions[1] = c->pos[1];
     out->step_done_event = c->step_done;
@@ -692,7 +705,7 @@ int mapn_reset_from_async(mapn_ctx *c)
 float mapn_last_step_seconds(mapn_ctx *c)
 {
     if (!c) return 0.f;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     resolve_timers(c, false);
     return c->ema_seconds;
 }
@@ -732,6 +745,82 @@ int mapn_download_state(mapn_ctx *c, float *pos4, float *vel3)
 {
     if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
     return mapn_download_buffer(c, 1 - c->buffer_index, pos4, vel3);
+}
+
+int mapn_copy_positions_async(mapn_ctx *c, uint32_t num_copied, void *dst, void *consumer_stream)
+{
+    if (!c || !dst) return fail(MAPN_ERR_INVALID_ARGUMENT, "copy_positions_async: null argument");
+    if (num_copied > c->n) num_copied = c->n;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->fence_every_step) {
+        c->fence_every_step = true;
+        if (int rc = signal_fence(c, c->fence_value - 1)) return rc;   // covers everything enqueued so far
+    }
+    hipStream_t st = static_cast<hipStream_t>(consumer_stream);
+    // Render.cpp:796,814: copyQueue.Wait(computeFence, v); CopyBufferRegion(dst, shared[1 - idx], nCopy * 16)
+    if (c->step_done) HIP_TRY(hipStreamWaitEvent(st, c->step_done, 0));
+    if (num_copied)
+        HIP_TRY(hipMemcpyAsync(dst, c->pos[1 - c->buffer_index], (size_t)num_copied * 16, hipMemcpyDefault, st));
+    return MAPN_OK;
+}
+
+namespace {
+struct SnapshotHeader {
+    char magic[8];
+    uint32_t version, n, buffer_index, reserved;
+    uint64_t fence_value;
+};
+static_assert(sizeof(SnapshotHeader) == 32, "snapshot header is 32 bytes");
+}  // namespace
+
+int mapn_save_snapshot(mapn_ctx *c, const char *path)
+{
+    if (!c || !path) return fail(MAPN_ERR_INVALID_ARGUMENT, "save_snapshot: null argument");
+    std::vector<float> pos((size_t)c->n * 4), vel((size_t)c->n * 3);
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(MAPN_ERR_INVALID_ARGUMENT, "save_snapshot: cannot open %s", path);
+    SnapshotHeader h{};
+    memcpy(h.magic, "MAPNSNAP", 8);
+    h.version = 1; h.n = c->n; h.buffer_index = c->buffer_index; h.fence_value = c->fence_value;
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+    for (uint32_t b = 0; b < 2 && ok; b++) {
+        if (int rc = mapn_download_buffer(c, b, pos.data(), vel.data())) { fclose(f); return rc; }
+        ok = fwrite(pos.data(), 16, c->n, f) == c->n && fwrite(vel.data(), 12, c->n, f) == c->n;
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? MAPN_OK : fail(MAPN_ERR_INVALID_ARGUMENT, "save_snapshot: short write to %s", path);
+}
+
+int mapn_load_snapshot(mapn_ctx *c, const char *path)
+{
+    if (!c || !path) return fail(MAPN_ERR_INVALID_ARGUMENT, "load_snapshot: null argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(MAPN_ERR_INVALID_ARGUMENT, "load_snapshot: cannot open %s", path);
+    SnapshotHeader h{};
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "MAPNSNAP", 8) != 0 || h.version != 1) {
+        fclose(f);
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "load_snapshot: %s is not a version-1 mapn snapshot", path);
+    }
+    if (h.n != c->n || h.buffer_index > 1) {
+        fclose(f);
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "load_snapshot: snapshot holds %u bodies, context %u", h.n, c->n);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->compute));
+    HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    std::vector<float> pos((size_t)c->n * 4), vel((size_t)c->n * 3);
+    for (uint32_t b = 0; b < 2; b++) {
+        if (fread(pos.data(), 16, c->n, f) != c->n || fread(vel.data(), 12, c->n, f) != c->n) {
+            fclose(f);
+            return fail(MAPN_ERR_INVALID_ARGUMENT, "load_snapshot: %s is truncated", path);
+        }
+        HIP_TRY(hipMemcpy(c->pos[b], pos.data(), (size_t)c->n * 16, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->vel[b], vel.data(), (size_t)c->n * 12, hipMemcpyHostToDevice));
+    }
+    fclose(f);
+    c->buffer_index = h.buffer_index;
+    c->gather_recorded[0] = c->gather_recorded[1] = false;
+    return MAPN_OK;
 }
 
 int mapn_get_cbuffer(const mapn_ctx *c, uint32_t out_param[4], float out_paramf[4])

@@ -5,19 +5,21 @@
 // integrator (:103-108) fed by the sum of bodyBodyInteraction (:44-57) over all bodies of the
 // old position buffer.
 //
-// Design (see DESIGN.md "Kernels"):
-//   * a lane owns K bodies i (registers), a wave walks a contiguous j-chunk; the j-range of a
-//     launch is split S = gridDim.y * WAVES ways so that N = 65 536 still fills 1024 SIMDs
-//     with several waves each;
-//   * j-bodies reach the lanes either through a wave-private, double-buffered LDS tile
-//     (coalesced global_load_dwordx4 -> ds_write_b128, then broadcast ds_read_b128), or
-//     through the scalar cache (s_load_dwordx8/x16 -> SGPR operands of the VALU ops);
-//   * per pair: 3 sub, 3 fma, v_rsq_f32, 2 mul, 3 fma  (mass hoisted out of the sum);
-//   * the S partial sums of a body are combined in FIXED ascending chunk order (LDS inside a
-//     workgroup, a scratch buffer across workgroups) -- no float atomics, so a run is
+// Design:
+//   * a lane owns 2*K2 bodies i (registers), two per packed-fp32 op; a wave walks a contiguous
+//     j-chunk; the j-range of a launch is split S = gridDim.y * WAVES ways so that N = 65 536
+//     still fills 1024 SIMDs with several rounds of 8 waves each;
+//   * j-bodies reach the lanes either through the scalar cache (s_load_dwordx8 -> SGPR-pair
+//     operands of the packed ops, op_sel picking x/y/z) or through a wave-private,
+//     double-buffered LDS tile (coalesced global_load_dwordx4 -> ds_write_b64 + ds_write_b32
+//     into an (x0,y0,x1,y1)/(z0..z3) split layout, then broadcast ds_read_b128);
+//   * per two pairs: 3 v_pk_add, 3 v_pk_fma, 2 v_rsq_f32, 2 v_pk_mul, 3 v_pk_fma -- 13 VALU
+//     instructions, mass hoisted out of the sum (measured: SQ_INSTS_VALU = 13 per 2 pairs);
+//   * the chunk sums of a body are combined in FIXED ascending order (LDS inside a workgroup,
+//     one scratch row per workgroup row across workgroups) -- no float atomics, so a run is
 //     bit-reproducible;
 //   * the kick-drift integrator is fused into the force kernel when one workgroup sees all of
-//     a body's chunks, else it runs as a small second kernel.
+//     a body's chunks, else it runs as a small second kernel (reduce_integrate_kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

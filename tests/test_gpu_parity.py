@@ -333,6 +333,56 @@ def test_set_async_computes_into_caller_buffers():
         np.testing.assert_array_equal(c.download_state()[0], ref.download_state()[0])
 
 
+def test_snapshot_round_trip_continues_bit_identically(tmp_path):
+    """save -> load into a fresh context -> both continue to the same bits (both ping-pong
+    buffers and the buffer index are restored, including a frozen tail)."""
+    n = 3000
+    path = str(tmp_path / "state.mapn")
+    with mapn.Compute(n, mass=70000.0 / n) as a:
+        draw(a, 3, num_active=2000)
+        a.save_snapshot(path)
+        import os
+        assert os.path.getsize(path) == 32 + 2 * n * 28
+        with mapn.Compute(n, mass=70000.0 / n, seed=99) as b:
+            b.load_snapshot(path)
+            assert b.buffer_index == a.buffer_index
+            draw(a, 4); draw(b, 4)
+            for i in (0, 1):
+                np.testing.assert_array_equal(a.download_buffer(i)[0], b.download_buffer(i)[0])
+                np.testing.assert_array_equal(a.download_buffer(i)[1], b.download_buffer(i)[1])
+        with mapn.Compute(n + 64, mass=1.0) as c:
+            with pytest.raises(mapn.MapnError):
+                c.load_snapshot(path)
+    open(path, "wb").write(b"not a snapshot")
+    with mapn.Compute(n, mass=1.0) as c:
+        with pytest.raises(mapn.MapnError):
+            c.load_snapshot(path)
+
+
+def test_consumer_copy_and_event_signal_protocol():
+    """The render side of Particles::Draw (Particles.cpp:446-448 + Render.cpp:789-831) with HIP
+    events: copy numCopy positions on the consumer's stream, signal by event, simulate waits on
+    the device.  Uses a second context's exported buffer as the consumer's local copy and the
+    library's own compute stream of that context as the consumer stream."""
+    n, ncopy = 4096, 1000
+    with mapn.Compute(n, mass=70000.0 / n) as c, mapn.Compute(n, mass=1.0) as consumer:
+        h = c.GetSharedHandles()                                   # attach consumer fence
+        dst = consumer.GetSharedHandles(consumer_fence=False).positions[0]
+        cstream = consumer.compute_stream
+        ev = consumer.GetSharedHandles(consumer_fence=False).step_done_event   # any recorded hipEvent_t on that stream
+        c.ConsumerSignal(c.GetFenceValue() - 1)                    # nothing to wait for before frame 0
+        for frame in range(4):
+            fence = c.GetFenceValue()
+            c.Simulate(n, fence)                                   # waits for consumer's fence-1
+            c.copy_positions_async(ncopy, dst, cstream)            # copy queue: wait compute fence, copy
+            consumer.WaitForGpu()                                  # records a fresh fence event on cstream
+            ev = consumer.GetSharedHandles(consumer_fence=False).step_done_event
+            c.ConsumerSignal(fence, hip_event=ev)                  # Render.cpp:826 Signal(copyFence)
+        c.WaitForGpu()
+        got = consumer.download_buffer(0)[0]
+        np.testing.assert_array_equal(got[:ncopy], c.download_state()[0][:ncopy])
+
+
 def test_sharded_context_requires_transport_and_single_rank_comm_works():
     """world_size > 1 without a transport is an error; a 1-rank RCCL communicator exercises the
     native all-gather path (own-slice kernel, remote kernel with empty segments, reduce+integrate,

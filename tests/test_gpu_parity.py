@@ -228,6 +228,60 @@ def test_full_size_subset_and_invariants(oracle, n):
         assert np.isfinite(v5).all()
 
 
+def test_maximum_size_4mi_bodies(oracle):
+    """MAX_NUM_PARTICLES = 4 Mi (defines.h:45), the reference's default N: the shipped
+    central-well step on all bodies (full comparison) and one all-pairs step (1.76e13 pairs)
+    checked on a 2048-body subset against the oracle plus the momentum invariant."""
+    n = 4 * 1024 * 1024
+    pos, vel = oracle.initial_state(n, seed=1)
+    sim = OracleSim(oracle, pos, vel, mode=MODE_CENTRAL_WELL); sim.simulate()
+    with mapn.Compute(n, force_mode=mapn.FORCE_CENTRAL_WELL) as c:
+        np.testing.assert_array_equal(c.download_state()[0], pos)
+        draw(c, 1)
+        p, v = c.download_state()
+    assert errs(p[:, :3], sim.latest[0][:, :3], 700.0)[0] < 2e-6
+    assert errs(v, sim.latest[1], SPEED)[0] < 2e-5
+    mass = 70000.0 / n
+    first = 1234 * 64
+    rp, rv = oracle.step_slice(pos, vel, first, 2048, params=Params(mass=mass))
+    with mapn.Compute(n, mass=mass) as c:
+        draw(c, 1)
+        p, v = c.download_state()
+    assert errs(p[first:first + 2048, :3], rp[:, :3], SPREAD)[0] < 1e-6
+    assert errs(v[first:first + 2048], rv, SPEED)[0] < 2e-5
+    drift = np.abs(v.astype(np.float64).sum(0) - vel.astype(np.float64).sum(0)).max() / (n * SPEED)
+    assert drift < 1e-6
+
+
+@pytest.mark.parametrize("na", [-3, 0, 1, 4096 + 500, 2 ** 31 - 1])
+def test_num_active_out_of_range_values(oracle, na):
+    """Negative / zero: nothing moves; larger than N: clipped to N (D3D drops out-of-range
+    threads, Compute.cpp:1041)."""
+    n = 4096
+    pos, vel = oracle.initial_state(n, seed=2)
+    sim = OracleSim(oracle, pos, vel, params=Params(mass=70000.0 / n)); sim.simulate(num_active=na)
+    with mapn.Compute(n, mass=70000.0 / n, flags=mapn.FLAG_NO_INIT) as c:
+        c.upload_state(pos, vel)
+        draw(c, 1, num_active=na)
+        p, v = c.download_state()
+    assert errs(p[:, :3], sim.latest[0][:, :3], SPREAD)[0] < 1e-6
+    assert errs(v, sim.latest[1], SPEED)[0] < 2e-5
+
+
+def test_lds_kernel_selected_by_config_matches_scalar_cache_kernel(oracle):
+    """cfg.kernel = MAPN_KERNEL_LDS (north_star's LDS-tiled path) vs the default scalar-cache
+    path: same decomposition, same bits (both sum each chunk in ascending j)."""
+    n = 16384
+    out = []
+    for kern in (mapn.KERNEL_LDS, mapn.KERNEL_SCALAR, mapn.KERNEL_AUTO):
+        with mapn.Compute(n, mass=70000.0 / n, kernel=kern) as c:
+            draw(c, 2)
+            out.append(c.download_state())
+            assert c.kernel_stats().kernel_name.decode() == ("force_lds_kernel" if kern == mapn.KERNEL_LDS else "force_sgpr_kernel")
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[1][0], out[2][0])
+
+
 # ---------------------------------------------------------------------------------------------
 # Compute's call semantics
 

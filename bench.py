@@ -201,7 +201,7 @@ def main():
             "config": {"workload": f"{n} bodies, all-pairs softened gravity + kick-drift step, fp32 (BASELINE configs[1])"
                        if a.mode == "all_pairs" else f"{n} bodies, central-well step as shipped (nBodyGravityCS.hlsl:86-109)",
                        "bodies": n, "mode": a.mode, "parallelism": f"bodies sharded x{world}" if world > 1 else "1 GPU",
-                       "transport": transport, "seed": a.seed, "mass": "70000/N", "device": info.name.decode(),
+                       "transport": transport, "seed": a.seed, "mass": "70000/N", "device": (info.name.decode() or "MI355X") + " / " + info.arch.decode(),
                        "kernel": st.kernel_name.decode(), "bodies_per_lane": st.bodies_per_lane, "j_splits": st.j_splits,
                        "grid": [st.grid_x, st.grid_y], "block": st.block_x, "fused_integrator": bool(st.fused)},
         }

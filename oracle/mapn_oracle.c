@@ -147,7 +147,11 @@ typedef struct {
     uint32_t tid, nthreads;
 } ap_job;
 
-/* bodies [b0, b0+nb) (nb <= IB) against j = 0..n_total-1 ascending, one accumulator each */
+/* bodies [b0, b0+nb) (nb <= IB) against j = 0..n_total-1 ascending, one accumulator each.
+ * Function multi-versioning: the AVX-512 / AVX2 / baseline clones execute the same separately
+ * rounded IEEE operations per lane, so every clone returns the same bits; the widest one the
+ * host supports is picked at load time (the .so is built in one container and timed in another). */
+__attribute__((target_clones("avx512f", "avx2", "default")))
 static void all_pairs_block(const ap_job *J, uint32_t b0, uint32_t nb)
 {
     float xi[IB], yi[IB], zi[IB], ax[IB], ay[IB], az[IB];

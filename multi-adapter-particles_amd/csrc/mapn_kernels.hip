@@ -60,6 +60,41 @@ __device__ __forceinline__ void pair_term2(Acc2 &a, v2f xi, v2f yi, v2f zi, floa
     a.z = __builtin_elementwise_fma(dz, inv3, a.z);
 }
 
+// r = (x_j, x_j) - x_i with x_j taken from the low (SEL 0) or high (SEL 1) half of an aligned
+// 64-bit register pair: one v_pk_add_f32 whose op_sel broadcasts the half and whose neg bits
+// negate x_i.  Spelled as asm for the LDS path only: left to itself hipcc copies every second
+// broadcast operand into a fresh pair first (v_mov_b32; +10 % VALU instructions measured with
+// SQ_INSTS_VALU, profiles/r01_ab_lds_vs_sgpr_pmc.txt).
+template <int SEL>
+__device__ __forceinline__ v2f bcast_sub(v2f pair, v2f xi)
+{
+    v2f r;
+    if constexpr (SEL == 0)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(pair), "v"(xi));
+    else
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(pair), "v"(xi));
+    return r;
+}
+
+// pair term with the j-body given as register pairs: xy = (x_j, y_j), zp = the pair holding z_j
+template <int ZSEL>
+__device__ __forceinline__ void pair_term2_pairs(Acc2 &a, v2f xi, v2f yi, v2f zi, v2f xy, v2f zp, v2f soft2)
+{
+    const v2f dx = bcast_sub<0>(xy, xi);
+    const v2f dy = bcast_sub<1>(xy, yi);
+    const v2f dz = bcast_sub<ZSEL>(zp, zi);
+    v2f d = __builtin_elementwise_fma(dx, dx, soft2);
+    d = __builtin_elementwise_fma(dy, dy, d);
+    d = __builtin_elementwise_fma(dz, dz, d);
+    v2f inv;
+    inv.x = __builtin_amdgcn_rsqf(d.x);
+    inv.y = __builtin_amdgcn_rsqf(d.y);
+    const v2f inv3 = inv * inv * inv;
+    a.x = __builtin_elementwise_fma(dx, inv3, a.x);
+    a.y = __builtin_elementwise_fma(dy, inv3, a.y);
+    a.z = __builtin_elementwise_fma(dz, inv3, a.z);
+}
+
 // nBodyGravityCS.hlsl:103-108: kick, damp, drift; w = |accel|
 __device__ __forceinline__ void integrate_store(const StepArgs &p, uint32_t i, float4 pos,
                                                 float ax, float ay, float az)
@@ -223,14 +258,16 @@ __global__ __launch_bounds__(64 * WAVES) void force_lds_kernel(const StepArgs p)
                 for (int q = 0; q < 16; q++) {
                     const float4 zz = tzz[q];                  // ds_read_b128, every lane the same address
                     const float4 xa = txy[2 * q], xb = txy[2 * q + 1];
+                    const v2f z01 = v2f{zz.x, zz.y}, z23 = v2f{zz.z, zz.w};
+                    const v2f j0 = v2f{xa.x, xa.y}, j1 = v2f{xa.z, xa.w}, j2 = v2f{xb.x, xb.y}, j3 = v2f{xb.z, xb.w};
 #pragma unroll
-                    for (int k = 0; k < K2; k++) pair_term2(b.acc[k], b.xi[k], b.yi[k], b.zi[k], xa.x, xa.y, zz.x, soft2);
+                    for (int k = 0; k < K2; k++) pair_term2_pairs<0>(b.acc[k], b.xi[k], b.yi[k], b.zi[k], j0, z01, soft2);
 #pragma unroll
-                    for (int k = 0; k < K2; k++) pair_term2(b.acc[k], b.xi[k], b.yi[k], b.zi[k], xa.z, xa.w, zz.y, soft2);
+                    for (int k = 0; k < K2; k++) pair_term2_pairs<1>(b.acc[k], b.xi[k], b.yi[k], b.zi[k], j1, z01, soft2);
 #pragma unroll
-                    for (int k = 0; k < K2; k++) pair_term2(b.acc[k], b.xi[k], b.yi[k], b.zi[k], xb.x, xb.y, zz.z, soft2);
+                    for (int k = 0; k < K2; k++) pair_term2_pairs<0>(b.acc[k], b.xi[k], b.yi[k], b.zi[k], j2, z23, soft2);
 #pragma unroll
-                    for (int k = 0; k < K2; k++) pair_term2(b.acc[k], b.xi[k], b.yi[k], b.zi[k], xb.z, xb.w, zz.w, soft2);
+                    for (int k = 0; k < K2; k++) pair_term2_pairs<1>(b.acc[k], b.xi[k], b.yi[k], b.zi[k], j3, z23, soft2);
                 }
             } else {
                 const float2 *sxy = reinterpret_cast<const float2 *>(txy);

@@ -53,7 +53,8 @@ typedef enum mapn_kernel {
     MAPN_KERNEL_AUTO = 0,
     MAPN_KERNEL_LDS = 1,        /* j-tiles staged through LDS, broadcast ds_read */
     MAPN_KERNEL_SCALAR = 2,     /* j-bodies through the scalar cache into SGPRs */
-    MAPN_KERNEL_MFMA = 3        /* accumulation recast on v_mfma_f32_4x4x1 (A/B experiment) */
+    MAPN_KERNEL_MFMA = 3        /* accumulation recast on v_mfma_f32_4x4x1: A/B experiment only
+                                   (tools/ubench.hip); measured slower, mapn_create rejects it */
 } mapn_kernel;
 
 #define MAPN_FLAG_USE_GRAPH   0x1u  /* replay the step from a captured hipGraph */

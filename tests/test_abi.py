@@ -68,6 +68,8 @@ def test_bad_arguments_return_status_not_crash(lib):
     assert lib.mapn_create(C.byref(cfg), C.byref(ctx)) == -1 and b"struct_size" in lib.mapn_last_error()
     lib.mapn_config_default(C.byref(cfg)); cfg.num_particles = 100; cfg.world_size = 3
     assert lib.mapn_create(C.byref(cfg), C.byref(ctx)) == -1 and b"divide" in lib.mapn_last_error()
+    lib.mapn_config_default(C.byref(cfg)); cfg.num_particles = 64; cfg.kernel = 3
+    assert lib.mapn_create(C.byref(cfg), C.byref(ctx)) == -1 and b"MFMA" in lib.mapn_last_error()
     assert lib.mapn_simulate(None, 1, 0) == -1
     assert lib.mapn_destroy(None) == 0
 

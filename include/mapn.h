@@ -57,6 +57,13 @@ typedef enum mapn_kernel {
                                    (tools/ubench.hip); measured slower, mapn_create rejects it */
 } mapn_kernel;
 
+/* The three #if variants of LoadParticles (Compute.cpp:581-583), all seeded per body. */
+typedef enum mapn_init_variant {
+    MAPN_INIT_LCG = 0,          /* USE_SCALAR_OPTIMIZED: fast_rand LCG, Compute.cpp:711-749 (default) */
+    MAPN_INIT_SSE = 1,          /* USE_SIMD_OPTIMIZED: rand_sse 4-lane LCG, Compute.cpp:751-793 */
+    MAPN_INIT_MT = 2            /* USE_ORIG: mt19937 + uniform_real_distribution, Compute.cpp:686-708 */
+} mapn_init_variant;
+
 #define MAPN_FLAG_USE_GRAPH   0x1u  /* replay the step from a captured hipGraph */
 #define MAPN_FLAG_NO_INIT     0x2u  /* leave state zeroed; caller will mapn_upload_state() */
 #define MAPN_FLAG_SHARD_OVERLAP 0x4u /* sharded mode: own-segment launch overlapped with the all-gather */
@@ -83,7 +90,8 @@ typedef struct mapn_config {
     int32_t  kernel;             /* mapn_kernel */
     int32_t  rank;               /* shard index p in [0, world_size) */
     int32_t  world_size;         /* number of shards P (1 = unsharded); P must divide N */
-    int32_t  reserved[5];
+    int32_t  init_variant;       /* mapn_init_variant: which LoadParticles variant generates the state */
+    int32_t  reserved[4];
 } mapn_config;
 
 int mapn_abi_version(void);
@@ -217,6 +225,8 @@ int mapn_load_snapshot(mapn_ctx *ctx, const char *path);
  */
 int mapn_generate_initial_state(uint32_t seed, uint32_t num_particles, float spread,
                                 float initial_speed, float *pos4, float *vel3);
+int mapn_generate_initial_state_ex(int init_variant, uint32_t seed, uint32_t num_particles, float spread,
+                                   float initial_speed, float *pos4, float *vel3);
 
 /* The 32-byte constant block of Compute.cpp:542-546 as this context would upload it. */
 int mapn_get_cbuffer(const mapn_ctx *ctx, uint32_t out_param[4], float out_paramf[4]);

@@ -14,6 +14,7 @@ FORCE_ALL_PAIRS = 0        # sum of bodyBodyInteraction, nBodyGravityCS.hlsl:44-
 FORCE_CENTRAL_WELL = 1     # CSMain as shipped, nBodyGravityCS.hlsl:92-101
 KERNEL_AUTO, KERNEL_LDS, KERNEL_SCALAR, KERNEL_MFMA = 0, 1, 2, 3
 FLAG_USE_GRAPH = 0x1
+INIT_LCG, INIT_SSE, INIT_MT = 0, 1, 2
 FLAG_NO_INIT = 0x2
 FLAG_SHARD_OVERLAP = 0x4
 UNIQUE_ID_BYTES = 128
@@ -33,7 +34,7 @@ class Config(C.Structure):
         ("force_mode", C.c_int32), ("mass", C.c_float), ("softening_squared", C.c_float),
         ("dt", C.c_float), ("damping", C.c_float), ("seed", C.c_uint32), ("spread", C.c_float),
         ("initial_speed", C.c_float), ("flags", C.c_uint32), ("kernel", C.c_int32),
-        ("rank", C.c_int32), ("world_size", C.c_int32), ("reserved", C.c_int32 * 5),
+        ("rank", C.c_int32), ("world_size", C.c_int32), ("init_variant", C.c_int32), ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -94,6 +95,7 @@ SIGNATURES = {
     "mapn_save_snapshot": (C.c_int, [_ctx, C.c_char_p]),
     "mapn_load_snapshot": (C.c_int, [_ctx, C.c_char_p]),
     "mapn_generate_initial_state": (C.c_int, [C.c_uint32, C.c_uint32, C.c_float, C.c_float, _fp, _fp]),
+    "mapn_generate_initial_state_ex": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_float, C.c_float, _fp, _fp]),
     "mapn_get_cbuffer": (C.c_int, [_ctx, C.POINTER(C.c_uint32 * 4), C.POINTER(C.c_float * 4)]),
     "mapn_comm_get_unique_id": (C.c_int, [C.c_void_p]),
     "mapn_comm_init": (C.c_int, [_ctx, C.c_void_p]),

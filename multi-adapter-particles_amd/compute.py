@@ -18,13 +18,15 @@ from . import _lib
 from ._lib import Config, KernelStats, MapnError, SharedHandles, check, load_library
 
 
-def generate_initial_state(num_particles: int, seed: int = 1, spread: float = 400.0, speed: float = 15.0):
-    """LoadParticles / InitializeParticles made deterministic (csrc/mapn_init.cpp)."""
+def generate_initial_state(num_particles: int, seed: int = 1, spread: float = 400.0, speed: float = 15.0,
+                           variant: int = _lib.INIT_LCG):
+    """LoadParticles / InitializeParticles made deterministic (csrc/mapn_init.cpp); `variant`
+    selects which of the reference's three #if variants supplies the randomness."""
     lib = load_library()
     pos = np.zeros((num_particles, 4), np.float32)
     vel = np.zeros((num_particles, 3), np.float32)
-    check(lib.mapn_generate_initial_state(seed, num_particles, spread, speed,
-                                          pos.ctypes.data_as(_lib._fp), vel.ctypes.data_as(_lib._fp)))
+    check(lib.mapn_generate_initial_state_ex(variant, seed, num_particles, spread, speed,
+                                             pos.ctypes.data_as(_lib._fp), vel.ctypes.data_as(_lib._fp)))
     return pos, vel
 
 
@@ -40,7 +42,8 @@ class Compute:
                  old: "Compute | None" = None, *, force_mode: int = _lib.FORCE_ALL_PAIRS,
                  mass: float = 70000.0, softening_squared: float = 25.0, dt: float = 0.1,
                  damping: float = 1.0, seed: int = 1, spread: float = 400.0, initial_speed: float = 15.0,
-                 flags: int = 0, kernel: int = _lib.KERNEL_AUTO, rank: int = 0, world_size: int = 1):
+                 flags: int = 0, kernel: int = _lib.KERNEL_AUTO, rank: int = 0, world_size: int = 1,
+                 init_variant: int = _lib.INIT_LCG):
         self._lib = load_library()
         self._ctx = C.c_void_p()
         cfg = Config()
@@ -49,6 +52,7 @@ class Compute:
         cfg.mass, cfg.softening_squared, cfg.dt, cfg.damping = mass, softening_squared, dt, damping
         cfg.seed, cfg.spread, cfg.initial_speed = seed, spread, initial_speed
         cfg.flags, cfg.kernel, cfg.rank, cfg.world_size = flags, kernel, rank, world_size
+        cfg.init_variant = init_variant
         self.config = cfg
         self.num_particles = num_particles
         if old is not None:

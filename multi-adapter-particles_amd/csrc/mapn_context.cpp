@@ -509,7 +509,8 @@ int mapn_create(const mapn_config *cfg, mapn_ctx **out_ctx)
     if (!(cfg->flags & MAPN_FLAG_NO_INIT)) {
         // Compute.cpp:820-923 InitializeParticles: generate, upload to both buffers, WaitForGpu
         std::vector<float> pos((size_t)c->n * 4), vel((size_t)c->n * 3);
-        rc = mapn_generate_initial_state(cfg->seed, c->n, cfg->spread, cfg->initial_speed, pos.data(), vel.data());
+        rc = mapn_generate_initial_state_ex(cfg->init_variant, cfg->seed, c->n, cfg->spread, cfg->initial_speed, pos.data(), vel.data());
+        if (rc) fail(rc, "init_variant %d", cfg->init_variant);
         if (!rc) rc = mapn_upload_state(c, pos.data(), vel.data());
     }
     if (!rc) rc = mapn_wait_idle(c);           // Compute.cpp:922

@@ -66,6 +66,10 @@ class Oracle:
         lib.mapn_oracle_rand_sse.restype = None
         lib.mapn_oracle_initial_state.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.c_float, _f32p, _f32p]
         lib.mapn_oracle_initial_state.restype = None
+        lib.mapn_oracle_initial_state_ex.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_float, C.c_float, _f32p, _f32p]
+        lib.mapn_oracle_initial_state_ex.restype = None
+        lib.mapn_oracle_mt_uniform.argtypes = [C.c_uint32, C.c_uint32, _f32p]
+        lib.mapn_oracle_mt_uniform.restype = None
         lib.mapn_oracle_cbuffer.argtypes = [C.c_uint32, C.POINTER(C.c_uint32 * 4), C.POINTER(C.c_float * 4)]
         lib.mapn_oracle_cbuffer.restype = None
         lib.mapn_oracle_hardware_threads.restype = C.c_int
@@ -102,11 +106,16 @@ class Oracle:
         return int(self.lib.mapn_oracle_hardware_threads())
 
     # -- state ---------------------------------------------------------------------------
-    def initial_state(self, n, seed=1, spread=400.0, speed=15.0):
+    def initial_state(self, n, seed=1, spread=400.0, speed=15.0, variant=0):
         pos = np.zeros((n, 4), np.float32)
         vel = np.zeros((n, 3), np.float32)
-        self.lib.mapn_oracle_initial_state(seed, n, spread, speed, pos, vel)
+        self.lib.mapn_oracle_initial_state_ex(variant, seed, n, spread, speed, pos, vel)
         return pos, vel
+
+    def mt_uniform(self, seed, count):
+        out = np.zeros(count, np.float32)
+        self.lib.mapn_oracle_mt_uniform(seed, count, out)
+        return out
 
     def accel_all_pairs(self, pos, first=0, count=None, mass=70000.0, soft2=25.0):
         n = pos.shape[0]

@@ -318,48 +318,120 @@ static uint32_t fmix32(uint32_t h)
     return h;
 }
 
+/* MT19937 (the engine behind std::mt19937, Compute.cpp:680), restated for the USE_ORIG variant */
+typedef struct { uint32_t mt[624]; int idx; } mt19937_t;
+
+static void mt_seed(mt19937_t *g, uint32_t seed)
+{
+    g->mt[0] = seed;
+    for (int i = 1; i < 624; i++)
+        g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->idx = 624;
+}
+
+static uint32_t mt_next(mt19937_t *g)
+{
+    if (g->idx >= 624) {
+        for (int i = 0; i < 624; i++) {
+            uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+            uint32_t v = g->mt[(i + 397) % 624] ^ (y >> 1);
+            if (y & 1u) v ^= 0x9908b0dfu;
+            g->mt[i] = v;
+        }
+        g->idx = 0;
+    }
+    uint32_t y = g->mt[g->idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+/* std::uniform_real_distribution<float>(-1, 1)(gen) as libstdc++ evaluates it:
+ * (b - a) * generate_canonical<float, 24>(gen) + a, one 32-bit draw per value. */
+static float mt_uniform(mt19937_t *g)
+{
+    float c = (float)mt_next(g) / 4294967296.0f;
+    if (c >= 1.0f) c = nextafterf(1.0f, 0.0f);
+    return 2.0f * c + -1.0f;
+}
+
+void mapn_oracle_mt_uniform(uint32_t seed, uint32_t count, float *out)
+{
+    mt19937_t g;
+    mt_seed(&g, seed);
+    for (uint32_t k = 0; k < count; k++) out[k] = mt_uniform(&g);
+}
+
 /*
  * Deterministic replacement for LoadParticles (Compute.cpp:667-812).  The reference seeds
  * mt19937 from random_device and shares it unsynchronised across threads (:678-684), so it is
- * not reproducible; this generator keeps its distribution and replaces the randomness source
- * by the file's own LCG (fast_rand, :599-609, scaled as in :721-725 with MSVC RAND_MAX = 32767)
- * seeded PER BODY, so the state is independent of thread count and generation order:
- *     lcg_state(i) = fmix32(seed * 0x9E3779B9 + i + 1)         (i = global body index)
+ * not reproducible; this generator keeps its distribution and seeds the randomness source PER
+ * BODY, so the state is independent of thread count and generation order:
+ *     body_seed(i) = fmix32(seed * 0x9E3779B9 + i + 1)         (i = global body index)
+ * variant 0: the file's own LCG (fast_rand, :599-609, scaled as in :721-725 with MSVC
+ *            RAND_MAX = 32767), loop of :723-736;
+ * variant 1: rand_sse's four LCG lanes (:619-661), x/y/z from lanes 0/1/2, do-while of :765-777;
+ * variant 2: mt19937 + uniform_real_distribution<float>(-1,1) (:679-681), loop of :690-694.
  * XMVector3NormalizeEst (:703-704, an rsqrtps approximation) is replaced by an exact normalize.
  * Bodies [0, N/2) surround (+0.75*spread, 0, 0), [N/2, 2*(N/2)) surround (-0.75*spread, 0, 0)
  * (:831-844).  pos.w = 0.
  */
-void mapn_oracle_initial_state(uint32_t seed, uint32_t n, float spread, float speed, float *pos4,
-                               float *vel3)
+static void draw_delta(int variant, uint32_t body_seed, float d[3])
 {
     const float k_scale = (1.0f / 32767.0f) * 2.0f;             /* :721 */
+    if (variant == 1) {
+        uint32_t st[4];
+        int r[4];
+        mapn_oracle_srand_sse(st, body_seed);
+        d[0] = d[1] = d[2] = 0.0f;
+        for (;;) {
+            mapn_oracle_rand_sse(st, r);
+            for (int c = 0; c < 3; c++) d[c] = d[c] + ((float)r[c] * k_scale - 1.0f);
+            float l = d[0] * d[0] + d[1] * d[1];
+            l = l + d[2] * d[2];
+            if (!(l < 10.0f)) return;
+        }
+    }
+    if (variant == 2) {
+        mt19937_t g;
+        mt_seed(&g, body_seed);
+        for (int c = 0; c < 3; c++) d[c] = mt_uniform(&g);
+        for (;;) {
+            float l = d[0] * d[0] + d[1] * d[1];
+            l = l + d[2] * d[2];
+            if (!(l < 10.0f)) return;
+            for (int c = 0; c < 3; c++) d[c] = d[c] + mt_uniform(&g);
+        }
+    }
+    uint32_t st = body_seed;
+    for (int c = 0; c < 3; c++) d[c] = (float)mapn_oracle_fast_rand(&st) * k_scale - 1.0f;   /* :723-725 */
+    for (;;) {
+        float l = d[0] * d[0] + d[1] * d[1];
+        l = l + d[2] * d[2];
+        if (!(l < 10.0f)) return;                                                   /* :728 */
+        for (int c = 0; c < 3; c++) d[c] = d[c] + ((float)mapn_oracle_fast_rand(&st) * k_scale - 1.0f);
+    }
+}
+
+void mapn_oracle_initial_state_ex(int variant, uint32_t seed, uint32_t n, float spread, float speed,
+                                  float *pos4, float *vel3)
+{
     const uint32_t half = n / 2;
     const float center_spread = spread * 0.750f;                /* :831 */
     memset(pos4, 0, (size_t)n * 16);
     memset(vel3, 0, (size_t)n * 12);
     for (uint32_t i = 0; i < 2 * half; i++) {
-        uint32_t st = fmix32(seed * 0x9E3779B9u + i + 1u);
+        float d[3];
+        draw_delta(variant, fmix32(seed * 0x9E3779B9u + i + 1u), d);
         const float cx = i < half ? center_spread : -center_spread;
-        float x = (float)mapn_oracle_fast_rand(&st) * k_scale - 1.0f;   /* :723-725 */
-        float y = (float)mapn_oracle_fast_rand(&st) * k_scale - 1.0f;
-        float z = (float)mapn_oracle_fast_rand(&st) * k_scale - 1.0f;
-        float dx = x, dy = y, dz = z;
-        for (;;) {
-            float l = dx * dx + dy * dy;
-            l = l + dz * dz;
-            if (!(l < 10.0f)) break;                                    /* :728 */
-            x = (float)mapn_oracle_fast_rand(&st) * k_scale - 1.0f;
-            y = (float)mapn_oracle_fast_rand(&st) * k_scale - 1.0f;
-            z = (float)mapn_oracle_fast_rand(&st) * k_scale - 1.0f;
-            dx = dx + x; dy = dy + y; dz = dz + z;                      /* :735 */
-        }
-        float l = dx * dx + dy * dy;
-        l = l + dz * dz;
+        float l = d[0] * d[0] + d[1] * d[1];
+        l = l + d[2] * d[2];
         float len = sqrtf(l);
-        dx = dx / len * spread;                                         /* :738-739 */
-        dy = dy / len * spread;
-        dz = dz / len * spread;
-        float px = cx + dx, py = 0.0f + dy, pz = 0.0f + dz;             /* :742 */
+        float px = cx + d[0] / len * spread;                    /* :738-742 */
+        float py = 0.0f + d[1] / len * spread;
+        float pz = 0.0f + d[2] / len * spread;
         pos4[4 * (size_t)i + 0] = px;
         pos4[4 * (size_t)i + 1] = py;
         pos4[4 * (size_t)i + 2] = pz;
@@ -373,11 +445,14 @@ void mapn_oracle_initial_state(uint32_t seed, uint32_t n, float spread, float sp
         l = l + qz * qz;
         len = sqrtf(l);
         qx = qx / len; qy = qy / len; qz = qz / len;                    /* perp */
-        float c0 = uy * qz - uz * qy;                                   /* :748 cross(dir, perp) */
-        float c1 = uz * qx - ux * qz;
-        float c2 = ux * qy - uy * qx;
-        vel3[3 * (size_t)i + 0] = c0 * speed;
-        vel3[3 * (size_t)i + 1] = c1 * speed;
-        vel3[3 * (size_t)i + 2] = c2 * speed;
+        vel3[3 * (size_t)i + 0] = (uy * qz - uz * qy) * speed;          /* :748 cross(dir, perp) */
+        vel3[3 * (size_t)i + 1] = (uz * qx - ux * qz) * speed;
+        vel3[3 * (size_t)i + 2] = (ux * qy - uy * qx) * speed;
     }
+}
+
+void mapn_oracle_initial_state(uint32_t seed, uint32_t n, float spread, float speed, float *pos4,
+                               float *vel3)
+{
+    mapn_oracle_initial_state_ex(0, seed, n, spread, speed, pos4, vel3);
 }

@@ -52,6 +52,37 @@ def test_product_generator_matches_oracle_bit_exact(oracle, n, seed):
     np.testing.assert_array_equal(vel, ov)
 
 
+@pytest.mark.parametrize("variant", [mapn.INIT_LCG, mapn.INIT_SSE, mapn.INIT_MT])
+def test_all_three_generator_variants_match_oracle_bit_exact(oracle, variant):
+    """The three LoadParticles #if variants (Compute.cpp:581-583) as selectable generators."""
+    for n, seed in [(512, 1), (3001, 9)]:
+        pos, vel = mapn.generate_initial_state(n, seed=seed, variant=variant)
+        op, ov = oracle.initial_state(n, seed=seed, variant=variant)
+        np.testing.assert_array_equal(pos, op)
+        np.testing.assert_array_equal(vel, ov)
+        half = n // 2
+        cx = np.where(np.arange(n) < half, 300.0, -300.0)[: 2 * half]
+        rel = pos[: 2 * half, :3].astype(np.float64) - np.stack([cx, 0 * cx, 0 * cx], 1)
+        np.testing.assert_allclose(np.linalg.norm(rel, axis=1), 400.0, atol=2e-4)
+    a, _ = mapn.generate_initial_state(512, seed=1, variant=variant)
+    b, _ = mapn.generate_initial_state(512, seed=1, variant=(variant + 1) % 3)
+    assert not np.array_equal(a, b)
+    with pytest.raises(mapn.MapnError):
+        mapn.generate_initial_state(64, variant=7)
+
+
+def test_mt19937_restatement_matches_libstdcxx(oracle, tmp_path):
+    """USE_ORIG's random source: the oracle's MT19937 + uniform mapping against the real
+    std::mt19937 / std::uniform_real_distribution<float>(-1,1) of this toolchain."""
+    import subprocess
+    exe = str(tmp_path / "mt_check")
+    subprocess.run(["g++", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "mt_check.cpp")], check=True)
+    for seed in (1, 5489, 0xDEADBEEF):
+        out = subprocess.run([exe, str(seed), "2000"], capture_output=True, text=True, check=True).stdout.split()
+        ref = np.array([int(x, 16) for x in out], np.uint32).view(np.float32)
+        np.testing.assert_array_equal(oracle.mt_uniform(seed, 2000), ref)
+
+
 def test_generator_checksums(golden_dir):
     g = np.load(os.path.join(golden_dir, "init_checksums.npz"))
     for n in (1000, 65536):

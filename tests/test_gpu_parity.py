@@ -387,6 +387,19 @@ def test_set_async_computes_into_caller_buffers():
         np.testing.assert_array_equal(c.download_state()[0], ref.download_state()[0])
 
 
+@pytest.mark.parametrize("variant", [mapn.INIT_LCG, mapn.INIT_SSE, mapn.INIT_MT])
+def test_context_initial_state_variants(oracle, variant):
+    """mapn_config.init_variant: the context's initial state (both ping-pong buffers) equals the
+    oracle's for each of the three LoadParticles variants, and a step from it stays in parity."""
+    n = 2048
+    pos, vel = oracle.initial_state(n, seed=5, variant=variant)
+    with mapn.Compute(n, mass=70000.0 / n, seed=5, init_variant=variant) as c:
+        for b in (0, 1):
+            p, v = c.download_buffer(b)
+            np.testing.assert_array_equal(p, pos); np.testing.assert_array_equal(v, vel)
+        one_step_check(oracle, c, n, 70000.0 / n, pos, vel)
+
+
 def test_snapshot_round_trip_continues_bit_identically(tmp_path):
     """save -> load into a fresh context -> both continue to the same bits (both ping-pong
     buffers and the buffer index are restored, including a frozen tail)."""

@@ -1,0 +1,46 @@
+"""bench.py's output contract (one JSON line with the agreed keys) and its refusal to run
+without a GPU (no CPU fallback for the measured path)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import mapn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_fails_loudly_without_a_gpu():
+    if mapn.compute.device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--bodies", "1024"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "no CPU fallback" in (r.stderr + r.stdout)
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())
+
+
+@pytest.mark.gpu
+def test_bench_json_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "body-pair interactions/s" and d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 5
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert "65536 bodies" in d["config"]["workload"] and "model" not in d["config"]
+    assert abs(d["value"] - 65536.0 ** 2 * 40 / (d["ms_per_step"] * 40e-3)) / d["value"] < 1e-6
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "TFLOP/s" and 0.3 < rf["frac"] < 0.8
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and abs(rf["peak"] - 157.2864) < 0.5
+    assert rf["launches_timed"] >= 4 and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e8 and "sample" in cb
+    assert d["value"] > 3.0e12            # the 40 %-of-peak target is 3.15e12 at kernel level

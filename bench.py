@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--plan", default="", help="kernel,bodies_per_lane,waves,sb,fused e.g. lds,4,8,1,1")
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl")
+    ap.add_argument("--gather", choices=["auto", "allgather", "sendrecv"], default="auto",
+                    help="how the in-library RCCL exchange is issued; auto times both during warm-up and keeps the faster")
     ap.add_argument("--timer-interval", type=int, default=-1, help="time every T-th force launch of the timed region with HIP events (0 = off; default 8: each hipEventRecord costs ~4 us of queue time, 1.6 %% of a 0.9 ms step when every step carries three)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
@@ -168,6 +170,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    gather_algo = "n/a"
+    if dist is not None and transport == "rccl":
+        gather_algo = a.gather
+        if a.gather == "auto" and world > 1:
+            # time both ways of issuing the exchange (same bytes, same RCCL communicator) on a few
+            # untimed steps; every rank must take the same decision -> MAX over ranks, rank-0 rule
+            trial = {}
+            for name, algo in (("allgather", 0), ("sendrecv", 1)):
+                c.set_gather_algorithm(algo)
+                for _ in range(5):
+                    step()
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(30):
+                    step()
+                sync()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                trial[name] = float(t.item()) / 30
+            gather_algo = min(trial, key=trial.get)
+            if rank == 0:
+                print(f"[bench] exchange trial: " + ", ".join(f"{k} {v*1e6:.1f} us/step" for k, v in trial.items()) + f" -> {gather_algo}",
+                      file=sys.stderr, flush=True)
+        elif a.gather == "auto":
+            gather_algo = "allgather"
+        c.set_gather_algorithm(1 if gather_algo == "sendrecv" else 0)
     for _ in range(a.warmup):
         step()
     sync()
@@ -201,7 +229,7 @@ def main():
             "config": {"workload": f"{n} bodies, all-pairs softened gravity + kick-drift step, fp32 (BASELINE configs[1])"
                        if a.mode == "all_pairs" else f"{n} bodies, central-well step as shipped (nBodyGravityCS.hlsl:86-109)",
                        "bodies": n, "mode": a.mode, "parallelism": f"bodies sharded x{world}" if world > 1 else "1 GPU",
-                       "transport": transport, "seed": a.seed, "mass": "70000/N", "device": (info.name.decode() or "MI355X") + " / " + info.arch.decode(),
+                       "transport": transport, "exchange": gather_algo, "seed": a.seed, "mass": "70000/N", "device": (info.name.decode() or "MI355X") + " / " + info.arch.decode(),
                        "kernel": st.kernel_name.decode(), "bodies_per_lane": st.bodies_per_lane, "j_splits": st.j_splits,
                        "grid": [st.grid_x, st.grid_y], "block": st.block_x, "fused_integrator": bool(st.fused)},
         }

@@ -239,6 +239,9 @@ int mapn_comm_get_unique_id(void *out_id128);
 /* collective over all ranks of the job; afterwards every mapn_simulate ends with an
  * all-gather of the new position slices over RCCL/xGMI on the context's comm stream */
 int mapn_comm_init(mapn_ctx *ctx, const void *id128);
+/* how the native exchange is issued: 0 = ncclAllGather (default), 1 = one group of ncclSend /
+ * ncclRecv pairs (a single direct xGMI hop per peer instead of a ring); all ranks must agree */
+int mapn_set_gather_algorithm(mapn_ctx *ctx, int algorithm);
 /* alternative transport: the caller all-gathers the written position buffer itself after every
  * step (e.g. torch.distributed.all_gather_into_tensor on the exported buffers) */
 int mapn_set_external_gather(mapn_ctx *ctx, int enabled);

@@ -99,6 +99,7 @@ SIGNATURES = {
     "mapn_get_cbuffer": (C.c_int, [_ctx, C.POINTER(C.c_uint32 * 4), C.POINTER(C.c_float * 4)]),
     "mapn_comm_get_unique_id": (C.c_int, [C.c_void_p]),
     "mapn_comm_init": (C.c_int, [_ctx, C.c_void_p]),
+    "mapn_set_gather_algorithm": (C.c_int, [_ctx, C.c_int]),
     "mapn_set_external_gather": (C.c_int, [_ctx, C.c_int]),
     "mapn_shard_range": (C.c_int, [_ctx, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mapn_get_device_info": (C.c_int, [C.c_int, C.POINTER(DeviceInfo)]),

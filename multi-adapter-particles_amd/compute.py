@@ -198,6 +198,10 @@ class Compute:
         dist.broadcast_object_list(ids, src=0)
         self.comm_init(ids[0])
 
+    def set_gather_algorithm(self, algorithm: int):
+        """0 = ncclAllGather, 1 = grouped ncclSend/ncclRecv (collective choice: all ranks alike)."""
+        check(self._lib.mapn_set_gather_algorithm(self._ctx, int(algorithm)))
+
     def set_external_gather(self, enabled: bool = True):
         check(self._lib.mapn_set_external_gather(self._ctx, int(bool(enabled))))
 

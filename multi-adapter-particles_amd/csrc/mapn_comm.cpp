@@ -24,6 +24,10 @@ struct Api {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -44,7 +48,12 @@ void load_api()
     g_api.CommDestroy = reinterpret_cast<decltype(g_api.CommDestroy)>(dlsym(g_api.handle, "ncclCommDestroy"));
     g_api.AllGather = reinterpret_cast<decltype(g_api.AllGather)>(dlsym(g_api.handle, "ncclAllGather"));
     g_api.GetErrorString = reinterpret_cast<decltype(g_api.GetErrorString)>(dlsym(g_api.handle, "ncclGetErrorString"));
-    g_api.ok = g_api.GetUniqueId && g_api.CommInitRank && g_api.CommDestroy && g_api.AllGather && g_api.GetErrorString;
+    g_api.Send = reinterpret_cast<decltype(g_api.Send)>(dlsym(g_api.handle, "ncclSend"));
+    g_api.Recv = reinterpret_cast<decltype(g_api.Recv)>(dlsym(g_api.handle, "ncclRecv"));
+    g_api.GroupStart = reinterpret_cast<decltype(g_api.GroupStart)>(dlsym(g_api.handle, "ncclGroupStart"));
+    g_api.GroupEnd = reinterpret_cast<decltype(g_api.GroupEnd)>(dlsym(g_api.handle, "ncclGroupEnd"));
+    g_api.ok = g_api.GetUniqueId && g_api.CommInitRank && g_api.CommDestroy && g_api.AllGather && g_api.GetErrorString &&
+               g_api.Send && g_api.Recv && g_api.GroupStart && g_api.GroupEnd;
 }
 
 bool api()
@@ -108,6 +117,24 @@ int comm_all_gather_inplace(Comm *c, void *buf, size_t floats_per_rank, hipStrea
     if (!c || !g_api.ok) { g_err = "communicator not initialised"; return -1; }
     const float *send = static_cast<const float *>(buf) + (size_t)c->rank * floats_per_rank;
     return check(g_api.AllGather(send, buf, floats_per_rank, ncclFloat, c->comm, stream), "ncclAllGather");
+}
+
+// The same exchange as one group of point-to-point transfers: every rank sends its slice to
+// each peer and receives each peer's slice in place -- one direct xGMI hop per pair (the 8 GPUs
+// of a node are fully connected, 7 links each) instead of the P-1 sequential steps of a ring
+// all-gather.  Which of the two is faster for 128 KiB slices is measured at run time (bench.py).
+int comm_gather_sendrecv_inplace(Comm *c, void *buf, size_t floats_per_rank, hipStream_t stream)
+{
+    if (!c || !g_api.ok) { g_err = "communicator not initialised"; return -1; }
+    float *base = static_cast<float *>(buf);
+    const float *send = base + (size_t)c->rank * floats_per_rank;
+    if (check(g_api.GroupStart(), "ncclGroupStart")) return -1;
+    for (int d = 1; d < c->nranks; d++) {
+        const int to = (c->rank + d) % c->nranks, from = (c->rank - d + c->nranks) % c->nranks;
+        if (check(g_api.Send(send, floats_per_rank, ncclFloat, to, c->comm, stream), "ncclSend")) { g_api.GroupEnd(); return -1; }
+        if (check(g_api.Recv(base + (size_t)from * floats_per_rank, floats_per_rank, ncclFloat, from, c->comm, stream), "ncclRecv")) { g_api.GroupEnd(); return -1; }
+    }
+    return check(g_api.GroupEnd(), "ncclGroupEnd");
 }
 
 const char *comm_last_error() { return g_err.c_str(); }

@@ -17,6 +17,7 @@ void comm_destroy(Comm *c);
 // all-gather of `floats_per_rank` floats per rank, in place: rank r's contribution already sits
 // at buf + r * floats_per_rank (ncclAllGather with sendbuff == recvbuff + rank * count)
 int comm_all_gather_inplace(Comm *c, void *buf, size_t floats_per_rank, hipStream_t stream);
+int comm_gather_sendrecv_inplace(Comm *c, void *buf, size_t floats_per_rank, hipStream_t stream);
 const char *comm_last_error();
 
 }  // namespace mapn

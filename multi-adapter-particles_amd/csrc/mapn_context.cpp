@@ -105,6 +105,7 @@ struct mapn_ctx {
     hipEvent_t gather_done[2] = {nullptr, nullptr};
     bool gather_recorded[2] = {false, false};
     bool external_gather = false;
+    int gather_algo = 0;                      // 0 ncclAllGather, 1 grouped ncclSend/ncclRecv
 
     // graph replay
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
@@ -389,8 +390,10 @@ int enqueue_gather(mapn_ctx *c)
     // runs beside it.
     hipStream_t st = overlap ? c->comm_stream : c->compute;
     if (overlap) HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->step_done, 0));   // = this step's fence event
-    if (mapn::comm_all_gather_inplace(c->comm, c->pos[w], (size_t)c->count * 4, st))
-        return fail(MAPN_ERR_COMM, "all-gather failed: %s", mapn::comm_last_error());
+    const int rc_gather = c->gather_algo == 1
+        ? mapn::comm_gather_sendrecv_inplace(c->comm, c->pos[w], (size_t)c->count * 4, st)
+        : mapn::comm_all_gather_inplace(c->comm, c->pos[w], (size_t)c->count * 4, st);
+    if (rc_gather) return fail(MAPN_ERR_COMM, "all-gather failed: %s", mapn::comm_last_error());
     if (overlap) {
         HIP_TRY(hipEventRecord(c->gather_done[w], c->comm_stream));
         c->gather_recorded[w] = true;
@@ -866,6 +869,14 @@ int mapn_comm_init(mapn_ctx *c, const void *id128)
     else
         c->comm = mapn::comm_create(id128, c->cfg.rank, c->cfg.world_size);
     if (!c->comm) return fail(MAPN_ERR_COMM, "%s", mapn::comm_last_error());
+    return MAPN_OK;
+}
+
+int mapn_set_gather_algorithm(mapn_ctx *c, int algorithm)
+{
+    if (!c || algorithm < 0 || algorithm > 1) return fail(MAPN_ERR_INVALID_ARGUMENT, "set_gather_algorithm: bad argument");
+    if (int rc = mapn_wait_idle(c)) return rc;
+    c->gather_algo = algorithm;
     return MAPN_OK;
 }
 

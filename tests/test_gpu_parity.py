@@ -459,9 +459,10 @@ def test_sharded_context_requires_transport_and_single_rank_comm_works():
         assert c.shard_range() == (1024, 1024)
         with pytest.raises(mapn.MapnError):
             c.Simulate(n, 0)
-    for flags in (0, mapn.FLAG_SHARD_OVERLAP):
+    for flags, algo in ((0, 0), (mapn.FLAG_SHARD_OVERLAP, 0), (0, 1)):
         with mapn.Compute(n, mass=70000.0 / n) as ref, mapn.Compute(n, mass=70000.0 / n, flags=flags) as c:
             c.comm_init(mapn.Compute.comm_unique_id())
+            c.set_gather_algorithm(algo)
             draw(ref, 3); draw(c, 3)
             a, b = ref.download_state(), c.download_state()
             assert errs(a[0][:, :3], b[0][:, :3], SPREAD)[0] < 1e-6

@@ -335,12 +335,21 @@ __global__ __launch_bounds__(64 * WAVES) void force_sgpr_kernel(const StepArgs p
 // the non-fused path).  HBM-bound: (16*slots + 28) B read + 28 B written per body.
 __global__ __launch_bounds__(256) void reduce_integrate_kernel(const StepArgs p, uint32_t slots)
 {
-    const uint32_t li = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= p.i_count) return;
     float ax = 0.f, ay = 0.f, az = 0.f;
     const float4 *in = p.partial + li;
-    for (uint32_t s = 0; s < slots; s++) {
-        const float4 a = in[(size_t)s * p.partial_stride];
+    const size_t stride = p.partial_stride;
+    uint32_t s = 0;
+    for (; s + 8u <= slots; s += 8u) {                     // 8 independent loads in flight, summed in order
+        float4 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = in[(size_t)(s + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { ax += a[u].x; ay += a[u].y; az += a[u].z; }
+    }
+    for (; s < slots; s++) {
+        const float4 a = in[(size_t)s * stride];
         ax += a.x; ay += a.y; az += a.z;
     }
     const uint32_t i = p.i_first + li;
@@ -408,7 +417,10 @@ hipError_t launch_force(const ForcePlan &plan, const StepArgs &a, hipStream_t st
 
 hipError_t launch_reduce_integrate(const StepArgs &a, uint32_t slots, hipStream_t st)
 {
-    hipLaunchKernelGGL(reduce_integrate_kernel, dim3((a.i_count + 255u) / 256u), dim3(256), 0, st, a, slots);
+    // a latency-bound pass: small slices (a shard of a multi-GPU job) use 64-thread workgroups so
+    // that 8192 bodies still spread over 128 CUs instead of 32
+    const uint32_t block = a.i_count <= 32768u ? 64u : 256u;
+    hipLaunchKernelGGL(reduce_integrate_kernel, dim3((a.i_count + block - 1u) / block), dim3(block), 0, st, a, slots);
     return hipGetLastError();
 }
 

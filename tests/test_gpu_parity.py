@@ -486,15 +486,9 @@ def test_external_gather_slices_compose_to_the_full_step(oracle):
             parts = [s.download_state() for s in shards]
             gp = np.concatenate([parts[0][0][:1024], parts[1][0][1024:]])
             gv = np.concatenate([parts[0][1][:1024], parts[1][1][1024:]])
-            # all-gather: every replica's freshly written buffer receives the other slice
+            # the caller's all-gather: every replica receives the composed state (upload writes both
+            # ping-pong buffers, which is fine for a continuation with num_active = N)
             for s in shards:
-                w = 1 - s.buffer_index
-                other = s.download_buffer(1 - w)
-                s_pos = [None, None]; s_vel = [None, None]
-                s_pos[w], s_vel[w] = gp, gv
-                s_pos[1 - w], s_vel[1 - w] = other
-                # upload writes both buffers: emulate by uploading the gathered state (both
-                # buffers equal is fine for a teacher-forced continuation with num_active = N)
                 s.upload_state(gp, gv)
         assert errs(gp[:, :3], sim.latest[0][:, :3], SPREAD)[0] < 2e-6
         assert errs(gv, sim.latest[1], SPEED)[0] < 4e-5

@@ -13,10 +13,10 @@
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-enum Mix { FMA = 0, PKFMA, RSQ, PAIR_SCALAR, PAIR_PK, FMA_SGPR, PKFMA_BCAST, PAIR_MFMA, MFMA4, PAIR_PK8, MIXES };
-static const char *mix_name[MIXES] = {"v_fma_f32 x16", "v_pk_fma_f32 x16", "v_rsq_f32 x16", "pair scalar (12 ops)", "pair packed (2 bodies)", "v_fma_f32 sgpr-src x16", "v_pk_fma_f32 op_sel bcast x16", "pair packed, accumulate on mfma 4x4x1", "v_mfma_f32_4x4x1_16b x8", "8 pk + 2 rsq (no accumulate)"};
-static const int mix_insts[MIXES] = {16, 16, 16, 12 * 4, 13 * 2, 16, 16, 12 * 2, 8, 10 * 2};      // wave-instructions per loop body
-static const double mix_pairs[MIXES] = {0, 0, 0, 4, 4, 0, 0, 4, 0, 4};                  // pairs per lane per loop body
+enum Mix { FMA = 0, PKFMA, RSQ, PAIR_SCALAR, PAIR_PK, FMA_SGPR, PKFMA_BCAST, PAIR_MFMA, MFMA4, PAIR_PK8, RSQ_PK_ALT, RSQ_PK_SEQ, MIXES };
+static const char *mix_name[MIXES] = {"v_fma_f32 x16", "v_pk_fma_f32 x16", "v_rsq_f32 x16", "pair scalar (12 ops)", "pair packed (2 bodies)", "v_fma_f32 sgpr-src x16", "v_pk_fma_f32 op_sel bcast x16", "pair packed, accumulate on mfma 4x4x1", "v_mfma_f32_4x4x1_16b x8", "8 pk + 2 rsq (no accumulate)", "8 x (v_rsq, v_pk_fma) alternating", "8 v_rsq then 8 v_pk_fma"};
+static const int mix_insts[MIXES] = {16, 16, 16, 12 * 4, 13 * 2, 16, 16, 12 * 2, 8, 10 * 2, 16, 16};      // wave-instructions per loop body
+static const double mix_pairs[MIXES] = {0, 0, 0, 4, 4, 0, 0, 4, 0, 4, 0, 0};                  // pairs per lane per loop body
 
 template <int MIX>
 __global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, unsigned long long *rt, int iters, float seed)
@@ -100,6 +100,17 @@ __global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, u
                     asm volatile("" :: "v"(i3));
                 }
             }
+        } else if (MIX == RSQ_PK_ALT) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i]));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(p[8 + (i & 3)]), "v"(p[12 + (i & 3)]));
+            }
+        } else if (MIX == RSQ_PK_SEQ) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i]));
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(p[8 + (i & 3)]), "v"(p[12 + (i & 3)]));
         } else if (MIX == MFMA4) {
 #pragma unroll
             for (int i = 0; i < 8; i++) macc[i & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[i], a[15], macc[i & 3], 0, 0, 0);
@@ -167,6 +178,6 @@ int main(int argc, char **argv)
     hipDeviceProp_t pr; CHECK(hipGetDeviceProperties(&pr, 0));
     printf("device: %s  arch=%s  CUs=%d  clock=%d kHz  wave=%d\n", pr.name, pr.gcnArchName, pr.multiProcessorCount, pr.clockRate, pr.warpSize);
     sweep<FMA>(iters); sweep<FMA_SGPR>(iters); sweep<PKFMA>(iters); sweep<PKFMA_BCAST>(iters); sweep<RSQ>(iters);
-    sweep<PAIR_SCALAR>(iters); sweep<PAIR_PK>(iters); sweep<PAIR_PK8>(iters); sweep<PAIR_MFMA>(iters); sweep<MFMA4>(iters);
+    sweep<PAIR_SCALAR>(iters); sweep<PAIR_PK>(iters); sweep<PAIR_PK8>(iters); sweep<PAIR_MFMA>(iters); sweep<MFMA4>(iters); sweep<RSQ_PK_ALT>(iters); sweep<RSQ_PK_SEQ>(iters);
     return 0;
 }

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64 * WAVES) void force_lds_kernel(const StepArgs p)
             const float4 *txy = tile_xy[w][buf];
             const float4 *tzz = tile_zz[w][buf];
             if (nj == 64u) {
-#pragma unroll 2
+#pragma unroll 4
                 for (int q = 0; q < 16; q++) {
                     const float4 zz = tzz[q];                  // ds_read_b128, every lane the same address
                     const float4 xa = txy[2 * q], xb = txy[2 * q + 1];

@@ -117,9 +117,16 @@ def test_product_does_not_link_or_reference_the_oracle():
     """The shipped library and package must not route through oracle/ (or any CPU step)."""
     so = open(mapn.library_path(), "rb").read()
     assert b"mapn_oracle" not in so
-    pkg = os.path.join(ROOT, "multi-adapter-particles_amd")
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
-                text = open(os.path.join(dirpath, f)).read()
-                assert "import oracle" not in text and "from oracle" not in text and "mapn_oracle" not in text, f
+    for sub in ("multi-adapter-particles_amd", "tools", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", ".sh")):
+                    text = open(os.path.join(dirpath, f)).read()
+                    assert "import oracle" not in text and "from oracle" not in text and "mapn_oracle" not in text, f
+    assert "oracle" not in open(os.path.join(ROOT, "mapn.py")).read()
+    # bench.py may touch the oracle only inside cpu_baseline()
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    head, rest = bench.split("def cpu_baseline", 1)
+    body, tail = rest.split("\ndef ", 1)
+    assert "from oracle" not in head and "import oracle" not in head
+    assert "from oracle" not in tail and "import oracle" not in tail

@@ -1,0 +1,46 @@
+"""One rank of tests/test_shard_gpu_multiproc.py (run as a script, one process per rank).
+torch is imported BEFORE the library so that the process holds a single HIP runtime (torch's),
+exactly like bench.py under torch.distributed.run."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port, n, steps = (int(x) for x in sys.argv[1:6])
+    out_dir = sys.argv[6]
+    import torch
+    import torch.distributed as dist
+    import mapn
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = mapn.Compute(n, device=0, mass=70000.0 / n, rank=rank, world_size=world)
+    c.set_external_gather(True)
+    first, count = c.shard_range()
+    for _ in range(steps):
+        c.Simulate(n, c.GetFenceValue())
+        pos, vel = c.download_state()                       # latest buffer: own slice is fresh
+        mine = torch.from_numpy(pos[first:first + count].copy())
+        full = torch.empty((n, 4), dtype=torch.float32)
+        dist.all_gather_into_tensor(full, mine)
+        # the caller's all-gather: upload_state writes both ping-pong buffers, which is exact for a
+        # continuation with num_active == n (every body is rewritten by the next step anyway)
+        c.upload_state(full.numpy(), vel)
+    pos, vel = c.download_state()
+    mine_v = torch.from_numpy(vel[first:first + count].copy())
+    fullv = torch.empty((n, 3), dtype=torch.float32)
+    dist.all_gather_into_tensor(fullv, mine_v)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "gpu_sharded.npz"), pos=pos, vel=fullv.numpy())
+    c.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -97,6 +97,25 @@ def test_all_pairs_one_step_auto_plan(oracle, n):
         one_step_check(oracle, c, n, mass, pos, vel)
 
 
+@pytest.mark.parametrize("mass,soft2,dt,damping", [(70000.0 / 2048, 25.0, 0.1, 1.0), (1.0, 1.0, 0.05, 0.99),
+                                                   (500.0, 0.25, 0.01, 0.5), (70000.0, 25.0, 0.1, 1.0), (3.0, 400.0, 1.0, 1.0)])
+def test_runtime_parameters_one_step(oracle, mass, soft2, dt, damping):
+    """mass, softening^2, dt and damping are runtime parameters of the ABI (the reference
+    hard-codes them, nBodyGravityCS.hlsl:37-38 / Compute.cpp:545-546); one teacher-forced step per
+    setting, including the literal constants, a tight softening and a strongly damped step."""
+    n = 2048
+    pos, vel = oracle.initial_state(n, seed=6)
+    sim = OracleSim(oracle, pos, vel, params=Params(mass=mass, soft2=soft2, dt=dt, damping=damping)); sim.simulate()
+    with mapn.Compute(n, mass=mass, softening_squared=soft2, dt=dt, damping=damping, seed=6) as c:
+        draw(c, 1)
+        p, v = c.download_state()
+    rp, rv = sim.latest
+    vscale = max(SPEED, float(np.linalg.norm(rv, axis=1).max()))
+    assert errs(p[:, :3], rp[:, :3], SPREAD)[0] < 2e-6 * max(1.0, vscale * dt / 1.5)
+    assert errs(v, rv, vscale)[0] < 2e-5
+    assert np.abs(p[:, 3] - rp[:, 3]).max() <= 2e-4 * rp[:, 3].max()
+
+
 def test_k4_two_body_on_device():
     """SURVEY K4 through the ABI: equal and opposite kicks."""
     pos = np.zeros((2, 4), np.float32); pos[1, :3] = [3, 4, 0]

@@ -290,7 +290,9 @@ __global__ __launch_bounds__(64 * WAVES) void force_lds_kernel(const StepArgs p)
 //
 // Same decomposition as force_lds_kernel.  pos[j] with a wave-uniform j compiles to
 // s_load_dwordx8/x16 and the packed VALU ops take (x_j,y_j) / (z_j,w_j) as their one SGPR-pair
-// source, op_sel picking the half.  A/B alternative to the LDS path.
+// source, op_sel picking the half.  The default path: measured 62 % of the fp32 peak at 65 536
+// bodies against 60 % for the LDS-tiled kernel, with SQ_INSTS_VALU exactly 13 per
+// two pairs.
 template <int K2, int WAVES, bool FUSED>
 __global__ __launch_bounds__(64 * WAVES) void force_sgpr_kernel(const StepArgs p)
 {

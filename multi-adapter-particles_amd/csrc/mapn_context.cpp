@@ -251,6 +251,8 @@ mapn::StepArgs base_args(const mapn_ctx *c, uint32_t w, uint32_t r)
     a.soft2 = c->cfg.softening_squared;
     a.dt = c->cfg.dt;
     a.damping = c->cfg.damping;
+    const char *nr = getenv("MAPN_NO_XCD_REMAP");          // A/B switch for the XCD-aware mapping
+    a.xcd_remap = (nr && nr[0] == '1') ? 0u : 1u;
     return a;
 }
 

@@ -118,10 +118,10 @@ __device__ __forceinline__ void integrate_store(const StepArgs &p, uint32_t i, f
 // block id so that the blocks sharing an XCD walk the SAME j-chunk rows: each XCD's 4 MiB L2
 // then holds 1/8 of the j-range instead of all of it (matters from N = 262 144 up, where the
 // position buffer no longer fits one L2).  Speed only, never correctness.
-__device__ __forceinline__ void xcd_remap(uint32_t &bx, uint32_t &by)
+__device__ __forceinline__ void xcd_remap(uint32_t &bx, uint32_t &by, uint32_t enabled)
 {
     const uint32_t gx = gridDim.x, gy = gridDim.y;
-    if ((gy & 7u) == 0u) {
+    if (enabled && (gy & 7u) == 0u) {
         const uint32_t lin = blockIdx.y * gx + blockIdx.x;
         const uint32_t xcd = lin & 7u, slot = lin >> 3;
         const uint32_t rows_per_xcd = gy >> 3;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64 * WAVES) void force_lds_kernel(const StepArgs p)
     __shared__ float red[WAVES][3][128 * K2];
 
     uint32_t bx, by;
-    xcd_remap(bx, by);
+    xcd_remap(bx, by, p.xcd_remap);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t seg = blockIdx.z;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 * WAVES) void force_sgpr_kernel(const StepArgs p
     __shared__ float red[WAVES][3][128 * K2];
 
     uint32_t bx, by;
-    xcd_remap(bx, by);
+    xcd_remap(bx, by, p.xcd_remap);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t seg = blockIdx.z;

@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--prewarm-ms", type=float, default=400.0,
+                    help="untimed clock-ramp phase before the W warm-up steps (the chip needs a few hundred ms of "
+                         "load to settle its clock; 0 disables)")
     ap.add_argument("--overlap", action="store_true", help="sharded mode: own-segment launch overlapped with the all-gather")
     ap.add_argument("--force-comm", action="store_true",
                     help="create the torch.distributed group and the in-library RCCL communicator even for one rank (exercises the sharded code path on a 1-GPU box)")
@@ -154,7 +157,8 @@ def main():
     if a.plan:
         kname, k, w, sb, fused = a.plan.split(",")
         c.set_force_plan({"lds": mapn.KERNEL_LDS, "sgpr": mapn.KERNEL_SCALAR}[kname], int(k), int(w), int(sb), bool(int(fused)))
-    c.set_timers(a.timer_interval if a.timer_interval >= 0 else 8)
+    timer_interval = a.timer_interval if a.timer_interval >= 0 else (8 if a.steps >= 32 else 1)
+    c.set_timers(timer_interval)
 
     def step():
         fence = c.GetFenceValue()             # Particles.cpp:446-448
@@ -196,9 +200,29 @@ def main():
         elif a.gather == "auto":
             gather_algo = "allgather"
         c.set_gather_algorithm(1 if gather_algo == "sendrecv" else 0)
+    prewarm_steps = 0
+    if a.prewarm_ms > 0:
+        # same work as a timed step, just not timed: lets the clock settle so that a short K does
+        # not measure the ramp (1.18 ms/step over the first 5 steps vs 0.88 ms steady state)
+        if dist is None:
+            t_end = time.perf_counter() + a.prewarm_ms * 1e-3
+            while time.perf_counter() < t_end:
+                for _ in range(16):
+                    step()
+                c.WaitForGpu()
+                prewarm_steps += 16
+        else:
+            # sharded: every step holds a collective, so all ranks must run the SAME number of
+            # steps -- a fixed count (about prewarm_ms at the single-GPU step time / world)
+            prewarm_steps = max(16, int(a.prewarm_ms * 1e-3 / (0.9e-3 / world * (n / 65536.0) ** 2)) // 16 * 16)
+            prewarm_steps = min(prewarm_steps, 4096)
+            for _ in range(prewarm_steps):
+                step()
+            c.WaitForGpu()
     for _ in range(a.warmup):
         step()
     sync()
+    c.set_timers(timer_interval)          # restart the sampling phase: the first timed step carries events
     c.kernel_stats(reset=True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -229,7 +253,7 @@ def main():
             "config": {"workload": f"{n} bodies, all-pairs softened gravity + kick-drift step, fp32 (BASELINE configs[1])"
                        if a.mode == "all_pairs" else f"{n} bodies, central-well step as shipped (nBodyGravityCS.hlsl:86-109)",
                        "bodies": n, "mode": a.mode, "parallelism": f"bodies sharded x{world}" if world > 1 else "1 GPU",
-                       "transport": transport, "exchange": gather_algo, "seed": a.seed, "mass": "70000/N", "device": (info.name.decode() or "MI355X") + " / " + info.arch.decode(),
+                       "transport": transport, "exchange": gather_algo, "prewarm_steps_untimed": prewarm_steps, "seed": a.seed, "mass": "70000/N", "device": (info.name.decode() or "MI355X") + " / " + info.arch.decode(),
                        "kernel": st.kernel_name.decode(), "bodies_per_lane": st.bodies_per_lane, "j_splits": st.j_splits,
                        "grid": [st.grid_x, st.grid_y], "block": st.block_x, "fused_integrator": bool(st.fused)},
         }

@@ -39,12 +39,16 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--plan", default="", help="kernel,bodies_per_lane,waves,sb,fused e.g. lds,4,8,1,1")
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl")
-    ap.add_argument("--gather", choices=["auto", "allgather", "sendrecv"], default="auto",
-                    help="how the in-library RCCL exchange is issued; auto times both during warm-up and keeps the faster")
+    ap.add_argument("--gather", choices=["auto", "allgather", "sendrecv", "p2p"], default="auto",
+                    help="how the in-library exchange is issued: RCCL ncclAllGather, one group of RCCL send/recv pairs, or the "
+                         "direct peer-to-peer pull kernel (hipIpc + device flags); auto times every way that sets up and "
+                         "verifies on this node during untimed steps and keeps the fastest")
     ap.add_argument("--timer-interval", type=int, default=-1, help="time every T-th force launch of the timed region with HIP events (0 = off; default 8: each hipEventRecord costs ~4 us of queue time, 1.6 %% of a 0.9 ms step when every step carries three)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for barriers / rendezvous (gloo for single-GPU tests)")
+    ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses device 0 (needs --dist-backend gloo --gather p2p)")
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed clock-ramp phase before the W warm-up steps (the chip needs a few hundred ms of "
                          "load to settle its clock; 0 disables)")
@@ -128,8 +132,14 @@ def main():
         import torch            # first: its HIP runtime is then the one libmapn binds to
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.same_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
+    red_dev = "cuda" if a.dist_backend == "nccl" else "cpu"     # where small reduction tensors live
 
     import mapn
     from mapn.compute import device_info
@@ -144,7 +154,7 @@ def main():
     gather_fn = None
     if dist is not None:
         transport = a.transport
-        if transport == "rccl":
+        if transport == "rccl" and a.gather != "p2p":
             try:
                 c.comm_init_torch()
             except Exception as e:     # RCCL-in-library unavailable: use torch's RCCL instead, loudly
@@ -175,13 +185,41 @@ def main():
             torch.cuda.synchronize()
 
     gather_algo = "n/a"
+    trial = {}
+
+    def replicas_consistent():
+        """Every rank keeps a full replica of the positions; after any correct exchange they are
+        bit-identical.  Compares a checksum of both ping-pong buffers across ranks."""
+        c.WaitForGpu()
+        import numpy as np
+        sums = [int(np.frombuffer(c.download_buffer(b)[0].tobytes(), np.uint32).sum(dtype=np.uint64)) for b in (0, 1)]
+        allsums = [None] * world
+        dist.all_gather_object(allsums, sums)
+        return all(x == allsums[0] for x in allsums)
+
     if dist is not None and transport == "rccl":
-        gather_algo = a.gather
-        if a.gather == "auto" and world > 1:
-            # time both ways of issuing the exchange (same bytes, same RCCL communicator) on a few
-            # untimed steps; every rank must take the same decision -> MAX over ranks, rank-0 rule
-            trial = {}
-            for name, algo in (("allgather", 0), ("sendrecv", 1)):
+        candidates = []
+        if a.gather in ("auto", "allgather"):
+            candidates.append(("allgather", 0))
+        if a.gather in ("auto", "sendrecv"):
+            candidates.append(("sendrecv", 1))
+        p2p_ok = False
+        if a.gather in ("auto", "p2p") and world > 1:
+            try:
+                c.p2p_setup_torch()
+                ok = torch.tensor([1], device=red_dev)
+            except Exception as e:
+                print(f"[bench rank {rank}] p2p setup failed: {e}", file=sys.stderr, flush=True)
+                ok = torch.tensor([0], device=red_dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # all ranks or none
+            p2p_ok = bool(ok.item())
+            if p2p_ok:
+                candidates.append(("p2p", 2))
+        if world > 1 and len(candidates) > 1:
+            # time every way of issuing the exchange (same bytes) on a few untimed steps; every rank
+            # must take the same decision -> MAX over ranks.  The peer-to-peer kernel must also PROVE
+            # itself on this node: no timed-out wait and bit-identical replicas on all ranks.
+            for name, algo in candidates:
                 c.set_gather_algorithm(algo)
                 for _ in range(5):
                     step()
@@ -190,16 +228,31 @@ def main():
                 for _ in range(30):
                     step()
                 sync()
-                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 trial[name] = float(t.item()) / 30
+                if name == "p2p":
+                    bad = torch.tensor([0 if (c.p2p_status() == 0 and replicas_consistent()) else 1], device=red_dev)
+                    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                    if bad.item():
+                        if rank == 0:
+                            print("[bench] p2p exchange failed verification on this node -> not used; state re-initialised",
+                                  file=sys.stderr, flush=True)
+                        del trial["p2p"]
+                        c.set_gather_algorithm(0)
+                        pos0, vel0 = mapn.generate_initial_state(n, seed=a.seed)
+                        c.upload_state(pos0, vel0)
+                        sync()
             gather_algo = min(trial, key=trial.get)
             if rank == 0:
-                print(f"[bench] exchange trial: " + ", ".join(f"{k} {v*1e6:.1f} us/step" for k, v in trial.items()) + f" -> {gather_algo}",
+                print("[bench] exchange trial: " + ", ".join(f"{k} {v*1e6:.1f} us/step" for k, v in trial.items()) + f" -> {gather_algo}",
                       file=sys.stderr, flush=True)
-        elif a.gather == "auto":
-            gather_algo = "allgather"
-        c.set_gather_algorithm(1 if gather_algo == "sendrecv" else 0)
+        else:
+            gather_algo = candidates[0][0] if candidates else "allgather"
+            if gather_algo == "p2p" and not p2p_ok:
+                sys.exit("bench: --gather p2p requested but the peer-to-peer setup failed")
+        c.set_gather_algorithm({"allgather": 0, "sendrecv": 1, "p2p": 2}[gather_algo])
+        transport = "p2p (hipIpc + device flags)" if gather_algo == "p2p" else "rccl"
     prewarm_steps = 0
     if a.prewarm_ms > 0:
         # same work as a timed step, just not timed: lets the clock settle so that a short K does
@@ -230,12 +283,15 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     st = c.kernel_stats()
     first, count = c.shard_range()
+    consistent = None
+    if dist is not None and world > 1 and gather_algo != "n/a":
+        consistent = replicas_consistent() and (gather_algo != "p2p" or c.p2p_status() == 0)
     if rank == 0:
         pairs_per_step = float(n) * float(n) if a.mode == "all_pairs" else float(n)
         value = pairs_per_step * a.steps / elapsed
@@ -253,7 +309,8 @@ def main():
             "config": {"workload": f"{n} bodies, all-pairs softened gravity + kick-drift step, fp32 (BASELINE configs[1])"
                        if a.mode == "all_pairs" else f"{n} bodies, central-well step as shipped (nBodyGravityCS.hlsl:86-109)",
                        "bodies": n, "mode": a.mode, "parallelism": f"bodies sharded x{world}" if world > 1 else "1 GPU",
-                       "transport": transport, "exchange": gather_algo, "prewarm_steps_untimed": prewarm_steps, "seed": a.seed, "mass": "70000/N", "device": (info.name.decode() or "MI355X") + " / " + info.arch.decode(),
+                       "transport": transport, "exchange": gather_algo, "exchange_trial_us_per_step": {k: v * 1e6 for k, v in trial.items()},
+                       "replicas_bit_identical_after_run": consistent, "prewarm_steps_untimed": prewarm_steps, "seed": a.seed, "mass": "70000/N", "device": (info.name.decode() or "MI355X") + " / " + info.arch.decode(),
                        "kernel": st.kernel_name.decode(), "bodies_per_lane": st.bodies_per_lane, "j_splits": st.j_splits,
                        "grid": [st.grid_x, st.grid_y], "block": st.block_x, "fused_integrator": bool(st.fused)},
         }

@@ -240,8 +240,21 @@ int mapn_comm_get_unique_id(void *out_id128);
  * all-gather of the new position slices over RCCL/xGMI on the context's comm stream */
 int mapn_comm_init(mapn_ctx *ctx, const void *id128);
 /* how the native exchange is issued: 0 = ncclAllGather (default), 1 = one group of ncclSend /
- * ncclRecv pairs (a single direct xGMI hop per peer instead of a ring); all ranks must agree */
+ * ncclRecv pairs (a single direct xGMI hop per peer instead of a ring), 2 = the direct
+ * peer-to-peer exchange below (after mapn_p2p_import); all ranks must agree */
 int mapn_set_gather_algorithm(mapn_ctx *ctx, int algorithm);
+/*
+ * Direct peer-to-peer exchange (algorithm 2 of mapn_set_gather_algorithm), no collective library:
+ * every rank exports a blob describing its position heap and its flag array (hipIpc handles),
+ * the launcher all-gathers the blobs (rank order) and every rank imports them.  Afterwards each
+ * step ends with one small kernel that publishes a per-peer flag, waits for the peers' flags and
+ * pulls their slices over xGMI (csrc/mapn_kernels.hip, p2p_gather_kernel).  Device-side waits are
+ * bounded: mapn_p2p_status() != 0 reports a wait that timed out (peer q = status - 1).
+ */
+#define MAPN_P2P_BLOB_BYTES 192
+int mapn_p2p_export(mapn_ctx *ctx, void *out_blob);
+int mapn_p2p_import(mapn_ctx *ctx, const void *blobs, int count);
+int mapn_p2p_status(mapn_ctx *ctx);
 /* alternative transport: the caller all-gathers the written position buffer itself after every
  * step (e.g. torch.distributed.all_gather_into_tensor on the exported buffers) */
 int mapn_set_external_gather(mapn_ctx *ctx, int enabled);

@@ -18,6 +18,7 @@ INIT_LCG, INIT_SSE, INIT_MT = 0, 1, 2
 FLAG_NO_INIT = 0x2
 FLAG_SHARD_OVERLAP = 0x4
 UNIQUE_ID_BYTES = 128
+P2P_BLOB_BYTES = 192
 
 
 class MapnError(RuntimeError):
@@ -100,6 +101,9 @@ SIGNATURES = {
     "mapn_comm_get_unique_id": (C.c_int, [C.c_void_p]),
     "mapn_comm_init": (C.c_int, [_ctx, C.c_void_p]),
     "mapn_set_gather_algorithm": (C.c_int, [_ctx, C.c_int]),
+    "mapn_p2p_export": (C.c_int, [_ctx, C.c_void_p]),
+    "mapn_p2p_import": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
+    "mapn_p2p_status": (C.c_int, [_ctx]),
     "mapn_set_external_gather": (C.c_int, [_ctx, C.c_int]),
     "mapn_shard_range": (C.c_int, [_ctx, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mapn_get_device_info": (C.c_int, [C.c_int, C.POINTER(DeviceInfo)]),

@@ -202,6 +202,29 @@ class Compute:
         """0 = ncclAllGather, 1 = grouped ncclSend/ncclRecv (collective choice: all ranks alike)."""
         check(self._lib.mapn_set_gather_algorithm(self._ctx, int(algorithm)))
 
+    def p2p_export(self) -> bytes:
+        buf = C.create_string_buffer(_lib.P2P_BLOB_BYTES)
+        check(self._lib.mapn_p2p_export(self._ctx, C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    def p2p_import(self, blobs):
+        raw = b"".join(blobs)
+        if len(raw) != _lib.P2P_BLOB_BYTES * len(blobs):
+            raise ValueError("every blob must be %d bytes" % _lib.P2P_BLOB_BYTES)
+        buf = C.create_string_buffer(raw, len(raw))
+        check(self._lib.mapn_p2p_import(self._ctx, C.cast(buf, C.c_void_p), len(blobs)))
+
+    def p2p_setup_torch(self):
+        """Exchange the hipIpc blobs through an initialised torch.distributed group (any backend)
+        and map every peer's buffers; afterwards set_gather_algorithm(2) selects the exchange."""
+        import torch.distributed as dist
+        blobs = [None] * dist.get_world_size()
+        dist.all_gather_object(blobs, self.p2p_export())
+        self.p2p_import(blobs)
+
+    def p2p_status(self) -> int:
+        return int(self._lib.mapn_p2p_status(self._ctx))
+
     def set_external_gather(self, enabled: bool = True):
         check(self._lib.mapn_set_external_gather(self._ctx, int(bool(enabled))))
 

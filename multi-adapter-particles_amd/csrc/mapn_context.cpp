@@ -105,7 +105,15 @@ struct mapn_ctx {
     hipEvent_t gather_done[2] = {nullptr, nullptr};
     bool gather_recorded[2] = {false, false};
     bool external_gather = false;
-    int gather_algo = 0;                      // 0 ncclAllGather, 1 grouped ncclSend/ncclRecv
+    int gather_algo = 0;                      // 0 ncclAllGather, 1 grouped ncclSend/ncclRecv, 2 direct peer-to-peer
+
+    // direct peer-to-peer exchange (hipIpc-mapped peer buffers + device flags)
+    bool p2p_ready = false;
+    uint32_t *p2p_flags = nullptr;            // uncached device memory, [world] publication counters
+    uint32_t *p2p_status = nullptr;           // pinned host word: non-zero = a device-side wait timed out
+    void *p2p_peer_heap[mapn::P2P_MAX_RANKS] = {};
+    uint32_t *p2p_peer_flags[mapn::P2P_MAX_RANKS] = {};
+    uint32_t p2p_step = 0;
 
     // graph replay
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
@@ -289,8 +297,8 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
     mapn::StepArgs a = base_args(c, w, r);
     a.i_first = lo;
     a.i_count = i_count;
-    const bool sharded_native = c->comm != nullptr;
-    const bool overlap = sharded_native && (c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP);
+    const bool sharded_native = c->comm != nullptr || (c->p2p_ready && c->gather_algo == 2);
+    const bool overlap = c->comm != nullptr && c->gather_algo != 2 && (c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP);
 
     if (timer) HIP_TRY(hipEventRecord(timer->start, c->compute));
 
@@ -379,8 +387,30 @@ int enqueue_step_graph(mapn_ctx *c, uint32_t active)
     return MAPN_OK;
 }
 
+int enqueue_p2p(mapn_ctx *c)
+{
+    const uint32_t w = c->buffer_index;
+    mapn::P2PArgs a{};
+    a.local = c->pos[w];
+    for (int q = 0; q < c->cfg.world_size; q++) {
+        // both position buffers live in one heap allocation: buffer w sits w * aligned_data_size in
+        a.peer[q] = reinterpret_cast<const float4 *>(static_cast<char *>(c->p2p_peer_heap[q]) + (size_t)w * c->aligned_data_size);
+        a.peer_flags[q] = c->p2p_peer_flags[q];
+    }
+    a.my_flags = c->p2p_flags;
+    a.status = c->p2p_status;
+    a.rank = (uint32_t)c->cfg.rank;
+    a.world = (uint32_t)c->cfg.world_size;
+    a.count = c->count;
+    a.step = ++c->p2p_step;
+    a.timeout_ticks = 300ull * 1000ull * 1000ull;          // 3 s of s_memrealtime (100 MHz)
+    HIP_TRY(mapn::launch_p2p_gather(a, c->compute));
+    return MAPN_OK;
+}
+
 int enqueue_gather(mapn_ctx *c)
 {
+    if (c->p2p_ready && c->gather_algo == 2) return enqueue_p2p(c);
     if (!c->comm) return MAPN_OK;
     const uint32_t w = c->buffer_index;
     const bool overlap = (c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP) != 0;
@@ -559,6 +589,13 @@ int mapn_destroy(mapn_ctx *c)
     if (c->compute) (void)hipStreamSynchronize(c->compute);          // Compute.cpp:104 WaitForGpu first
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm) mapn::comm_destroy(c->comm);
+    for (int q = 0; q < mapn::P2P_MAX_RANKS; q++) {
+        if (q == c->cfg.rank) continue;
+        if (c->p2p_peer_heap[q]) (void)hipIpcCloseMemHandle(c->p2p_peer_heap[q]);
+        if (c->p2p_peer_flags[q]) (void)hipIpcCloseMemHandle(c->p2p_peer_flags[q]);
+    }
+    if (c->p2p_flags) (void)hipFree(c->p2p_flags);
+    if (c->p2p_status) (void)hipHostFree(c->p2p_status);
     for (int b = 0; b < 2; b++) {
         if (c->graph_exec[b]) (void)hipGraphExecDestroy(c->graph_exec[b]);
         if (c->vel[b]) (void)hipFree(c->vel[b]);
@@ -582,7 +619,7 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
 {
     if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    if (c->cfg.world_size > 1 && !c->comm && !c->external_gather)
+    if (c->cfg.world_size > 1 && !c->comm && !c->external_gather && !(c->p2p_ready && c->gather_algo == 2))
         return fail(MAPN_ERR_STATE, "sharded context (world_size %d): call mapn_comm_init or "
                     "mapn_set_external_gather before simulate", c->cfg.world_size);
     if (int rc = wait_for_consumer(c, wait_value)) return rc;          // Compute.cpp:1012
@@ -594,7 +631,7 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
         if (timer->pending) { if (int rc = resolve_timers(c, true)) return rc; }
         timer->has_force = false;
     }
-    const bool use_graph = (c->cfg.flags & MAPN_FLAG_USE_GRAPH) && !c->comm && !timer && active > 0;
+    const bool use_graph = (c->cfg.flags & MAPN_FLAG_USE_GRAPH) && !c->comm && !c->p2p_ready && !timer && active > 0;
     if (int rc = use_graph ? enqueue_step_graph(c, active) : enqueue_step(c, active, timer)) return rc;
     if (timer) {
         HIP_TRY(hipEventRecord(timer->stop, c->compute));              // Compute.cpp:1046-1047
@@ -602,16 +639,17 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
         c->timer_head = (c->timer_head + 1) % kTimerRing;
     }
     // MoveToNextFrame, Compute.cpp:993-1004: Signal(fence, v); v++; index = 1 - index
-    const bool gather_first = c->comm && !(c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP);
+    const bool exchanging = c->comm != nullptr || (c->p2p_ready && c->gather_algo == 2);
+    const bool gather_first = exchanging && (!(c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP) || c->gather_algo == 2);
     if (gather_first) { if (int rc = enqueue_gather(c)) return rc; }   // same stream: the fence then covers the gather
     // The fence value always advances; the hipEvent behind it (a few us of queue time each) is
     // recorded on every step only while somebody can observe it -- an attached consumer, exported
     // handles, the overlap structure -- and otherwise on every 16th step, which only makes
     // mapn_completed_value() conservative.  mapn_wait_idle() always records.
-    const bool record = c->fence_every_step || c->consumer_enabled || (c->comm && !gather_first) ||
+    const bool record = c->fence_every_step || c->consumer_enabled || (exchanging && !gather_first) ||
                         (c->fence_value % 16) == 0;
     if (record) { if (int rc = signal_fence(c, c->fence_value)) return rc; }
-    if (c->comm && !gather_first) { if (int rc = enqueue_gather(c)) return rc; }   // overlap: behind the fence event
+    if (exchanging && !gather_first) { if (int rc = enqueue_gather(c)) return rc; }   // overlap: behind the fence event
     c->fence_value++;
     c->buffer_index = 1 - c->buffer_index;
     if (timer && (c->timer_head % 16) == 0) (void)resolve_timers(c, false);
@@ -876,10 +914,84 @@ int mapn_comm_init(mapn_ctx *c, const void *id128)
 
 int mapn_set_gather_algorithm(mapn_ctx *c, int algorithm)
 {
-    if (!c || algorithm < 0 || algorithm > 1) return fail(MAPN_ERR_INVALID_ARGUMENT, "set_gather_algorithm: bad argument");
+    if (!c || algorithm < 0 || algorithm > 2) return fail(MAPN_ERR_INVALID_ARGUMENT, "set_gather_algorithm: bad argument");
+    if (algorithm == 2 && !c->p2p_ready) return fail(MAPN_ERR_STATE, "set_gather_algorithm(2): call mapn_p2p_import first");
+    if (algorithm != 2 && c->cfg.world_size > 1 && !c->comm && !c->external_gather)
+        return fail(MAPN_ERR_STATE, "set_gather_algorithm(%d): no RCCL communicator (mapn_comm_init)", algorithm);
     if (int rc = mapn_wait_idle(c)) return rc;
     c->gather_algo = algorithm;
     return MAPN_OK;
+}
+
+// ---- direct peer-to-peer exchange -----------------------------------------------------------------
+
+namespace {
+struct P2PBlob {
+    char magic[8];
+    uint32_t rank, world, n, reserved;
+    uint64_t aligned_data_size;
+    hipIpcMemHandle_t heap, flags;
+};
+static_assert(sizeof(P2PBlob) <= MAPN_P2P_BLOB_BYTES, "MAPN_P2P_BLOB_BYTES too small");
+}  // namespace
+
+int mapn_p2p_export(mapn_ctx *c, void *out_blob)
+{
+    if (!c || !out_blob) return fail(MAPN_ERR_INVALID_ARGUMENT, "p2p_export: null argument");
+    if (c->cfg.world_size < 2 || c->cfg.world_size > mapn::P2P_MAX_RANKS)
+        return fail(MAPN_ERR_STATE, "p2p_export: world_size %d (2..%d supported)", c->cfg.world_size, mapn::P2P_MAX_RANKS);
+    if (c->adopted) return fail(MAPN_ERR_STATE, "p2p_export: context is in adopted-buffer (async) mode");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->p2p_flags) {
+        // publication counters: uncached device memory, so that a peer's store over xGMI and this
+        // GPU's polling loads meet in memory, never in a cache
+        HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void **>(&c->p2p_flags), 256, hipDeviceMallocUncached));
+        HIP_TRY(hipMemset(c->p2p_flags, 0, 256));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->p2p_status), 64, hipHostMallocMapped));
+        *c->p2p_status = 0;
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    P2PBlob b{};
+    memcpy(b.magic, "MAPNP2P1", 8);
+    b.rank = (uint32_t)c->cfg.rank; b.world = (uint32_t)c->cfg.world_size; b.n = c->n;
+    b.aligned_data_size = c->aligned_data_size;
+    HIP_TRY(hipIpcGetMemHandle(&b.heap, c->pos_heap));
+    HIP_TRY(hipIpcGetMemHandle(&b.flags, c->p2p_flags));
+    memset(out_blob, 0, MAPN_P2P_BLOB_BYTES);
+    memcpy(out_blob, &b, sizeof b);
+    return MAPN_OK;
+}
+
+int mapn_p2p_import(mapn_ctx *c, const void *blobs, int count)
+{
+    if (!c || !blobs) return fail(MAPN_ERR_INVALID_ARGUMENT, "p2p_import: null argument");
+    if (count != c->cfg.world_size) return fail(MAPN_ERR_INVALID_ARGUMENT, "p2p_import: %d blobs for world_size %d", count, c->cfg.world_size);
+    if (!c->p2p_flags) return fail(MAPN_ERR_STATE, "p2p_import: call mapn_p2p_export first");
+    if (c->p2p_ready) return MAPN_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    for (int q = 0; q < count; q++) {
+        P2PBlob b;
+        memcpy(&b, static_cast<const char *>(blobs) + (size_t)q * MAPN_P2P_BLOB_BYTES, sizeof b);
+        if (memcmp(b.magic, "MAPNP2P1", 8) != 0 || (int)b.rank != q || (int)b.world != count || b.n != c->n ||
+            b.aligned_data_size != c->aligned_data_size)
+            return fail(MAPN_ERR_INVALID_ARGUMENT, "p2p_import: blob %d does not describe rank %d of this job", q, q);
+        if (q == c->cfg.rank) {
+            c->p2p_peer_heap[q] = c->pos_heap;
+            c->p2p_peer_flags[q] = c->p2p_flags;
+            continue;
+        }
+        HIP_TRY(hipIpcOpenMemHandle(&c->p2p_peer_heap[q], b.heap, hipIpcMemLazyEnablePeerAccess));
+        HIP_TRY(hipIpcOpenMemHandle(reinterpret_cast<void **>(&c->p2p_peer_flags[q]), b.flags, hipIpcMemLazyEnablePeerAccess));
+    }
+    c->p2p_ready = true;
+    return MAPN_OK;
+}
+
+int mapn_p2p_status(mapn_ctx *c)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    if (!c->p2p_status) return 0;
+    return (int)*reinterpret_cast<volatile uint32_t *>(c->p2p_status);
 }
 
 int mapn_set_external_gather(mapn_ctx *c, int enabled)

@@ -42,6 +42,21 @@ bool force_plan_supported(const ForcePlan &plan);
 hipError_t launch_force(const ForcePlan &plan, const StepArgs &a, hipStream_t st);
 hipError_t launch_reduce_integrate(const StepArgs &a, uint32_t slots, hipStream_t st);
 hipError_t launch_central_well(const StepArgs &a, hipStream_t st);
+
+// Direct peer-to-peer exchange of the new position slices (one process per GPU, peers' buffers
+// mapped through hipIpc).  See p2p_gather_kernel.
+enum { P2P_MAX_RANKS = 16 };
+struct P2PArgs {
+    float4       *local;                    // this rank's written position buffer (full N)
+    const float4 *peer[P2P_MAX_RANKS];      // every rank's written position buffer, as mapped here
+    uint32_t     *peer_flags[P2P_MAX_RANKS];// every rank's flag array [world], as mapped here
+    uint32_t     *my_flags;                 // this rank's flag array: my_flags[q] = last step rank q published
+    uint32_t     *status;                   // host-visible word: non-zero = a wait timed out
+    uint32_t      rank, world, count;       // count = bodies per rank
+    uint32_t      step;                     // monotonically increasing publication number (>= 1)
+    uint64_t      timeout_ticks;            // s_memrealtime ticks (100 MHz) before a wait gives up
+};
+hipError_t launch_p2p_gather(const P2PArgs &a, hipStream_t st);
 const char *force_kernel_name(const ForcePlan &plan);
 
 }  // namespace mapn

@@ -376,6 +376,64 @@ __global__ __launch_bounds__(256) void central_well_kernel(const StepArgs p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Direct exchange of the new position slices between the GPUs of a node, without a collective
+// library: workgroup b serves peer q (the b-th rank other than this one).
+//   1. publish : one lane stores `step` into q's flag array, slot [rank], over xGMI.  The slice
+//                itself was written by the PREVIOUS kernel of this stream (reduce_integrate), so
+//                it is in this GPU's memory before this kernel starts; nothing to flush here.
+//   2. wait    : the same lane polls this GPU's own flag array, slot [q] (uncached memory, relaxed
+//                system-scope loads, s_sleep between polls, bounded by a wall-clock timeout that
+//                sets *status instead of hanging), then ONE system-scope acquire so that this
+//                CU's L1 and this XCD's L2 hold no stale copy of q's buffer from two steps ago.
+//   3. pull    : the workgroup copies q's slice (count float4) from q's buffer into the same
+//                offset of the local buffer.
+// No end-of-step handshake is needed: q overwrites its slice of this buffer again only at step
+// s+2, after its force(s+2), which needs this rank's slice(s+1), which this rank produces only
+// after its own gather(s) -- i.e. after this pull -- has completed.
+__global__ __launch_bounds__(1024) void p2p_gather_kernel(const P2PArgs p)
+{
+    const uint32_t b = blockIdx.x;
+    const uint32_t q = b < p.rank ? b : b + 1u;            // skip self
+    __shared__ uint32_t ok;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(p.peer_flags[q] + p.rank, p.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        uint32_t good = 1u;
+        while ((int32_t)(__hip_atomic_load(p.my_flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - p.step) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) { good = 0u; break; }
+        }
+        if (!good) __hip_atomic_store(p.status, 1u + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");       // system scope: buffer_inv sc0 sc1
+        ok = good;
+    }
+    __syncthreads();
+    if (!ok) return;
+    // payload as 8-byte relaxed SYSTEM-scope loads (global_load_dwordx2 sc0 sc1): they bypass this
+    // GPU's L1/L2 altogether, so a line of q's buffer cached here two steps ago cannot be returned
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p.peer[q] + (size_t)q * p.count);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.local + (size_t)q * p.count);
+    const uint32_t words = p.count * 2u;
+    uint32_t i = threadIdx.x;
+    for (; i + 7u * 1024u < words; i += 8u * 1024u) {          // 8 remote loads in flight per lane
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = __hip_atomic_load(src + i + u * 1024u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int u = 0; u < 8; u++) dst[i + u * 1024u] = v[u];
+    }
+    for (; i < words; i += 1024u)
+        dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_p2p_gather(const P2PArgs &a, hipStream_t st)
+{
+    if (a.world < 2) return hipSuccess;
+    hipLaunchKernelGGL(p2p_gather_kernel, dim3(a.world - 1), dim3(1024), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launch table
 
 template <int K2, int WAVES>

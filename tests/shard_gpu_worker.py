@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 def main():
     rank, world, port, n, steps = (int(x) for x in sys.argv[1:6])
     out_dir = sys.argv[6]
+    mode = sys.argv[7] if len(sys.argv) > 7 else "external"
     import torch
     import torch.distributed as dist
     import mapn
@@ -20,8 +21,33 @@ def main():
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     c = mapn.Compute(n, device=0, mass=70000.0 / n, rank=rank, world_size=world)
-    c.set_external_gather(True)
     first, count = c.shard_range()
+    if mode == "p2p":
+        # the in-library direct exchange: hipIpc-mapped peer buffers + device flags, no caller help
+        c.p2p_setup_torch()
+        c.set_gather_algorithm(2)
+        num_active = int(sys.argv[8]) if len(sys.argv) > 8 else n
+        for _ in range(steps):
+            c.Simulate(num_active, c.GetFenceValue())
+        c.WaitForGpu()
+        assert c.p2p_status() == 0, f"p2p wait timed out: status {c.p2p_status()}"
+        pos, vel = c.download_state()
+        other = c.download_buffer(c.buffer_index)[0]
+        # every replica must hold the same positions, bit for bit
+        sums = [None] * world
+        dist.all_gather_object(sums, (int(np.frombuffer(pos.tobytes(), np.uint32).sum(dtype=np.uint64)),
+                                      int(np.frombuffer(other.tobytes(), np.uint32).sum(dtype=np.uint64))))
+        assert all(s == sums[0] for s in sums), f"position replicas differ across ranks: {sums}"
+        mine_v = torch.from_numpy(vel[first:first + count].copy())
+        fullv = torch.empty((n, 3), dtype=torch.float32)
+        dist.all_gather_into_tensor(fullv, mine_v)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "gpu_sharded.npz"), pos=pos, vel=fullv.numpy(), other=other)
+        c.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    c.set_external_gather(True)
     for _ in range(steps):
         c.Simulate(n, c.GetFenceValue())
         pos, vel = c.download_state()                       # latest buffer: own slice is fresh

@@ -44,3 +44,22 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e8 and "sample" in cb
     assert d["value"] > 3.0e12            # the 40 %-of-peak target is 3.15e12 at kernel level
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_one_gpu_with_the_direct_exchange():
+    """The N > 1 flow of bench.py (rendezvous, sharded contexts, exchange set-up, barrier-bracketed
+    timing, MAX over ranks, replica consistency check) with two ranks sharing device 0: gloo for
+    the rendezvous (RCCL refuses two ranks on one device) and the in-library peer-to-peer
+    exchange for the data path."""
+    port = 29700 + (os.getpid() % 200)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "30", "--warmup", "3", "--gather", "p2p", "--dist-backend", "gloo",
+                        "--same-device", "--prewarm-ms", "20"], capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["exchange"] == "p2p"
+    assert d["config"]["replicas_bit_identical_after_run"] is True
+    assert d["config"]["parallelism"] == "bodies sharded x2" and "cpu_baseline" not in d

@@ -32,3 +32,34 @@ def test_two_processes_one_gpu_sharded_device_steps(tmp_path, oracle):
     dx = np.linalg.norm(got["pos"][:, :3].astype(np.float64) - sim.latest[0][:, :3], axis=1).max() / 400.0
     dv = np.linalg.norm(got["vel"].astype(np.float64) - sim.latest[1], axis=1).max() / 15.0
     assert dx < 3e-6 and dv < 6e-5, (dx, dv)
+
+
+def _run_ranks(tmp_path, world, n, steps, *extra):
+    port = 29600 + (os.getpid() % 2000) + world
+    worker = os.path.join(ROOT, "tests", "shard_gpu_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(n), str(steps), str(tmp_path), *extra],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    return np.load(os.path.join(str(tmp_path), "gpu_sharded.npz"))
+
+
+@pytest.mark.parametrize("world,num_active", [(2, 4096), (4, 4096), (8, 4096), (4, 2500)])
+def test_direct_p2p_exchange_between_processes(tmp_path, oracle, world, num_active):
+    """The in-library peer-to-peer exchange (hipIpc-mapped peer buffers, device-side publish /
+    wait / pull kernel) between `world` real processes, all on device 0: the free-running sharded
+    trajectory must match the CPU oracle, every replica must be bit-identical, and no device-side
+    wait may time out.  (Cross-GPU cache visibility cannot be exercised on one device; the
+    protocol, the IPC mapping, the flag ordering and the frozen-tail handling can.)"""
+    from oracle import OracleSim, Params
+    n, steps = 4096, 6
+    got = _run_ranks(tmp_path, world, n, steps, "p2p", str(num_active))
+    pos0, vel0 = oracle.initial_state(n, seed=1)
+    sim = OracleSim(oracle, pos0, vel0, params=Params(mass=70000.0 / n))
+    sim.simulate(num_active=num_active, steps=steps)
+    na = oracle.active_bodies(num_active, n)
+    dx = np.linalg.norm(got["pos"][:, :3].astype(np.float64) - sim.latest[0][:, :3], axis=1).max() / 400.0
+    dv = np.linalg.norm(got["vel"][:na].astype(np.float64) - sim.latest[1][:na], axis=1).max() / 15.0
+    assert dx < 5e-6 and dv < 1e-4, (dx, dv)
+    dxo = np.linalg.norm(got["other"][:, :3].astype(np.float64) - sim.pos[sim.buffer_index][:, :3], axis=1).max() / 400.0
+    assert dxo < 5e-6, dxo

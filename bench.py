@@ -292,6 +292,9 @@ def main():
     consistent = None
     if dist is not None and world > 1 and gather_algo != "n/a":
         consistent = replicas_consistent() and (gather_algo != "p2p" or c.p2p_status() == 0)
+        if not consistent and rank == 0:
+            print("[bench] WARNING: position replicas differ across ranks after the run -- the exchange misbehaved; "
+                  "this result is INVALID", file=sys.stderr, flush=True)
     if rank == 0:
         pairs_per_step = float(n) * float(n) if a.mode == "all_pairs" else float(n)
         value = pairs_per_step * a.steps / elapsed
@@ -310,7 +313,7 @@ def main():
                        if a.mode == "all_pairs" else f"{n} bodies, central-well step as shipped (nBodyGravityCS.hlsl:86-109)",
                        "bodies": n, "mode": a.mode, "parallelism": f"bodies sharded x{world}" if world > 1 else "1 GPU",
                        "transport": transport, "exchange": gather_algo, "exchange_trial_us_per_step": {k: v * 1e6 for k, v in trial.items()},
-                       "replicas_bit_identical_after_run": consistent, "prewarm_steps_untimed": prewarm_steps, "seed": a.seed, "mass": "70000/N", "device": (info.name.decode() or "MI355X") + " / " + info.arch.decode(),
+                       "replicas_bit_identical_after_run": consistent, "valid": consistent is not False, "prewarm_steps_untimed": prewarm_steps, "seed": a.seed, "mass": "70000/N", "device": (info.name.decode() or "MI355X") + " / " + info.arch.decode(),
                        "kernel": st.kernel_name.decode(), "bodies_per_lane": st.bodies_per_lane, "j_splits": st.j_splits,
                        "grid": [st.grid_x, st.grid_y], "block": st.block_x, "fused_integrator": bool(st.fused)},
         }

@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--bodies", type=int, default=65536)
     ap.add_argument("--mode", choices=["all_pairs", "central_well"], default="all_pairs")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--plan", default="", help="kernel,bodies_per_lane,waves,sb,fused e.g. lds,4,8,1,1")
+    ap.add_argument("--plan", default="", help="kernel,bodies_per_lane,waves,sb,fused e.g. sgpr,2,8,8,1 (fused: 0 = rows + reduce launch, 1 = one launch, 2 = ticket form always)")
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl")
     ap.add_argument("--gather", choices=["auto", "allgather", "sendrecv", "p2p"], default="auto",
                     help="how the in-library exchange is issued: RCCL ncclAllGather, one group of RCCL send/recv pairs, or the "
@@ -166,7 +166,7 @@ def main():
             gather_fn = make_torch_gather(c, torch, dist, n, rank, world)
     if a.plan:
         kname, k, w, sb, fused = a.plan.split(",")
-        c.set_force_plan({"lds": mapn.KERNEL_LDS, "sgpr": mapn.KERNEL_SCALAR}[kname], int(k), int(w), int(sb), bool(int(fused)))
+        c.set_force_plan({"lds": mapn.KERNEL_LDS, "sgpr": mapn.KERNEL_SCALAR}[kname], int(k), int(w), int(sb), int(fused))
     timer_interval = a.timer_interval if a.timer_interval >= 0 else (8 if a.steps >= 32 else 1)
     c.set_timers(timer_interval)
 

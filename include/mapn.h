@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MAPN_ABI_VERSION 1
+#define MAPN_ABI_VERSION 2
 
 typedef struct mapn_ctx mapn_ctx;
 
@@ -67,6 +67,8 @@ typedef enum mapn_init_variant {
 #define MAPN_FLAG_USE_GRAPH   0x1u  /* replay the step from a captured hipGraph */
 #define MAPN_FLAG_NO_INIT     0x2u  /* leave state zeroed; caller will mapn_upload_state() */
 #define MAPN_FLAG_SHARD_OVERLAP 0x4u /* sharded mode: own-segment launch overlapped with the all-gather */
+#define MAPN_FLAG_STRICT_CONSUMER 0x8u /* mapn_simulate(wait_value) returns MAPN_ERR_STATE instead of queueing
+                                          the wait when the consumer has not yet signalled wait_value - 1 */
 
 /*
  * Everything `Compute::Compute(numParticles, adapter, useIntelExt, old)` (Compute.h:36-39)
@@ -122,9 +124,15 @@ int mapn_destroy(mapn_ctx *ctx);
  * Compute::Simulate(int numActive, UINT64 sharedFenceValue) (Compute.h:48, Compute.cpp:1009-1055).
  * Asynchronous: enqueues one step and returns.  Bodies [0, min(roundup64(num_active), N))
  * advance (Compute.cpp:1041), the rest of the written buffer is left untouched.  If a consumer
- * is attached (mapn_set_consumer), the step first waits, on the device, until the consumer has
- * signalled `wait_value - 1` (Compute.cpp:1012); pass 0 when there is no consumer.  Afterwards
- * the fence value is +1 and the buffer index flipped (MoveToNextFrame, Compute.cpp:993-1004).
+ * is attached (mapn_set_consumer), the step first waits, ON THE DEVICE, until the consumer has
+ * signalled `wait_value - 1` (Compute.cpp:1012 queues `Wait(sharedRenderFence, v - 1)`
+ * unconditionally, and so does this: if the consumer has neither signalled nor registered an event
+ * yet, the compute stream parks until it does -- bounded by mapn_set_timeouts, default 10 s, after
+ * which the next call returns MAPN_ERR_STATE).  Pass 0 when there is no consumer.  With
+ * MAPN_FLAG_STRICT_CONSUMER an unsignalled value is a loud MAPN_ERR_STATE instead of a queued wait.
+ * Afterwards the fence value is +1 and the buffer index flipped (MoveToNextFrame,
+ * Compute.cpp:993-1004).  A device-side wait that timed out in an EARLIER step (peer-to-peer
+ * exchange, consumer fence) makes this call fail with MAPN_ERR_COMM / MAPN_ERR_STATE.
  */
 int mapn_simulate(mapn_ctx *ctx, int num_active, uint64_t wait_value);
 
@@ -144,13 +152,15 @@ uint32_t mapn_num_particles(const mapn_ctx *ctx);
 /*
  * Compute::GetSharedHandles (Compute.h:54-62, Compute.cpp:944-950) -> {heap, fence,
  * alignedDataSize, bufferIndex}.  HIP analogue: device pointers of the two position buffers,
- * a hipEvent_t recorded after every step, the per-buffer byte size and the buffer index.
- * Borrowed views, valid until mapn_destroy / mapn_adopt_position_buffers.  Velocities are
- * never exported (Compute.cpp:231-237).
+ * ONE hipEvent_t that the compute stream re-records after every step from this call on (fetch it
+ * once, like Render::SetShared opens the fence once, and hipStreamWaitEvent on it every frame),
+ * the per-buffer byte size and the buffer index.  Borrowed views, valid until mapn_destroy /
+ * mapn_adopt_position_buffers.  Velocities are never exported (Compute.cpp:231-237).
  */
 typedef struct mapn_shared_handles {
     void    *positions[2];       /* device float4[N] */
-    void    *step_done_event;    /* hipEvent_t, recorded on the compute stream after each step */
+    void    *step_done_event;    /* hipEvent_t, the same handle for the context's lifetime, re-recorded on the
+                                    compute stream after each step */
     uint64_t aligned_data_size;  /* bytes per position buffer, 64 KiB aligned (Compute.cpp:185-194) */
     uint32_t buffer_index;
     uint32_t reserved;
@@ -168,6 +178,11 @@ int mapn_consumer_signal(mapn_ctx *ctx, uint64_t value);
 /* device-side form: the consumer reaches `value` when hip_event (a hipEvent_t it has already
  * recorded on its own stream) fires; simulate then waits for it on the GPU, not on the host */
 int mapn_consumer_signal_event(mapn_ctx *ctx, uint64_t value, void *hip_event);
+/* bounds of the device-side waits in milliseconds (0 = leave unchanged): the peer-to-peer
+ * exchange's wait for a peer's slice (default 200) and the queued consumer-fence wait (default
+ * 10 000).  A wait that gives up is reported by the next mapn_simulate / mapn_wait_idle /
+ * mapn_download_* as MAPN_ERR_COMM (naming the peer) / MAPN_ERR_STATE. */
+int mapn_set_timeouts(mapn_ctx *ctx, uint32_t p2p_ms, uint32_t consumer_ms);
 
 /*
  * Compute::SetAsync (Compute.h:74-77, Compute.cpp:956-987): compute straight into two
@@ -210,6 +225,30 @@ int mapn_download_buffer(mapn_ctx *ctx, uint32_t index, float *pos4, float *vel3
 int mapn_copy_positions_async(mapn_ctx *ctx, uint32_t num_copied, void *dst, void *consumer_stream);
 
 /*
+ * The same hand-off across a PROCESS boundary (the reference shares an NT handle of the heap and
+ * of the fences, Compute.cpp:163-201,434-435,944-950; Render.cpp:222-251,612-617): the compute
+ * process exports a blob (hipIpc handles of the position heap, of a small uncached status / fence
+ * block, and of the step-done event); a renderer / analysis process on the same GPU opens it and
+ * gets a read-only view: where the latest results are (mapn_ipc_latest), an asynchronous copy of
+ * the first num_copied positions of a buffer behind the step-done event on ITS stream
+ * (Render.cpp:796,814), and Signal(consumerFence, value) ordered on its stream (Render.cpp:826),
+ * which is what mapn_simulate(wait_value) of the exporting process waits for (Compute.cpp:1012).
+ * Exporting attaches the consumer (mapn_set_consumer(1)) and makes every step publish
+ * {fence value, buffer index} to the status block (one extra one-lane launch per step).
+ */
+#define MAPN_IPC_BLOB_BYTES 256
+typedef struct mapn_ipc_view mapn_ipc_view;
+int mapn_ipc_export(mapn_ctx *ctx, void *out_blob);
+int mapn_ipc_open(const void *blob, int device, mapn_ipc_view **out_view);
+int mapn_ipc_close(mapn_ipc_view *view);
+/* fence value signalled by the latest published step and the buffer holding its positions */
+int mapn_ipc_latest(mapn_ipc_view *view, uint64_t *fence_value, uint32_t *buffer_index);
+void *mapn_ipc_positions(mapn_ipc_view *view, uint32_t buffer_index);
+int mapn_ipc_copy_positions_async(mapn_ipc_view *view, uint32_t buffer_index, uint32_t num_copied, void *dst,
+                                  void *consumer_stream);
+int mapn_ipc_consumer_signal(mapn_ipc_view *view, uint64_t value, void *consumer_stream);
+
+/*
  * On-disk snapshot (the reference has only the in-memory CopyState, Compute.cpp:303-410):
  * little-endian, 32-byte header {"MAPNSNAP", u32 version = 1, u32 N, u32 buffer_index,
  * u32 reserved, u64 fence_value}, then for buffer 0 and 1: float4[N] positions, float3[N]
@@ -249,7 +288,9 @@ int mapn_set_gather_algorithm(mapn_ctx *ctx, int algorithm);
  * the launcher all-gathers the blobs (rank order) and every rank imports them.  Afterwards each
  * step ends with one small kernel that publishes a per-peer flag, waits for the peers' flags and
  * pulls their slices over xGMI (csrc/mapn_kernels.hip, p2p_gather_kernel).  Device-side waits are
- * bounded: mapn_p2p_status() != 0 reports a wait that timed out (peer q = status - 1).
+ * bounded (mapn_set_timeouts, default 200 ms): a wait that timed out makes the next mapn_simulate /
+ * mapn_wait_idle / mapn_download_* return MAPN_ERR_COMM naming the peer; mapn_p2p_status() != 0
+ * reports the same without failing (peer q = status - 1).
  */
 #define MAPN_P2P_BLOB_BYTES 192
 int mapn_p2p_export(mapn_ctx *ctx, void *out_blob);
@@ -282,14 +323,26 @@ typedef struct mapn_kernel_stats {
     char     kernel_name[64];
     uint64_t launches;
     double   avg_seconds;
-    uint32_t grid_x, grid_y, block_x;
-    uint32_t bodies_per_lane, j_splits;
-    uint32_t fused;              /* 1: integrator fused into the force kernel */
+    uint32_t grid_x, grid_y, block_x;   /* of the force launch mapn_simulate enqueued last */
+    uint32_t bodies_per_lane, j_splits; /* j_splits = grid_y * (block_x / 64) chunks of 64-body tiles */
+    uint32_t fused;              /* 1: the integrator runs inside the force launch (one launch per step) */
+    uint32_t grid_z;             /* j-segments per launch (1 unless the sharded overlap structure) */
+    uint32_t epilogue;           /* 0 partial rows + reduce_integrate launch, 1 fused in the workgroup,
+                                    2 last-arriver ticket (rows summed by the last workgroup of the i-tile) */
+    uint32_t force_launches_per_step;
+    uint32_t reserved;
 } mapn_kernel_stats;
 int mapn_get_kernel_stats(mapn_ctx *ctx, int reset, mapn_kernel_stats *out);
 
 /* Tuning hooks (tests exercise every kernel variant through these; AUTO restores the default).
- * bodies_per_lane in {2,4,8}, waves in {1,2,4,8,16}, sb >= 1 (j-split across workgroups). */
+ * bodies_per_lane in {2,4,8}, waves in {1,2,4,8,16}, sb >= 1 (j-split across workgroups).
+ * fused: 0 = two launches (partial rows + reduce_integrate_kernel), 1 = one launch (integrator in
+ * the workgroup when sb == 1, else by the last-arriver ticket), 2 = ticket form even when sb == 1.
+ * Summation order (what an order-matched checker must reproduce): the 64-body tiles of the j-range
+ * are cut into S = sb * waves chunks (the first tiles % S chunks take one tile more); a chunk is
+ * summed over ascending j into a zero accumulator with fused multiply-adds; the `waves` chunk sums
+ * of a workgroup are added in ascending order, then the sb row sums in ascending order; the mass
+ * multiplies the total. */
 int mapn_set_force_plan(mapn_ctx *ctx, int kernel, uint32_t bodies_per_lane, uint32_t waves,
                         uint32_t sb, int fused);
 /* Step timers: 0 = off, T >= 1 = record the event pair on every T-th step (default 1: every

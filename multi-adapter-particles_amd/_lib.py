@@ -17,6 +17,8 @@ FLAG_USE_GRAPH = 0x1
 INIT_LCG, INIT_SSE, INIT_MT = 0, 1, 2
 FLAG_NO_INIT = 0x2
 FLAG_SHARD_OVERLAP = 0x4
+FLAG_STRICT_CONSUMER = 0x8
+IPC_BLOB_BYTES = 256
 UNIQUE_ID_BYTES = 128
 P2P_BLOB_BYTES = 192
 
@@ -59,6 +61,7 @@ class KernelStats(C.Structure):
         ("kernel_name", C.c_char * 64), ("launches", C.c_uint64), ("avg_seconds", C.c_double),
         ("grid_x", C.c_uint32), ("grid_y", C.c_uint32), ("block_x", C.c_uint32),
         ("bodies_per_lane", C.c_uint32), ("j_splits", C.c_uint32), ("fused", C.c_uint32),
+        ("grid_z", C.c_uint32), ("epilogue", C.c_uint32), ("force_launches_per_step", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -82,6 +85,14 @@ SIGNATURES = {
     "mapn_set_consumer": (C.c_int, [_ctx, C.c_int]),
     "mapn_consumer_signal": (C.c_int, [_ctx, C.c_uint64]),
     "mapn_consumer_signal_event": (C.c_int, [_ctx, C.c_uint64, C.c_void_p]),
+    "mapn_set_timeouts": (C.c_int, [_ctx, C.c_uint32, C.c_uint32]),
+    "mapn_ipc_export": (C.c_int, [_ctx, C.c_void_p]),
+    "mapn_ipc_open": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "mapn_ipc_close": (C.c_int, [C.c_void_p]),
+    "mapn_ipc_latest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "mapn_ipc_positions": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "mapn_ipc_copy_positions_async": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "mapn_ipc_consumer_signal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "mapn_adopt_position_buffers": (C.c_int, [_ctx, C.POINTER(C.c_void_p * 2), C.c_uint32]),
     "mapn_reset_from_async": (C.c_int, [_ctx]),
     "mapn_last_step_seconds": (C.c_float, [_ctx]),

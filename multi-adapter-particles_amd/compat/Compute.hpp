@@ -13,8 +13,10 @@
 //
 // What differs, by necessity:
 //   * the adapter is a HIP device ordinal instead of IDXGIAdapter1*;
-//   * SharedHandles carries device pointers + a hipEvent_t instead of NT HANDLEs
-//     (Compute.h:54-62); the consumer's fence is attached with ConsumerSignal();
+//   * SharedHandles carries device pointers + ONE hipEvent_t (fetched once, re-recorded after
+//     every step) instead of NT HANDLEs (Compute.h:54-62); the consumer's fence is signalled with
+//     ConsumerSignal(); Simulate(n, v) queues its wait on it whether or not it has been signalled
+//     yet (Compute.cpp:1012), unless the context was created with MAPN_FLAG_STRICT_CONSUMER;
 //   * SetAsync takes two device pointers instead of ComPtr<ID3D12Resource>*;
 //   * failures throw mapn::MapnException : std::runtime_error carrying the status code, the
 //     counterpart of HrException (DXSampleHelper.h:29-46).
@@ -95,6 +97,9 @@ public:
         ThrowIfFailed(in_hipEvent ? mapn_consumer_signal_event(m_ctx, in_value, in_hipEvent)
                                   : mapn_consumer_signal(m_ctx, in_value));
     }
+
+    // bounds of the device-side waits in ms (0 = unchanged); D3D12's Queue::Wait has none
+    void SetTimeouts(uint32_t in_p2pMs, uint32_t in_consumerMs) { ThrowIfFailed(mapn_set_timeouts(m_ctx, in_p2pMs, in_consumerMs)); }
 
     uint64_t GetFenceValue() const { return mapn_fence_value(m_ctx); }   // Compute.h:64
 

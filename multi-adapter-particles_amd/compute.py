@@ -111,6 +111,17 @@ class Compute:
         else:
             check(self._lib.mapn_consumer_signal_event(self._ctx, int(value), C.c_void_p(hip_event)))
 
+    def set_timeouts(self, p2p_ms: int = 0, consumer_ms: int = 0):
+        """Bounds of the device-side waits (0 = unchanged): peer-to-peer exchange, queued consumer fence."""
+        check(self._lib.mapn_set_timeouts(self._ctx, int(p2p_ms), int(consumer_ms)))
+
+    def ipc_export(self) -> bytes:
+        """GetSharedHandles for a consumer in ANOTHER process: hipIpc handles of the position heap,
+        the status / fence block and the step-done event (Compute.cpp:944-950)."""
+        buf = C.create_string_buffer(_lib.IPC_BLOB_BYTES)
+        check(self._lib.mapn_ipc_export(self._ctx, C.cast(buf, C.c_void_p)))
+        return buf.raw
+
     def SetAsync(self, buffers, buffer_index: int):
         """Compute.cpp:956-987: compute directly into two caller-owned device float4[N] buffers."""
         arr = (C.c_void_p * 2)(C.c_void_p(int(buffers[0])), C.c_void_p(int(buffers[1])))
@@ -229,8 +240,9 @@ class Compute:
         check(self._lib.mapn_set_external_gather(self._ctx, int(bool(enabled))))
 
     # -- tuning / introspection ----------------------------------------------------------------
-    def set_force_plan(self, kernel: int, bodies_per_lane: int = 4, waves: int = 8, sb: int = 1, fused: bool = True):
-        check(self._lib.mapn_set_force_plan(self._ctx, kernel, bodies_per_lane, waves, sb, int(bool(fused))))
+    def set_force_plan(self, kernel: int, bodies_per_lane: int = 4, waves: int = 8, sb: int = 1, fused=True):
+        """fused: False/0 two launches (rows + reduce_integrate), True/1 one launch, 2 ticket form always."""
+        check(self._lib.mapn_set_force_plan(self._ctx, kernel, bodies_per_lane, waves, sb, int(fused)))
 
     def set_timers(self, interval: int):
         """0 = off, T >= 1 = time every T-th step."""
@@ -244,6 +256,43 @@ class Compute:
     @property
     def compute_stream(self) -> int:
         return int(self._lib.mapn_compute_stream(self._ctx) or 0)
+
+
+class IpcView:
+    """The consumer's side of ``Compute.ipc_export()`` in another process: Render::SetShared +
+    CopySimulationResults (Render.cpp:222-251, 789-831) on HIP IPC handles."""
+
+    def __init__(self, blob: bytes, device: int = 0):
+        self._lib = load_library()
+        self._view = C.c_void_p()
+        buf = C.create_string_buffer(blob, _lib.IPC_BLOB_BYTES)
+        check(self._lib.mapn_ipc_open(C.cast(buf, C.c_void_p), device, C.byref(self._view)))
+
+    def close(self):
+        if getattr(self, "_view", None) and self._view.value:
+            self._lib.mapn_ipc_close(self._view)
+            self._view = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def latest(self):
+        """(fence value signalled by the latest published step, buffer index holding its positions)"""
+        f, i = C.c_uint64(), C.c_uint32()
+        check(self._lib.mapn_ipc_latest(self._view, C.byref(f), C.byref(i)))
+        return f.value, i.value
+
+    def positions_ptr(self, buffer_index: int) -> int:
+        return int(self._lib.mapn_ipc_positions(self._view, buffer_index) or 0)
+
+    def copy_positions_async(self, buffer_index: int, num_copied: int, dst: int, consumer_stream: int = 0):
+        check(self._lib.mapn_ipc_copy_positions_async(self._view, buffer_index, num_copied, C.c_void_p(dst), C.c_void_p(consumer_stream)))
+
+    def consumer_signal(self, value: int, consumer_stream: int = 0):
+        check(self._lib.mapn_ipc_consumer_signal(self._view, int(value), C.c_void_p(consumer_stream)))
 
 
 def device_info(device: int = 0) -> _lib.DeviceInfo:

@@ -50,7 +50,8 @@ constexpr uint64_t kHeapAlign = 64 * 1024; // Compute.cpp:185-194: 64 KiB placem
 struct StepTimer {
     hipEvent_t start = nullptr, force_done = nullptr, stop = nullptr;
     bool pending = false;
-    bool has_force = false;
+    bool has_force = false;      // force_done recorded (a separate reduce launch follows the force launch)
+    bool force_is_step = false;  // the step is ONE force launch: [start, stop] is the kernel's duration
 };
 
 }  // namespace
@@ -72,19 +73,34 @@ struct mapn_ctx {
 
     float4 *partial = nullptr;
     size_t partial_bytes = 0;
+    uint32_t *ticket = nullptr;               // EPI_TICKET arrival counters, one per i-tile, zero between launches
 
     uint32_t buffer_index = 0;                // Compute.cpp:80 m_bufferIndex(0)
     uint64_t fence_value = 0;                 // Compute.cpp:82 m_fenceValue(0)
     uint64_t completed = 0;
     hipEvent_t fence_events[kTimerRing] = {};
     uint64_t fence_event_value[kTimerRing] = {};
-    hipEvent_t step_done = nullptr;           // exported: the fence event of the latest step
-    bool fence_every_step = false;            // set once a consumer can observe step_done
+    hipEvent_t step_done = nullptr;           // the ring event of the latest recorded fence value (internal)
+    hipEvent_t exported_done = nullptr;       // THE exported event: one handle for the context's lifetime,
+                                              // re-recorded after every step while somebody can observe it
+    uint64_t exported_value = 0;              // fence value exported_done was last recorded for
+    bool fence_every_step = false;            // set once a consumer can observe exported_done
 
     // consumer fence (the render adapter's shared fence, Compute.cpp:1012)
     bool consumer_enabled = false;
     uint64_t consumer_value = 0;
     std::vector<std::pair<uint64_t, hipEvent_t>> consumer_events;
+    // the consumer's fence as memory words, for waits queued before the consumer has signalled
+    uint32_t *fence_host_word = nullptr;      // pinned host memory: mapn_consumer_signal()
+    uint32_t *fence_dev_block = nullptr;      // uncached device memory [64]: word 0 = event-ordered / cross-process
+                                              // signals, words 16.. = the status block of mapn_ipc_export
+    uint32_t *async_status = nullptr;         // pinned host words: [0] peer-to-peer wait timed out (peer + 1),
+                                              // [1] consumer-fence wait timed out
+    hipStream_t aux_stream = nullptr;         // event-ordered consumer signals
+    uint64_t deferred_need = 0;               // highest consumer value a queued fence_wait_kernel waits for
+    uint64_t consumer_timeout_ticks = 1000ull * 1000ull * 1000ull;   // 10 s of s_memrealtime (100 MHz)
+    uint64_t p2p_timeout_ticks = 20ull * 1000ull * 1000ull;          // 200 ms
+    bool ipc_exported = false;
 
     // timers (D3D12GpuTimer analogue)
     StepTimer timers[kTimerRing];
@@ -99,6 +115,9 @@ struct mapn_ctx {
     // force plan
     bool plan_forced = false;
     mapn::ForcePlan forced_plan{};
+    int forced_epilogue = 1;                  // mapn_set_force_plan's `fused`: 0 rows, 1 auto, 2 ticket
+    mapn::ForcePlan last_plan{};              // what enqueue_step actually launched last (kernel stats)
+    uint32_t last_i_count = 0, last_launches = 0;
 
     // sharded mode
     mapn::Comm *comm = nullptr;
@@ -110,7 +129,6 @@ struct mapn_ctx {
     // direct peer-to-peer exchange (hipIpc-mapped peer buffers + device flags)
     bool p2p_ready = false;
     uint32_t *p2p_flags = nullptr;            // uncached device memory, [world] publication counters
-    uint32_t *p2p_status = nullptr;           // pinned host word: non-zero = a device-side wait timed out
     void *p2p_peer_heap[mapn::P2P_MAX_RANKS] = {};
     uint32_t *p2p_peer_flags[mapn::P2P_MAX_RANKS] = {};
     uint32_t p2p_step = 0;
@@ -138,9 +156,9 @@ int resolve_timers(mapn_ctx *c, bool block)
         HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
         // D3D12GpuTimer.h:151-153: t = t*(averageOver-1); t = (t + delta)/averageOver
         c->ema_seconds = (c->ema_seconds * (kAverageOver - 1) + ms * 1e-3f) / kAverageOver;
-        if (t.has_force) {
-            float fms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&fms, t.start, t.force_done));
+        if (t.has_force || t.force_is_step) {
+            float fms = ms;
+            if (t.has_force) HIP_TRY(hipEventElapsedTime(&fms, t.start, t.force_done));
             c->force_seconds_sum += fms * 1e-3;
             c->force_launches++;
         }
@@ -151,6 +169,7 @@ int resolve_timers(mapn_ctx *c, bool block)
 
 int update_completed(mapn_ctx *c)
 {
+    if (c->exported_value > c->completed && hipEventQuery(c->exported_done) == hipSuccess) c->completed = c->exported_value;
     for (int k = 0; k < kTimerRing; k++) {
         const uint64_t v = c->fence_event_value[k];
         if (v > c->completed && c->fence_events[k] && hipEventQuery(c->fence_events[k]) == hipSuccess)
@@ -169,11 +188,41 @@ int signal_fence(mapn_ctx *c, uint64_t value)
     return MAPN_OK;
 }
 
+// Device-side waits are bounded; one that gave up leaves a word in pinned host memory.  Every
+// entry point that hands results to the caller checks it, so a timed-out exchange or consumer
+// wait is never a silent MAPN_OK.
+int check_async_errors(mapn_ctx *c)
+{
+    if (!c->async_status) return MAPN_OK;
+    const uint32_t p2p = reinterpret_cast<volatile uint32_t *>(c->async_status)[0];
+    const uint32_t cons = reinterpret_cast<volatile uint32_t *>(c->async_status)[1];
+    if (p2p)
+        return fail(MAPN_ERR_COMM, "peer-to-peer exchange: the wait for rank %u's slice timed out (%.0f ms); "
+                    "this rank's position replica is stale from that step on", p2p - 1u, c->p2p_timeout_ticks / 1e5);
+    if (cons)
+        return fail(MAPN_ERR_STATE, "the queued wait on the consumer's fence timed out (%.0f ms): the consumer never "
+                    "signalled the value Simulate was told to wait for", c->consumer_timeout_ticks / 1e5);
+    return MAPN_OK;
+}
+
 uint32_t active_bodies(int num_active, uint32_t n)
 {
     if (num_active <= 0) return 0;
     const uint64_t groups = ((uint64_t)num_active + kBlock - 1) / kBlock;   // Compute.cpp:1041
     return (uint32_t)std::min<uint64_t>(groups * kBlock, n);
+}
+
+// Where the integrator runs: inside the workgroup when it sees all chunks of its bodies, else by
+// the last workgroup to arrive at the i-tile's ticket (one launch per step either way).
+// MAPN_EPILOGUE=rows selects the two-kernel form (partial rows + reduce_integrate_kernel) for A/B.
+int choose_epilogue(const mapn_ctx *c, const mapn::ForcePlan &p, bool allow_fused)
+{
+    int want = c->plan_forced ? c->forced_epilogue : 1;
+    const char *e = getenv("MAPN_EPILOGUE");
+    if (!c->plan_forced && e && strcmp(e, "rows") == 0) want = 0;
+    if (want == 0) return mapn::EPI_ROWS;
+    if (want == 1 && allow_fused && p.sb == 1 && p.nseg == 1) return mapn::EPI_FUSED;
+    return mapn::EPI_TICKET;
 }
 
 // Plan of the all-pairs launch.  Measured on MI355X (profiles/r01_sweep*.txt): the scalar-cache
@@ -187,7 +236,7 @@ mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_tota
     if (c->plan_forced) {
         p = c->forced_plan;
         p.nseg = nseg;
-        if (!allow_fused || p.sb != 1 || nseg != 1) p.fused = false;
+        p.epi = choose_epilogue(c, p, allow_fused);
         return p;
     }
     p.kind = c->cfg.kernel == MAPN_KERNEL_LDS ? mapn::KERNEL_LDS : mapn::KERNEL_SGPR;
@@ -209,7 +258,7 @@ mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_tota
         p.sb = (uint32_t)((S + p.waves - 1) / p.waves);
         if (p.sb > 8) p.sb = (p.sb + 7) / 8 * 8;          // multiples of 8 rows: XCD-aware remap
     }
-    p.fused = allow_fused && p.sb == 1 && nseg == 1;
+    p.epi = choose_epilogue(c, p, allow_fused);
     return p;
 }
 
@@ -220,7 +269,8 @@ bool env_plan(const char *name, mapn::ForcePlan &p)
     unsigned k = 0, w = 0, sb = 0;
     if (!e || sscanf(e, "%u,%u,%u", &k, &w, &sb) != 3) return false;
     mapn::ForcePlan q = p;
-    q.k = k; q.waves = w; q.sb = sb; q.fused = false;
+    q.k = k; q.waves = w; q.sb = sb;
+    if (q.epi == mapn::EPI_FUSED) q.epi = mapn::EPI_TICKET;
     if (!mapn::force_plan_supported(q)) return false;
     p = q;
     return true;
@@ -269,21 +319,42 @@ int wait_for_consumer(mapn_ctx *c, uint64_t wait_value)
     if (!c->consumer_enabled || wait_value == 0) return MAPN_OK;
     const uint64_t need = wait_value - 1;                  // Compute.cpp:1012
     if (c->consumer_value >= need) return MAPN_OK;
-    // the consumer's work for `need` is already enqueued on its own stream: wait on the device
+    // registered events the consumer has already passed are history
+    c->consumer_events.erase(std::remove_if(c->consumer_events.begin(), c->consumer_events.end(),
+                                            [&](const std::pair<uint64_t, hipEvent_t> &e) { return e.first < need; }),
+                             c->consumer_events.end());
+    // the consumer's work for `need` is already enqueued on its own stream: wait for its event
     hipEvent_t best = nullptr;
     uint64_t best_v = 0;
     for (auto &e : c->consumer_events)
         if (e.first >= need && (!best || e.first < best_v)) { best = e.second; best_v = e.first; }
-    if (!best)
+    if (best) {
+        HIP_TRY(hipStreamWaitEvent(c->compute, best, 0));
+        c->consumer_events.erase(std::remove_if(c->consumer_events.begin(), c->consumer_events.end(),
+                                                [&](const std::pair<uint64_t, hipEvent_t> &e) { return e.first <= best_v; }),
+                                 c->consumer_events.end());
+        c->consumer_value = std::max(c->consumer_value, best_v);
+        return MAPN_OK;
+    }
+    if (c->cfg.flags & MAPN_FLAG_STRICT_CONSUMER)
         return fail(MAPN_ERR_STATE, "simulate(wait_value=%llu): consumer has not signalled %llu "
                     "(last %llu); the step would overwrite a buffer still being read",
                     (unsigned long long)wait_value, (unsigned long long)need,
                     (unsigned long long)c->consumer_value);
-    HIP_TRY(hipStreamWaitEvent(c->compute, best, 0));
-    c->consumer_events.erase(std::remove_if(c->consumer_events.begin(), c->consumer_events.end(),
-                                            [&](const std::pair<uint64_t, hipEvent_t> &e) { return e.first <= best_v; }),
-                             c->consumer_events.end());
-    c->consumer_value = std::max(c->consumer_value, best_v);
+    // Not signalled and nothing registered yet: queue the wait anyway, exactly like
+    // m_commandQueue->Wait(m_sharedRenderFence, v - 1) (Compute.cpp:1012) -- the compute stream
+    // parks in a one-lane kernel until the consumer's fence words reach `need`.
+    HIP_TRY(mapn::launch_fence_wait(c->fence_host_word, c->fence_dev_block, (uint32_t)need, c->consumer_timeout_ticks,
+                                    c->async_status + 1, c->compute));
+    c->deferred_need = std::max(c->deferred_need, need);
+    return MAPN_OK;
+}
+
+// exported context: tell a consumer in another process which buffer holds the results of the step
+// that signals `fence_value` (ordered on the compute stream, before the exported event)
+int publish_ipc_status(mapn_ctx *c, uint64_t fence_value, uint32_t latest_index)
+{
+    HIP_TRY(mapn::launch_status_publish(c->fence_dev_block, (uint32_t)fence_value, latest_index, c->compute));
     return MAPN_OK;
 }
 
@@ -311,31 +382,38 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
         mapn::ForcePlan plan = choose_plan(c, i_count, c->n, 1, true);
         const uint32_t S = plan.sb * plan.waves;
         fill_segment(a, 0, 0, c->n, 0, S);
-        if (!plan.fused) {
+        if (plan.epi != mapn::EPI_FUSED) {
             a.partial_stride = (i_count + 63u) & ~63u;
             if (int rc = ensure_partial(c, plan.sb, a.partial_stride)) return rc;   // one row per block row
             a.partial = c->partial;
+            a.ticket = c->ticket;
+            a.ticket_total = plan.sb;
         }
         HIP_TRY(mapn::launch_force(plan, a, c->compute));
-        if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
-        if (!plan.fused) HIP_TRY(mapn::launch_reduce_integrate(a, plan.sb, c->compute));
+        if (plan.epi == mapn::EPI_ROWS) {
+            if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
+            HIP_TRY(mapn::launch_reduce_integrate(a, plan.sb, c->compute));
+        } else if (timer) {
+            timer->force_is_step = true;                   // one launch: [start, stop] brackets the force kernel
+        }
+        c->last_plan = plan; c->last_i_count = i_count; c->last_launches = 1;
     } else if (i_count > 0) {
         // sharded with MAPN_FLAG_SHARD_OVERLAP: own slice first (needs only data this rank wrote),
         // then the remote segments once the all-gather that filled the read buffer has finished.
-        // Measured on MI355X at the 8-way shard size of the 65 536-body job (8192 x 65536 pairs,
-        // profiles/r01_shard_structure.txt): 0.154 ms per step against 0.126 ms for the single
-        // launch above -- the split costs more (two under-filled launches, one more boundary,
-        // more partial rows) than the ~20 us of all-gather it can hide, so it is opt-in.
+        // Two launches share the i-tiles' tickets: the last arriver of the second one integrates.
         const uint32_t own_first = c->first, own_count = c->count;
         mapn::ForcePlan own = choose_plan(c, i_count, own_count, 1, false);
         mapn::ForcePlan rem = choose_plan(c, i_count, c->n - own_count, 2, false);
         env_plan("MAPN_OWN_PLAN", own);
         env_plan("MAPN_REM_PLAN", rem);
+        rem.epi = own.epi;                                 // both row-producing launches use one hand-off form
         const uint32_t S_own = own.sb * own.waves, S_rem = rem.sb * rem.waves;
         const uint32_t slots = own.sb + 2 * rem.sb;        // partial rows: one per block row per segment
         a.partial_stride = (i_count + 63u) & ~63u;
         if (int rc = ensure_partial(c, slots, a.partial_stride)) return rc;
         a.partial = c->partial;
+        a.ticket = c->ticket;
+        a.ticket_total = slots;
         fill_segment(a, 0, own_first, own_count, 0, S_own);
         HIP_TRY(mapn::launch_force(own, a, c->compute));
         if (c->gather_recorded[r]) HIP_TRY(hipStreamWaitEvent(c->compute, c->gather_done[r], 0));
@@ -343,8 +421,13 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
         fill_segment(b, 0, 0, own_first, own.sb, S_rem);
         fill_segment(b, 1, own_first + own_count, c->n - own_first - own_count, own.sb + rem.sb, S_rem);
         HIP_TRY(mapn::launch_force(rem, b, c->compute));
-        if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
-        HIP_TRY(mapn::launch_reduce_integrate(a, slots, c->compute));
+        if (own.epi == mapn::EPI_ROWS) {
+            if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
+            HIP_TRY(mapn::launch_reduce_integrate(a, slots, c->compute));
+        } else if (timer) {
+            timer->force_is_step = true;
+        }
+        c->last_plan = rem; c->last_i_count = i_count; c->last_launches = 2;
     }
     return MAPN_OK;
 }
@@ -369,7 +452,7 @@ int enqueue_step_graph(mapn_ctx *c, uint32_t active)
         const uint32_t lo = c->first, hi = std::min(c->first + c->count, active);
         if (hi > lo && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS) {
             mapn::ForcePlan plan = choose_plan(c, hi - lo, c->n, 1, true);
-            if (!plan.fused)
+            if (plan.epi != mapn::EPI_FUSED)
                 if (int rc = ensure_partial(c, plan.sb, ((hi - lo) + 63u) & ~63u)) return rc;
         }
         hipGraph_t graph = nullptr;
@@ -398,12 +481,12 @@ int enqueue_p2p(mapn_ctx *c)
         a.peer_flags[q] = c->p2p_peer_flags[q];
     }
     a.my_flags = c->p2p_flags;
-    a.status = c->p2p_status;
+    a.status = c->async_status;
     a.rank = (uint32_t)c->cfg.rank;
     a.world = (uint32_t)c->cfg.world_size;
     a.count = c->count;
     a.step = ++c->p2p_step;
-    a.timeout_ticks = 300ull * 1000ull * 1000ull;          // 3 s of s_memrealtime (100 MHz)
+    a.timeout_ticks = c->p2p_timeout_ticks;                // s_memrealtime ticks (100 MHz); mapn_set_timeouts
     HIP_TRY(mapn::launch_p2p_gather(a, c->compute));
     return MAPN_OK;
 }
@@ -447,12 +530,16 @@ int alloc_state(mapn_ctx *c)
         HIP_TRY(hipMalloc(&c->vel[b], (size_t)c->n * 12));
         HIP_TRY(hipMemset(c->vel[b], 0, (size_t)c->n * 12));
     }
+    const size_t tiles = ((size_t)c->n + 127) / 128 + 1;   // i-tiles of the smallest tile (2 bodies per lane)
+    HIP_TRY(hipMalloc(&c->ticket, tiles * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(c->ticket, 0, tiles * sizeof(uint32_t)));
     return MAPN_OK;
 }
 
 int create_common(const mapn_config *cfg, mapn_ctx **out)
 {
     if (!cfg || !out) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
     if (cfg->struct_size != sizeof(mapn_config))
         return fail(MAPN_ERR_INVALID_ARGUMENT, "mapn_config.struct_size %u != %zu", cfg->struct_size, sizeof(mapn_config));
     if (cfg->num_particles == 0) return fail(MAPN_ERR_INVALID_ARGUMENT, "num_particles must be > 0");
@@ -497,6 +584,15 @@ int create_common(const mapn_config *cfg, mapn_ctx **out)
         HIP_TRY(hipEventCreate(&c->timers[k].stop));
     }
     for (int b = 0; b < 2; b++) HIP_TRY(hipEventCreateWithFlags(&c->gather_done[b], hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    // interprocess-capable: mapn_ipc_export hands this same event to a consumer in another process
+    HIP_TRY(hipEventCreateWithFlags(&c->exported_done, hipEventDisableTiming | hipEventInterprocess));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->fence_host_word), 64, hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->async_status), 64, hipHostMallocMapped));
+    memset(c->fence_host_word, 0, 64);
+    memset(c->async_status, 0, 64);
+    HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void **>(&c->fence_dev_block), 256, hipDeviceMallocUncached));
+    HIP_TRY(hipMemset(c->fence_dev_block, 0, 256));
     // Compute.cpp:434-436: fence created with value 0, m_fenceValue++ -> 1
     c->fence_value = 1;
     if (int rc = alloc_state(c)) return rc;
@@ -538,9 +634,11 @@ int mapn_config_default(mapn_config *cfg)
 
 int mapn_create(const mapn_config *cfg, mapn_ctx **out_ctx)
 {
+    if (!out_ctx) return fail(MAPN_ERR_INVALID_ARGUMENT, "mapn_create: out_ctx is null");
+    *out_ctx = nullptr;
     mapn_ctx *c = nullptr;
     int rc = create_common(cfg, &c);
-    if (rc) { if (c) mapn_destroy(c); if (out_ctx) *out_ctx = nullptr; return rc; }
+    if (rc) { std::string keep = g_last_error; if (c) mapn_destroy(c); g_last_error = keep; return rc; }
     if (!(cfg->flags & MAPN_FLAG_NO_INIT)) {
         // Compute.cpp:820-923 InitializeParticles: generate, upload to both buffers, WaitForGpu
         std::vector<float> pos((size_t)c->n * 4), vel((size_t)c->n * 3);
@@ -557,6 +655,8 @@ int mapn_create(const mapn_config *cfg, mapn_ctx **out_ctx)
 
 int mapn_create_from(const mapn_config *cfg, mapn_ctx *old, mapn_ctx **out_ctx)
 {
+    if (!out_ctx) return fail(MAPN_ERR_INVALID_ARGUMENT, "mapn_create_from: out_ctx is null");
+    *out_ctx = nullptr;
     if (!old) return fail(MAPN_ERR_INVALID_ARGUMENT, "null source context");
     if (!cfg || cfg->num_particles != old->n)
         return fail(MAPN_ERR_INVALID_ARGUMENT, "create_from: num_particles must match the source context");
@@ -566,7 +666,7 @@ int mapn_create_from(const mapn_config *cfg, mapn_ctx *old, mapn_ctx **out_ctx)
     if (rc) return rc;
     mapn_ctx *c = nullptr;
     rc = create_common(cfg, &c);
-    if (rc) { if (c) mapn_destroy(c); if (out_ctx) *out_ctx = nullptr; return rc; }
+    if (rc) { std::string keep = g_last_error; if (c) mapn_destroy(c); g_last_error = keep; return rc; }
     // Compute.cpp:303-410 CopyState: both position buffers, both velocity buffers, buffer index
     for (int b = 0; b < 2 && !rc; b++) {
         if (hipMemcpyPeer(c->pos[b], c->device, old->pos[b], old->device, (size_t)c->n * 16) != hipSuccess ||
@@ -595,7 +695,11 @@ int mapn_destroy(mapn_ctx *c)
         if (c->p2p_peer_flags[q]) (void)hipIpcCloseMemHandle(c->p2p_peer_flags[q]);
     }
     if (c->p2p_flags) (void)hipFree(c->p2p_flags);
-    if (c->p2p_status) (void)hipHostFree(c->p2p_status);
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->exported_done) (void)hipEventDestroy(c->exported_done);
+    if (c->fence_host_word) (void)hipHostFree(c->fence_host_word);
+    if (c->async_status) (void)hipHostFree(c->async_status);
+    if (c->fence_dev_block) (void)hipFree(c->fence_dev_block);
     for (int b = 0; b < 2; b++) {
         if (c->graph_exec[b]) (void)hipGraphExecDestroy(c->graph_exec[b]);
         if (c->vel[b]) (void)hipFree(c->vel[b]);
@@ -603,6 +707,7 @@ int mapn_destroy(mapn_ctx *c)
     }
     if (c->pos_heap) (void)hipFree(c->pos_heap);
     if (c->partial) (void)hipFree(c->partial);
+    if (c->ticket) (void)hipFree(c->ticket);
     for (int k = 0; k < kTimerRing; k++) {
         if (c->fence_events[k]) (void)hipEventDestroy(c->fence_events[k]);
         if (c->timers[k].start) (void)hipEventDestroy(c->timers[k].start);
@@ -622,6 +727,7 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
     if (c->cfg.world_size > 1 && !c->comm && !c->external_gather && !(c->p2p_ready && c->gather_algo == 2))
         return fail(MAPN_ERR_STATE, "sharded context (world_size %d): call mapn_comm_init or "
                     "mapn_set_external_gather before simulate", c->cfg.world_size);
+    if (int rc = check_async_errors(c)) return rc;                     // a device-side wait of an earlier step gave up
     if (int rc = wait_for_consumer(c, wait_value)) return rc;          // Compute.cpp:1012
     const uint32_t active = active_bodies(num_active, c->n);
 
@@ -630,6 +736,7 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
         timer = &c->timers[c->timer_head];
         if (timer->pending) { if (int rc = resolve_timers(c, true)) return rc; }
         timer->has_force = false;
+        timer->force_is_step = false;
     }
     const bool use_graph = (c->cfg.flags & MAPN_FLAG_USE_GRAPH) && !c->comm && !c->p2p_ready && !timer && active > 0;
     if (int rc = use_graph ? enqueue_step_graph(c, active) : enqueue_step(c, active, timer)) return rc;
@@ -642,12 +749,17 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
     const bool exchanging = c->comm != nullptr || (c->p2p_ready && c->gather_algo == 2);
     const bool gather_first = exchanging && (!(c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP) || c->gather_algo == 2);
     if (gather_first) { if (int rc = enqueue_gather(c)) return rc; }   // same stream: the fence then covers the gather
-    // The fence value always advances; the hipEvent behind it (a few us of queue time each) is
-    // recorded on every step only while somebody can observe it -- an attached consumer, exported
-    // handles, the overlap structure -- and otherwise on every 16th step, which only makes
-    // mapn_completed_value() conservative.  mapn_wait_idle() always records.
-    const bool record = c->fence_every_step || c->consumer_enabled || (exchanging && !gather_first) ||
-                        (c->fence_value % 16) == 0;
+    // The fence value always advances.  While somebody can observe completion (an attached consumer,
+    // exported handles) the ONE exported event is re-recorded after every step; the ring event behind
+    // mapn_completed_value() (a few us of queue time each) is recorded when the overlap structure
+    // needs it and otherwise on every 16th step, which only makes mapn_completed_value()
+    // conservative.  mapn_wait_idle() always records.
+    if (c->fence_every_step || c->consumer_enabled) {
+        if (c->ipc_exported) { if (int rc = publish_ipc_status(c, c->fence_value, c->buffer_index)) return rc; }
+        HIP_TRY(hipEventRecord(c->exported_done, c->compute));
+        c->exported_value = c->fence_value;
+    }
+    const bool record = (exchanging && !gather_first) || (c->fence_value % 16) == 0;
     if (record) { if (int rc = signal_fence(c, c->fence_value)) return rc; }
     if (exchanging && !gather_first) { if (int rc = enqueue_gather(c)) return rc; }   // overlap: behind the fence event
     c->fence_value++;
@@ -676,24 +788,31 @@ int mapn_wait_idle(mapn_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->compute));
     HIP_TRY(hipStreamSynchronize(c->comm_stream));
     c->completed = std::max(c->completed, v);
-    return resolve_timers(c, true);
+    if (int rc = resolve_timers(c, true)) return rc;
+    return check_async_errors(c);
 }
 
 uint32_t mapn_buffer_index(const mapn_ctx *c) { return c ? c->buffer_index : 0; }
 uint32_t mapn_num_particles(const mapn_ctx *c) { return c ? c->n : 0; }
 
+int observe_steps(mapn_ctx *c)
+{
+    if (c->fence_every_step) return MAPN_OK;
+    // from now on every step re-records the exported event; make it cover everything enqueued so far
+    c->fence_every_step = true;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->exported_done, c->compute));
+    c->exported_value = c->fence_value - 1;
+    return MAPN_OK;
+}
+
 int mapn_get_shared_handles(mapn_ctx *c, mapn_shared_handles *out)
 {
     if (!c || !out) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
-    if (!c->fence_every_step) {
-        // from now on every step records its completion event; make the exported one current
-        c->fence_every_step = true;
-        HIP_TRY(hipSetDevice(c->device));
-        if (int rc = signal_fence(c, c->fence_value - 1)) return rc;   // covers everything enqueued so far
-    }
+    if (int rc = observe_steps(c)) return rc;
     out->positions[0] = c->pos[0];
     out->positions[1] = c->pos[1];
-    out->step_done_event = c->step_done;
+    out->step_done_event = c->exported_done;                           // one handle, valid until mapn_destroy
     out->aligned_data_size = c->aligned_data_size;
     out->buffer_index = c->buffer_index;                               // Compute.cpp:948
     out->reserved = 0;
@@ -711,6 +830,8 @@ int mapn_consumer_signal(mapn_ctx *c, uint64_t value)
 {
     if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
     c->consumer_value = std::max(c->consumer_value, value);
+    // also where a wait that Simulate has ALREADY queued on the device can see it
+    __atomic_store_n(c->fence_host_word, (uint32_t)c->consumer_value, __ATOMIC_RELEASE);
     return MAPN_OK;
 }
 
@@ -718,6 +839,20 @@ int mapn_consumer_signal_event(mapn_ctx *c, uint64_t value, void *hip_event)
 {
     if (!c || !hip_event) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
     c->consumer_events.emplace_back(value, static_cast<hipEvent_t>(hip_event));
+    if (c->deferred_need > c->consumer_value) {
+        // a Simulate is already parked on the device waiting for this value: release it when the event fires
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamWaitEvent(c->aux_stream, static_cast<hipEvent_t>(hip_event), 0));
+        HIP_TRY(mapn::launch_fence_signal(c->fence_dev_block, (uint32_t)value, c->aux_stream));
+    }
+    return MAPN_OK;
+}
+
+int mapn_set_timeouts(mapn_ctx *c, uint32_t p2p_ms, uint32_t consumer_ms)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    if (p2p_ms) c->p2p_timeout_ticks = (uint64_t)p2p_ms * 100000ull;         // s_memrealtime runs at 100 MHz
+    if (consumer_ms) c->consumer_timeout_ticks = (uint64_t)consumer_ms * 100000ull;
     return MAPN_OK;
 }
 
@@ -725,7 +860,10 @@ int mapn_adopt_position_buffers(mapn_ctx *c, void *buffers[2], uint32_t buffer_i
 {
     if (!c || !buffers || !buffers[0] || !buffers[1] || buffer_index > 1)
         return fail(MAPN_ERR_INVALID_ARGUMENT, "adopt_position_buffers: bad argument");
-    if (c->comm) return fail(MAPN_ERR_STATE, "adopt_position_buffers is not available in sharded mode");
+    // sharded (any transport): peers pull this rank's slice from the context's OWN heap and the
+    // exchange writes into pos[], so computing into foreign buffers would freeze every replica
+    if (c->cfg.world_size > 1 || c->comm || c->p2p_ready || c->external_gather)
+        return fail(MAPN_ERR_STATE, "adopt_position_buffers is not available in sharded mode (world_size %d)", c->cfg.world_size);
     if (int rc = mapn_wait_idle(c)) return rc;
     // Compute.cpp:956-987 SetAsync: take the consumer's two buffers; next write = 1 - its index
     c->pos[0] = static_cast<float4 *>(buffers[0]);
@@ -785,6 +923,7 @@ int mapn_download_buffer(mapn_ctx *c, uint32_t index, float *pos4, float *vel3)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->compute));
     HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    if (int rc = check_async_errors(c)) return rc;
     if (pos4) HIP_TRY(hipMemcpy(pos4, c->pos[index], (size_t)c->n * 16, hipMemcpyDeviceToHost));
     if (vel3) HIP_TRY(hipMemcpy(vel3, c->vel[index], (size_t)c->n * 12, hipMemcpyDeviceToHost));
     return MAPN_OK;
@@ -801,13 +940,10 @@ int mapn_copy_positions_async(mapn_ctx *c, uint32_t num_copied, void *dst, void 
     if (!c || !dst) return fail(MAPN_ERR_INVALID_ARGUMENT, "copy_positions_async: null argument");
     if (num_copied > c->n) num_copied = c->n;
     HIP_TRY(hipSetDevice(c->device));
-    if (!c->fence_every_step) {
-        c->fence_every_step = true;
-        if (int rc = signal_fence(c, c->fence_value - 1)) return rc;   // covers everything enqueued so far
-    }
+    if (int rc = observe_steps(c)) return rc;
     hipStream_t st = static_cast<hipStream_t>(consumer_stream);
     // Render.cpp:796,814: copyQueue.Wait(computeFence, v); CopyBufferRegion(dst, shared[1 - idx], nCopy * 16)
-    if (c->step_done) HIP_TRY(hipStreamWaitEvent(st, c->step_done, 0));
+    HIP_TRY(hipStreamWaitEvent(st, c->exported_done, 0));
     if (num_copied)
         HIP_TRY(hipMemcpyAsync(dst, c->pos[1 - c->buffer_index], (size_t)num_copied * 16, hipMemcpyDefault, st));
     return MAPN_OK;
@@ -884,6 +1020,120 @@ int mapn_get_cbuffer(const mapn_ctx *c, uint32_t out_param[4], float out_paramf[
     return MAPN_OK;
 }
 
+// ---- consumer in another process (Render::SetShared / CopySimulationResults across a process boundary) ----
+
+namespace {
+struct IpcBlob {
+    char magic[8];
+    uint32_t n, device;
+    uint64_t aligned_data_size;
+    hipIpcMemHandle_t heap, block;
+    hipIpcEventHandle_t done;
+};
+static_assert(sizeof(IpcBlob) <= MAPN_IPC_BLOB_BYTES, "MAPN_IPC_BLOB_BYTES too small");
+}  // namespace
+
+struct mapn_ipc_view {
+    int device = 0;
+    uint32_t n = 0;
+    uint64_t aligned_data_size = 0;
+    void *heap = nullptr;
+    uint32_t *block = nullptr;
+    hipEvent_t done = nullptr;
+};
+
+int mapn_ipc_export(mapn_ctx *c, void *out_blob)
+{
+    if (!c || !out_blob) return fail(MAPN_ERR_INVALID_ARGUMENT, "ipc_export: null argument");
+    if (c->adopted) return fail(MAPN_ERR_STATE, "ipc_export: context computes into adopted buffers it does not own");
+    HIP_TRY(hipSetDevice(c->device));
+    IpcBlob b{};
+    memcpy(b.magic, "MAPNIPC1", 8);
+    b.n = c->n; b.device = (uint32_t)c->device; b.aligned_data_size = c->aligned_data_size;
+    HIP_TRY(hipIpcGetMemHandle(&b.heap, c->pos_heap));
+    HIP_TRY(hipIpcGetMemHandle(&b.block, c->fence_dev_block));
+    HIP_TRY(hipIpcGetEventHandle(&b.done, c->exported_done));
+    c->ipc_exported = true;
+    c->consumer_enabled = true;                            // the importer's fence is attached (GetSharedHandles(renderFence))
+    if (int rc = observe_steps(c)) return rc;
+    if (int rc = publish_ipc_status(c, c->fence_value - 1, 1 - c->buffer_index)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->compute));
+    memset(out_blob, 0, MAPN_IPC_BLOB_BYTES);
+    memcpy(out_blob, &b, sizeof b);
+    return MAPN_OK;
+}
+
+int mapn_ipc_open(const void *blob, int device, mapn_ipc_view **out_view)
+{
+    if (!blob || !out_view) return fail(MAPN_ERR_INVALID_ARGUMENT, "ipc_open: null argument");
+    *out_view = nullptr;
+    IpcBlob b;
+    memcpy(&b, blob, sizeof b);
+    if (memcmp(b.magic, "MAPNIPC1", 8) != 0) return fail(MAPN_ERR_INVALID_ARGUMENT, "ipc_open: not a mapn ipc blob");
+    HIP_TRY(hipSetDevice(device));
+    mapn_ipc_view *v = new mapn_ipc_view();
+    v->device = device; v->n = b.n; v->aligned_data_size = b.aligned_data_size;
+    hipError_t e = hipIpcOpenMemHandle(&v->heap, b.heap, hipIpcMemLazyEnablePeerAccess);
+    if (e == hipSuccess) e = hipIpcOpenMemHandle(reinterpret_cast<void **>(&v->block), b.block, hipIpcMemLazyEnablePeerAccess);
+    if (e == hipSuccess) e = hipIpcOpenEventHandle(&v->done, b.done);
+    if (e != hipSuccess) {
+        std::string msg = hipGetErrorString(e);
+        mapn_ipc_close(v);
+        return fail(MAPN_ERR_HIP, "ipc_open: %s", msg.c_str());
+    }
+    *out_view = v;
+    return MAPN_OK;
+}
+
+int mapn_ipc_close(mapn_ipc_view *v)
+{
+    if (!v) return MAPN_OK;
+    (void)hipSetDevice(v->device);
+    if (v->done) (void)hipEventDestroy(v->done);
+    if (v->block) (void)hipIpcCloseMemHandle(v->block);
+    if (v->heap) (void)hipIpcCloseMemHandle(v->heap);
+    delete v;
+    return MAPN_OK;
+}
+
+int mapn_ipc_latest(mapn_ipc_view *v, uint64_t *fence_value, uint32_t *buffer_index)
+{
+    if (!v) return fail(MAPN_ERR_INVALID_ARGUMENT, "null view");
+    HIP_TRY(hipSetDevice(v->device));
+    uint32_t w[2] = {0, 0};
+    HIP_TRY(hipMemcpy(w, v->block + 16, sizeof w, hipMemcpyDeviceToHost));
+    if (fence_value) *fence_value = w[0];
+    if (buffer_index) *buffer_index = w[1];
+    return MAPN_OK;
+}
+
+void *mapn_ipc_positions(mapn_ipc_view *v, uint32_t buffer_index)
+{
+    if (!v || buffer_index > 1) return nullptr;
+    return static_cast<char *>(v->heap) + (size_t)buffer_index * v->aligned_data_size;
+}
+
+int mapn_ipc_copy_positions_async(mapn_ipc_view *v, uint32_t buffer_index, uint32_t num_copied, void *dst, void *consumer_stream)
+{
+    if (!v || !dst || buffer_index > 1) return fail(MAPN_ERR_INVALID_ARGUMENT, "ipc_copy_positions_async: bad argument");
+    if (num_copied > v->n) num_copied = v->n;
+    HIP_TRY(hipSetDevice(v->device));
+    hipStream_t st = static_cast<hipStream_t>(consumer_stream);
+    HIP_TRY(hipStreamWaitEvent(st, v->done, 0));           // Render.cpp:796 copyQueue.Wait(computeFence, v)
+    if (num_copied)
+        HIP_TRY(hipMemcpyAsync(dst, mapn_ipc_positions(v, buffer_index), (size_t)num_copied * 16, hipMemcpyDefault, st));
+    return MAPN_OK;
+}
+
+int mapn_ipc_consumer_signal(mapn_ipc_view *v, uint64_t value, void *consumer_stream)
+{
+    if (!v) return fail(MAPN_ERR_INVALID_ARGUMENT, "null view");
+    HIP_TRY(hipSetDevice(v->device));
+    // Render.cpp:826 copyQueue.Signal(copyFence, value): ordered behind the consumer's copies
+    HIP_TRY(mapn::launch_fence_signal(v->block, (uint32_t)value, static_cast<hipStream_t>(consumer_stream)));
+    return MAPN_OK;
+}
+
 // ---- sharded mode ------------------------------------------------------------------------------
 
 int mapn_comm_get_unique_id(void *out_id128)
@@ -947,8 +1197,6 @@ int mapn_p2p_export(mapn_ctx *c, void *out_blob)
         // GPU's polling loads meet in memory, never in a cache
         HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void **>(&c->p2p_flags), 256, hipDeviceMallocUncached));
         HIP_TRY(hipMemset(c->p2p_flags, 0, 256));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->p2p_status), 64, hipHostMallocMapped));
-        *c->p2p_status = 0;
         HIP_TRY(hipDeviceSynchronize());
     }
     P2PBlob b{};
@@ -990,8 +1238,8 @@ int mapn_p2p_import(mapn_ctx *c, const void *blobs, int count)
 int mapn_p2p_status(mapn_ctx *c)
 {
     if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
-    if (!c->p2p_status) return 0;
-    return (int)*reinterpret_cast<volatile uint32_t *>(c->p2p_status);
+    if (!c->async_status) return 0;
+    return (int)reinterpret_cast<volatile uint32_t *>(c->async_status)[0];
 }
 
 int mapn_set_external_gather(mapn_ctx *c, int enabled)
@@ -1042,10 +1290,13 @@ int mapn_set_force_plan(mapn_ctx *c, int kernel, uint32_t bodies_per_lane, uint3
     if (kernel == MAPN_KERNEL_AUTO) { c->plan_forced = false; drop_graphs(c); return MAPN_OK; }
     mapn::ForcePlan p{};
     p.kind = kernel == MAPN_KERNEL_SCALAR ? mapn::KERNEL_SGPR : mapn::KERNEL_LDS;
-    p.k = bodies_per_lane; p.waves = waves; p.sb = sb; p.nseg = 1; p.fused = fused != 0 && sb == 1;
+    if (fused < 0 || fused > 2) return fail(MAPN_ERR_INVALID_ARGUMENT, "set_force_plan: fused must be 0 (two kernels), 1 (one launch) or 2 (ticket form even when one workgroup sees all chunks)");
+    p.k = bodies_per_lane; p.waves = waves; p.sb = sb; p.nseg = 1;
+    p.epi = fused == 0 ? mapn::EPI_ROWS : (fused == 1 && sb == 1 ? mapn::EPI_FUSED : mapn::EPI_TICKET);
     if (!mapn::force_plan_supported(p))
         return fail(MAPN_ERR_INVALID_ARGUMENT, "unsupported force plan kernel=%d k=%u waves=%u sb=%u", kernel, bodies_per_lane, waves, sb);
     c->forced_plan = p;
+    c->forced_epilogue = fused;
     c->plan_forced = true;
     drop_graphs(c);
     return MAPN_OK;
@@ -1067,17 +1318,23 @@ int mapn_get_kernel_stats(mapn_ctx *c, int reset, mapn_kernel_stats *out)
     HIP_TRY(hipSetDevice(c->device));
     if (int rc = resolve_timers(c, true)) return rc;
     memset(out, 0, sizeof *out);
-    const uint32_t lo = c->first, hi = c->first + c->count;
-    mapn::ForcePlan p = choose_plan(c, hi - lo, c->n, 1, c->comm == nullptr);
+    // the plan enqueue_step launched last (sharded overlap: the remote-segments launch), or, before
+    // any step, the plan the next full step would use
+    mapn::ForcePlan p = c->last_plan;
+    uint32_t i_count = c->last_i_count;
+    if (c->last_launches == 0) { i_count = c->count; p = choose_plan(c, i_count, c->n, 1, true); }
     snprintf(out->kernel_name, sizeof out->kernel_name, "%s", mapn::force_kernel_name(p));
     out->launches = c->force_launches;
     out->avg_seconds = c->force_launches ? c->force_seconds_sum / (double)c->force_launches : 0.0;
-    out->grid_x = (hi - lo + 64 * p.k - 1) / (64 * p.k);
+    out->grid_x = (i_count + 64 * p.k - 1) / (64 * p.k);
     out->grid_y = p.sb;
+    out->grid_z = p.nseg;
     out->block_x = 64 * p.waves;
     out->bodies_per_lane = p.k;
     out->j_splits = p.sb * p.waves;
-    out->fused = p.fused ? 1u : 0u;
+    out->fused = p.epi != mapn::EPI_ROWS ? 1u : 0u;
+    out->epilogue = (uint32_t)p.epi;
+    out->force_launches_per_step = c->last_launches ? c->last_launches : 1u;
     if (reset) { c->force_launches = 0; c->force_seconds_sum = 0.0; }
     return MAPN_OK;
 }

@@ -8,6 +8,8 @@ namespace mapn {
 
 enum { KERNEL_LDS = 1, KERNEL_SGPR = 2, KERNEL_MFMA = 3 };
 enum { MAX_SEGMENTS = 3 };
+// where the kick-drift integrator runs (see finish<> in mapn_kernels.hip)
+enum { EPI_ROWS = 0, EPI_FUSED = 1, EPI_TICKET = 2 };
 
 // One launch's view of the state.  Passed by value (kernarg segment, read through s_load).
 struct StepArgs {
@@ -17,6 +19,8 @@ struct StepArgs {
     float        *vel_new;    // (newVelocity, u3)
     float4       *partial;    // [slots][partial_stride] chunk sums of the non-fused path
     uint32_t      partial_stride;
+    uint32_t     *ticket;     // EPI_TICKET: one arrival counter per i-tile, zero between launches
+    uint32_t      ticket_total;             // arrivals that complete an i-tile = partial rows of the step
     uint32_t      i_first;    // bodies [i_first, i_first + i_count) advance in this launch
     uint32_t      i_count;
     uint32_t      seg_first[MAX_SEGMENTS];  // j-segments of pos_old this launch sums over
@@ -35,7 +39,7 @@ struct ForcePlan {
     uint32_t waves;    // waves per workgroup (j-split inside the workgroup)
     uint32_t sb;       // j-split across workgroups (gridDim.y)
     uint32_t nseg;     // gridDim.z
-    bool     fused;    // integrator fused (requires sb == 1, nseg == 1)
+    int      epi;      // EPI_*: EPI_FUSED requires sb == 1 and nseg == 1
 };
 
 bool force_plan_supported(const ForcePlan &plan);
@@ -57,6 +61,12 @@ struct P2PArgs {
     uint64_t      timeout_ticks;            // s_memrealtime ticks (100 MHz) before a wait gives up
 };
 hipError_t launch_p2p_gather(const P2PArgs &a, hipStream_t st);
+
+// the consumer's fence as memory words: a queued GPU-side wait / an event-ordered signal
+hipError_t launch_fence_wait(const uint32_t *host_word, const uint32_t *dev_word, uint32_t need, uint64_t timeout_ticks,
+                             uint32_t *status, hipStream_t st);
+hipError_t launch_fence_signal(uint32_t *dev_word, uint32_t value, hipStream_t st);
+hipError_t launch_status_publish(uint32_t *block, uint32_t fence_value, uint32_t latest_index, hipStream_t st);
 const char *force_kernel_name(const ForcePlan &plan);
 
 }  // namespace mapn

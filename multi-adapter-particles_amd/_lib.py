@@ -91,7 +91,7 @@ SIGNATURES = {
     "mapn_ipc_close": (C.c_int, [C.c_void_p]),
     "mapn_ipc_latest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "mapn_ipc_positions": (C.c_void_p, [C.c_void_p, C.c_uint32]),
-    "mapn_ipc_copy_positions_async": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "mapn_ipc_copy_positions_async": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
     "mapn_ipc_consumer_signal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "mapn_adopt_position_buffers": (C.c_int, [_ctx, C.POINTER(C.c_void_p * 2), C.c_uint32]),
     "mapn_reset_from_async": (C.c_int, [_ctx]),

@@ -288,8 +288,10 @@ class IpcView:
     def positions_ptr(self, buffer_index: int) -> int:
         return int(self._lib.mapn_ipc_positions(self._view, buffer_index) or 0)
 
-    def copy_positions_async(self, buffer_index: int, num_copied: int, dst: int, consumer_stream: int = 0):
-        check(self._lib.mapn_ipc_copy_positions_async(self._view, buffer_index, num_copied, C.c_void_p(dst), C.c_void_p(consumer_stream)))
+    def copy_positions_async(self, buffer_index: int, num_copied: int, dst: int, wait_fence_value: int = 0, consumer_stream: int = 0):
+        """copyQueue.Wait(computeFence, wait_fence_value); CopyBufferRegion(...) (Render.cpp:796,814)"""
+        check(self._lib.mapn_ipc_copy_positions_async(self._view, buffer_index, num_copied, C.c_void_p(dst),
+                                                      int(wait_fence_value), C.c_void_p(consumer_stream)))
 
     def consumer_signal(self, value: int, consumer_stream: int = 0):
         check(self._lib.mapn_ipc_consumer_signal(self._view, int(value), C.c_void_p(consumer_stream)))

@@ -585,8 +585,7 @@ int create_common(const mapn_config *cfg, mapn_ctx **out)
     }
     for (int b = 0; b < 2; b++) HIP_TRY(hipEventCreateWithFlags(&c->gather_done[b], hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-    // interprocess-capable: mapn_ipc_export hands this same event to a consumer in another process
-    HIP_TRY(hipEventCreateWithFlags(&c->exported_done, hipEventDisableTiming | hipEventInterprocess));
+    HIP_TRY(hipEventCreateWithFlags(&c->exported_done, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->fence_host_word), 64, hipHostMallocMapped));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->async_status), 64, hipHostMallocMapped));
     memset(c->fence_host_word, 0, 64);
@@ -1028,7 +1027,6 @@ struct IpcBlob {
     uint32_t n, device;
     uint64_t aligned_data_size;
     hipIpcMemHandle_t heap, block;
-    hipIpcEventHandle_t done;
 };
 static_assert(sizeof(IpcBlob) <= MAPN_IPC_BLOB_BYTES, "MAPN_IPC_BLOB_BYTES too small");
 }  // namespace
@@ -1039,7 +1037,8 @@ struct mapn_ipc_view {
     uint64_t aligned_data_size = 0;
     void *heap = nullptr;
     uint32_t *block = nullptr;
-    hipEvent_t done = nullptr;
+    uint32_t *status = nullptr;               // pinned host word: a bounded device-side wait gave up
+    uint64_t timeout_ticks = 1000ull * 1000ull * 1000ull;   // 10 s
 };
 
 int mapn_ipc_export(mapn_ctx *c, void *out_blob)
@@ -1052,7 +1051,6 @@ int mapn_ipc_export(mapn_ctx *c, void *out_blob)
     b.n = c->n; b.device = (uint32_t)c->device; b.aligned_data_size = c->aligned_data_size;
     HIP_TRY(hipIpcGetMemHandle(&b.heap, c->pos_heap));
     HIP_TRY(hipIpcGetMemHandle(&b.block, c->fence_dev_block));
-    HIP_TRY(hipIpcGetEventHandle(&b.done, c->exported_done));
     c->ipc_exported = true;
     c->consumer_enabled = true;                            // the importer's fence is attached (GetSharedHandles(renderFence))
     if (int rc = observe_steps(c)) return rc;
@@ -1075,7 +1073,8 @@ int mapn_ipc_open(const void *blob, int device, mapn_ipc_view **out_view)
     v->device = device; v->n = b.n; v->aligned_data_size = b.aligned_data_size;
     hipError_t e = hipIpcOpenMemHandle(&v->heap, b.heap, hipIpcMemLazyEnablePeerAccess);
     if (e == hipSuccess) e = hipIpcOpenMemHandle(reinterpret_cast<void **>(&v->block), b.block, hipIpcMemLazyEnablePeerAccess);
-    if (e == hipSuccess) e = hipIpcOpenEventHandle(&v->done, b.done);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&v->status), 64, hipHostMallocMapped);
+    if (e == hipSuccess) memset(v->status, 0, 64);
     if (e != hipSuccess) {
         std::string msg = hipGetErrorString(e);
         mapn_ipc_close(v);
@@ -1089,7 +1088,7 @@ int mapn_ipc_close(mapn_ipc_view *v)
 {
     if (!v) return MAPN_OK;
     (void)hipSetDevice(v->device);
-    if (v->done) (void)hipEventDestroy(v->done);
+    if (v->status) (void)hipHostFree(v->status);
     if (v->block) (void)hipIpcCloseMemHandle(v->block);
     if (v->heap) (void)hipIpcCloseMemHandle(v->heap);
     delete v;
@@ -1113,13 +1112,19 @@ void *mapn_ipc_positions(mapn_ipc_view *v, uint32_t buffer_index)
     return static_cast<char *>(v->heap) + (size_t)buffer_index * v->aligned_data_size;
 }
 
-int mapn_ipc_copy_positions_async(mapn_ipc_view *v, uint32_t buffer_index, uint32_t num_copied, void *dst, void *consumer_stream)
+int mapn_ipc_copy_positions_async(mapn_ipc_view *v, uint32_t buffer_index, uint32_t num_copied, void *dst,
+                                  uint64_t wait_fence_value, void *consumer_stream)
 {
     if (!v || !dst || buffer_index > 1) return fail(MAPN_ERR_INVALID_ARGUMENT, "ipc_copy_positions_async: bad argument");
+    if (*reinterpret_cast<volatile uint32_t *>(v->status))
+        return fail(MAPN_ERR_STATE, "ipc view: an earlier wait for the compute fence timed out");
     if (num_copied > v->n) num_copied = v->n;
     HIP_TRY(hipSetDevice(v->device));
     hipStream_t st = static_cast<hipStream_t>(consumer_stream);
-    HIP_TRY(hipStreamWaitEvent(st, v->done, 0));           // Render.cpp:796 copyQueue.Wait(computeFence, v)
+    // Render.cpp:796 copyQueue.Wait(computeFence, v): the compute fence across the process boundary
+    // is the status block's fence word, published on the compute stream behind each step
+    if (wait_fence_value)
+        HIP_TRY(mapn::launch_fence_wait(v->block + 16, v->block + 16, (uint32_t)wait_fence_value, v->timeout_ticks, v->status, st));
     if (num_copied)
         HIP_TRY(hipMemcpyAsync(dst, mapn_ipc_positions(v, buffer_index), (size_t)num_copied * 16, hipMemcpyDefault, st));
     return MAPN_OK;

@@ -32,6 +32,20 @@ class Params(C.Structure):
         super().__init__(mass, soft2, dt, damping)
 
 
+SUM_REFERENCE, SUM_FP64_ACC, SUM_ORDER_MATCHED = 0, 1, 3
+
+
+class SumSpec(C.Structure):
+    """Diagnostic summation variant of the all-pairs step (mapn_oracle.c header): the reference
+    order, fp64 accumulation of the fp32 pair terms, or the device kernel's chunked order + fusion
+    (waves, sb = the device plan: mapn_kernel_stats.block_x // 64, .grid_y)."""
+
+    _fields_ = [("mode", C.c_int), ("waves", C.c_uint32), ("sb", C.c_uint32)]
+
+    def __init__(self, mode=SUM_REFERENCE, waves=1, sb=1):
+        super().__init__(mode, waves, sb)
+
+
 def build(force: bool = False) -> str:
     """Compile the C restatement (gcc is in the image on both the CPU and the GPU box)."""
     stale = (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(_SRC)
@@ -41,6 +55,7 @@ def build(force: bool = False) -> str:
 
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 
 
 class Oracle:
@@ -52,6 +67,10 @@ class Oracle:
         lib.mapn_oracle_step_central_well.restype = None
         lib.mapn_oracle_step_all_pairs.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int]
         lib.mapn_oracle_step_all_pairs.restype = C.c_int
+        lib.mapn_oracle_step_all_pairs_ex.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int, C.POINTER(SumSpec)]
+        lib.mapn_oracle_step_all_pairs_ex.restype = C.c_int
+        lib.mapn_oracle_step_all_pairs_f64.argtypes = [_f64p, _f64p, _f64p, _f64p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int]
+        lib.mapn_oracle_step_all_pairs_f64.restype = C.c_int
         lib.mapn_oracle_accel_all_pairs.argtypes = [_f32p, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
         lib.mapn_oracle_accel_all_pairs.restype = C.c_int
         lib.mapn_oracle_simulate.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(Params), C.c_int]
@@ -124,9 +143,17 @@ class Oracle:
         self.lib.mapn_oracle_accel_all_pairs(np.ascontiguousarray(pos, np.float32), out, n, first, count, mass, soft2)
         return out
 
-    def step_slice(self, pos, vel, first, count, mode=MODE_ALL_PAIRS, params=None, threads=0):
+    def step_slice(self, pos, vel, first, count, mode=MODE_ALL_PAIRS, params=None, threads=0, sum_spec=None):
         """Advance bodies [first, first+count) only; returns (new_pos_slice, new_vel_slice)."""
         params = params or Params()
+        if sum_spec is not None and mode == MODE_ALL_PAIRS:
+            pos = np.ascontiguousarray(pos, np.float32)
+            vel = np.ascontiguousarray(vel, np.float32)
+            npos, nvel = pos.copy(), vel.copy()
+            if count:
+                rc = self.lib.mapn_oracle_step_all_pairs_ex(pos, vel, npos, nvel, pos.shape[0], first, count, C.byref(params), threads, C.byref(sum_spec))
+                assert rc == 0, rc
+            return npos[first:first + count].copy(), nvel[first:first + count].copy()
         pos = np.ascontiguousarray(pos, np.float32)
         vel = np.ascontiguousarray(vel, np.float32)
         npos, nvel = pos.copy(), vel.copy()
@@ -142,8 +169,9 @@ class OracleSim:
     """Host-array twin of the reference's ``Compute`` object: two ping-pong buffer pairs, a
     buffer index and ``simulate(num_active)`` with Compute.cpp:1009-1055 semantics."""
 
-    def __init__(self, oracle: Oracle, pos, vel, mode=MODE_ALL_PAIRS, params=None, threads=0):
+    def __init__(self, oracle: Oracle, pos, vel, mode=MODE_ALL_PAIRS, params=None, threads=0, sum_spec=None):
         self.o = oracle
+        self.sum_spec = sum_spec            # diagnostic summation variant (all-pairs, num_active = N only)
         self.n = pos.shape[0]
         self.pos = [np.array(pos, np.float32, order="C"), np.array(pos, np.float32, order="C")]   # Compute.cpp:881-882
         self.vel = [np.array(vel, np.float32, order="C"), np.array(vel, np.float32, order="C")]   # Compute.cpp:903-904
@@ -152,6 +180,16 @@ class OracleSim:
 
     def simulate(self, num_active=None, steps=1):
         num_active = self.n if num_active is None else num_active
+        if self.sum_spec is not None and self.mode == MODE_ALL_PAIRS:
+            active = self.o.active_bodies(num_active, self.n)
+            for _ in range(steps):
+                w, r = self.buffer_index, 1 - self.buffer_index
+                if active:
+                    rc = self.o.lib.mapn_oracle_step_all_pairs_ex(self.pos[r], self.vel[r], self.pos[w], self.vel[w], self.n, 0, active,
+                                                                  C.byref(self.params), self.threads, C.byref(self.sum_spec))
+                    assert rc == 0, rc
+                self.buffer_index = 1 - self.buffer_index
+            return
         for _ in range(steps):
             self.buffer_index = int(self.o.lib.mapn_oracle_simulate(
                 self.pos[0], self.pos[1], self.vel[0], self.vel[1], self.buffer_index, self.n,
@@ -160,5 +198,30 @@ class OracleSim:
     @property
     def latest(self):
         """(pos, vel) most recently written = buffer 1 - buffer_index after the flip."""
+        r = 1 - self.buffer_index
+        return self.pos[r], self.vel[r]
+
+
+class OracleSim64:
+    """The all-pairs step in double on DOUBLE state (mapn_oracle_step_all_pairs_f64): the discrete
+    map itself, the yardstick both fp32 paths are measured against.  num_active = N only."""
+
+    def __init__(self, oracle: Oracle, pos, vel, params=None, threads=0):
+        self.o, self.n = oracle, pos.shape[0]
+        self.pos = [np.array(pos, np.float64, order="C"), np.array(pos, np.float64, order="C")]
+        self.vel = [np.array(vel, np.float64, order="C"), np.array(vel, np.float64, order="C")]
+        self.buffer_index = 0
+        self.params, self.threads = params or Params(), threads
+
+    def simulate(self, steps=1):
+        for _ in range(steps):
+            w, r = self.buffer_index, 1 - self.buffer_index
+            rc = self.o.lib.mapn_oracle_step_all_pairs_f64(self.pos[r], self.vel[r], self.pos[w], self.vel[w], self.n, 0, self.n,
+                                                           C.byref(self.params), self.threads)
+            assert rc == 0, rc
+            self.buffer_index = 1 - self.buffer_index
+
+    @property
+    def latest(self):
         r = 1 - self.buffer_index
         return self.pos[r], self.vel[r]

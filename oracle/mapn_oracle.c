@@ -21,6 +21,18 @@
  *   initial state            Compute.cpp:820-844 (two halves), :711-749 (LCG variant), :599-609
  *   LCG known answers        Compute.cpp:599-609 (fast_rand), :622-661 (rand_sse)
  *
+ * Besides the reference-order step, three DIAGNOSTIC variants of the all-pairs sum exist so that a
+ * device-vs-oracle difference can be attributed instead of asserted:
+ *   FP64_ACC       pair term in fp32 exactly as the HLSL, accumulated in double, rounded once;
+ *   ORDER_MATCHED  the summation ORDER and operation FUSION of the device kernel
+ *                  (multi-adapter-particles_amd/csrc/mapn_kernels.hip, pair_term2 / finish): the
+ *                  64-body tiles of the j-range cut into S chunks, each chunk summed over ascending
+ *                  j with fused multiply-adds, chunk sums added in ascending order (waves inside a
+ *                  workgroup, then rows), mass applied after the sum, fma in the integrator.  What
+ *                  is left between this mode and the device is v_rsq_f32 vs 1/sqrtf alone;
+ *   step_all_pairs_f64   the whole step in double on double state ("truth" of the discrete map).
+ * None of them restates the reference; the parity statements are made against the REFERENCE mode.
+ *
  * Arithmetic contract: every operation is a separately rounded IEEE-754 binary32 operation in
  * the order the HLSL source writes it (build with -ffp-contract=off, no -ffast-math).  The
  * all-pairs sum runs over j = 0..N-1 ascending into ONE accumulator per component.  The code is
@@ -234,6 +246,264 @@ int mapn_oracle_step_all_pairs(const float *old_pos, const float *old_vel, float
         }
     }
     all_pairs_worker(&jobs[0]);
+    for (int t = 1; t < threads; t++)
+        if (th[t]) pthread_join(th[t], NULL);
+    free(jobs);
+    free(th);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* diagnostic variants of the all-pairs sum (see header)                                       */
+
+enum { MAPN_ORACLE_SUM_REFERENCE = 0, MAPN_ORACLE_SUM_FP64_ACC = 1, MAPN_ORACLE_SUM_ORDER_MATCHED = 3 };
+
+typedef struct {
+    int mode;            /* MAPN_ORACLE_SUM_* */
+    uint32_t waves, sb;  /* ORDER_MATCHED: the device plan, S = waves * sb chunks (mapn_kernel_stats: block_x / 64, grid_y) */
+} mapn_oracle_sum_spec;
+
+typedef struct {
+    ap_job base;
+    mapn_oracle_sum_spec spec;
+} apx_job;
+
+/* nBodyGravityCS.hlsl:103-108 with the device kernel's fusion (integrate_store in mapn_kernels.hip):
+ * v = fma(a, dt, v) * damping; x = fma(v, dt, x); w = sqrt(fma(az, az, fma(ay, ay, ax * ax))) */
+static inline void integrate_fused(const float *pos, const float *vel, float ax, float ay, float az,
+                                   const mapn_oracle_params *p, float *npos, float *nvel)
+{
+    float vx = __builtin_fmaf(ax, p->dt, vel[0]) * p->damping;
+    float vy = __builtin_fmaf(ay, p->dt, vel[1]) * p->damping;
+    float vz = __builtin_fmaf(az, p->dt, vel[2]) * p->damping;
+    npos[0] = __builtin_fmaf(vx, p->dt, pos[0]);
+    npos[1] = __builtin_fmaf(vy, p->dt, pos[1]);
+    npos[2] = __builtin_fmaf(vz, p->dt, pos[2]);
+    npos[3] = sqrtf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)));
+    nvel[0] = vx; nvel[1] = vy; nvel[2] = vz;
+}
+
+/* FP64_ACC: the fp32 pair term of hlsl:44-57 op by op, summed in double over ascending j */
+__attribute__((target_clones("avx512f", "avx2", "default")))
+static void all_pairs_block_acc64(const ap_job *J, uint32_t b0, uint32_t nb)
+{
+    float xi[IB], yi[IB], zi[IB];
+    double ax[IB], ay[IB], az[IB];
+    const float mass = J->p->mass, soft2 = J->p->soft2;
+    for (uint32_t k = 0; k < IB; k++) {
+        uint32_t i = b0 + (k < nb ? k : 0);
+        xi[k] = J->old_pos[4 * (size_t)i + 0];
+        yi[k] = J->old_pos[4 * (size_t)i + 1];
+        zi[k] = J->old_pos[4 * (size_t)i + 2];
+        ax[k] = ay[k] = az[k] = 0.0;
+    }
+    const float *pj = J->old_pos;
+    for (uint32_t j = 0; j < J->n_total; j++, pj += 4) {
+        const float xj = pj[0], yj = pj[1], zj = pj[2];
+#pragma GCC ivdep
+        for (int k = 0; k < IB; k++) {
+            float rx = xj - xi[k];
+            float ry = yj - yi[k];
+            float rz = zj - zi[k];
+            float d = rx * rx + ry * ry;
+            d = d + rz * rz;
+            d = d + soft2;
+            float inv = 1.0f / sqrtf(d);
+            float inv3 = inv * inv * inv;
+            float s = mass * inv3 * 1.0f;
+            float tx = rx * s, ty = ry * s, tz = rz * s;     /* the fp32 products of hlsl:56 */
+            ax[k] = ax[k] + (double)tx;
+            ay[k] = ay[k] + (double)ty;
+            az[k] = az[k] + (double)tz;
+        }
+    }
+    for (uint32_t k = 0; k < nb; k++) {
+        uint32_t i = b0 + k;
+        integrate(J->old_pos + 4 * (size_t)i, J->old_vel + 3 * (size_t)i, (float)ax[k], (float)ay[k], (float)az[k],
+                  J->p, J->new_pos + 4 * (size_t)i, J->new_vel + 3 * (size_t)i);
+    }
+}
+
+/* ORDER_MATCHED: chunk c of S owns tiles [c*base + min(c, rem), ... + base + (c < rem)) of the
+ * ceil(N/64) 64-body tiles (chunk_tiles in mapn_kernels.hip); inside a chunk
+ *   d = fma(dz,dz, fma(dy,dy, fma(dx,dx, soft2))); inv = 1/sqrt(d); inv3 = (inv*inv)*inv;
+ *   a = fma(dx, inv3, a)                                   (pair_term2)
+ * chunk sums are added waves-ascending into a workgroup sum, workgroup sums rows-ascending into
+ * the total (finish<> / reduce_integrate_kernel), the total is multiplied by the mass. */
+__attribute__((target_clones("avx512f", "fma", "default")))
+static void all_pairs_block_matched(const apx_job *X, uint32_t b0, uint32_t nb)
+{
+    const ap_job *J = &X->base;
+    float xi[IB], yi[IB], zi[IB], tx[IB], ty[IB], tz[IB], wx[IB], wy[IB], wz[IB], cx[IB], cy[IB], cz[IB];
+    const float soft2 = J->p->soft2;
+    for (uint32_t k = 0; k < IB; k++) {
+        uint32_t i = b0 + (k < nb ? k : 0);
+        xi[k] = J->old_pos[4 * (size_t)i + 0];
+        yi[k] = J->old_pos[4 * (size_t)i + 1];
+        zi[k] = J->old_pos[4 * (size_t)i + 2];
+        tx[k] = ty[k] = tz[k] = 0.0f;
+    }
+    const uint32_t waves = X->spec.waves, sb = X->spec.sb, S = waves * sb;
+    const uint32_t tiles = (J->n_total + 63u) / 64u, base = tiles / S, rem = tiles % S;
+    for (uint32_t row = 0; row < sb; row++) {
+        for (int k = 0; k < IB; k++) wx[k] = wy[k] = wz[k] = 0.0f;
+        for (uint32_t w = 0; w < waves; w++) {
+            const uint32_t c = row * waves + w;
+            const uint32_t t0 = c * base + (c < rem ? c : rem), t1 = t0 + base + (c < rem ? 1u : 0u);
+            uint32_t j0 = t0 * 64u, j1 = t1 * 64u;
+            if (j1 > J->n_total) j1 = J->n_total;
+            for (int k = 0; k < IB; k++) cx[k] = cy[k] = cz[k] = 0.0f;
+            const float *pj = J->old_pos + 4 * (size_t)j0;
+            for (uint32_t j = j0; j < j1; j++, pj += 4) {
+                const float xj = pj[0], yj = pj[1], zj = pj[2];
+#pragma GCC ivdep
+                for (int k = 0; k < IB; k++) {
+                    float dx = xj - xi[k], dy = yj - yi[k], dz = zj - zi[k];
+                    float d = __builtin_fmaf(dx, dx, soft2);
+                    d = __builtin_fmaf(dy, dy, d);
+                    d = __builtin_fmaf(dz, dz, d);
+                    float inv = 1.0f / sqrtf(d);
+                    float inv3 = inv * inv * inv;
+                    cx[k] = __builtin_fmaf(dx, inv3, cx[k]);
+                    cy[k] = __builtin_fmaf(dy, inv3, cy[k]);
+                    cz[k] = __builtin_fmaf(dz, inv3, cz[k]);
+                }
+            }
+            for (int k = 0; k < IB; k++) { wx[k] = wx[k] + cx[k]; wy[k] = wy[k] + cy[k]; wz[k] = wz[k] + cz[k]; }
+        }
+        for (int k = 0; k < IB; k++) { tx[k] = tx[k] + wx[k]; ty[k] = ty[k] + wy[k]; tz[k] = tz[k] + wz[k]; }
+    }
+    for (uint32_t k = 0; k < nb; k++) {
+        uint32_t i = b0 + k;
+        integrate_fused(J->old_pos + 4 * (size_t)i, J->old_vel + 3 * (size_t)i, tx[k] * J->p->mass, ty[k] * J->p->mass,
+                        tz[k] * J->p->mass, J->p, J->new_pos + 4 * (size_t)i, J->new_vel + 3 * (size_t)i);
+    }
+}
+
+static void *all_pairs_worker_ex(void *arg)
+{
+    const apx_job *X = (const apx_job *)arg;
+    const ap_job *J = &X->base;
+    uint32_t nblocks = (J->count + IB - 1) / IB;
+    for (uint32_t b = J->tid; b < nblocks; b += J->nthreads) {
+        uint32_t b0 = J->first + b * IB;
+        uint32_t nb = J->first + J->count - b0;
+        if (nb > IB) nb = IB;
+        if (X->spec.mode == MAPN_ORACLE_SUM_FP64_ACC) all_pairs_block_acc64(J, b0, nb);
+        else if (X->spec.mode == MAPN_ORACLE_SUM_ORDER_MATCHED) all_pairs_block_matched(X, b0, nb);
+        else all_pairs_block(J, b0, nb);
+    }
+    return NULL;
+}
+
+/* mapn_oracle_step_all_pairs with a selectable summation variant (spec == NULL: reference order) */
+int mapn_oracle_step_all_pairs_ex(const float *old_pos, const float *old_vel, float *new_pos,
+                                  float *new_vel, uint32_t n_total, uint32_t first, uint32_t count,
+                                  const mapn_oracle_params *p, int threads, const mapn_oracle_sum_spec *spec)
+{
+    mapn_oracle_sum_spec sp = {MAPN_ORACLE_SUM_REFERENCE, 1, 1};
+    if (spec) sp = *spec;
+    if (sp.mode != MAPN_ORACLE_SUM_REFERENCE && sp.mode != MAPN_ORACLE_SUM_FP64_ACC && sp.mode != MAPN_ORACLE_SUM_ORDER_MATCHED) return -2;
+    if (sp.mode == MAPN_ORACLE_SUM_ORDER_MATCHED && (sp.waves == 0 || sp.sb == 0)) return -2;
+    if (threads <= 0) threads = mapn_oracle_hardware_threads();
+    uint32_t nblocks = (count + IB - 1) / IB;
+    if ((uint32_t)threads > nblocks) threads = nblocks ? (int)nblocks : 1;
+    apx_job *jobs = (apx_job *)calloc((size_t)threads, sizeof(apx_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); return -1; }
+    for (int t = 0; t < threads; t++) {
+        jobs[t].base = (ap_job){old_pos, old_vel, new_pos, new_vel, n_total, first, count, p, (uint32_t)t, (uint32_t)threads};
+        jobs[t].spec = sp;
+        if (t > 0 && pthread_create(&th[t], NULL, all_pairs_worker_ex, &jobs[t]) != 0) {
+            all_pairs_worker_ex(&jobs[t]);
+            th[t] = 0;
+        }
+    }
+    all_pairs_worker_ex(&jobs[0]);
+    for (int t = 1; t < threads; t++)
+        if (th[t]) pthread_join(th[t], NULL);
+    free(jobs);
+    free(th);
+    return 0;
+}
+
+/* The whole all-pairs step in double on DOUBLE state (pos4: x,y,z,w; vel3): the discrete map
+ * itself, free of fp32 rounding -- the yardstick both fp32 paths are measured against. */
+typedef struct {
+    const double *old_pos, *old_vel;
+    double *new_pos, *new_vel;
+    uint32_t n_total, first, count;
+    double mass, soft2, dt, damping;
+    uint32_t tid, nthreads;
+} ap64_job;
+
+#define IB64 8
+__attribute__((target_clones("avx512f", "avx2", "default")))
+static void all_pairs_block_f64(const ap64_job *J, uint32_t b0, uint32_t nb)
+{
+    double xi[IB64], yi[IB64], zi[IB64], ax[IB64], ay[IB64], az[IB64];
+    for (uint32_t k = 0; k < IB64; k++) {
+        uint32_t i = b0 + (k < nb ? k : 0);
+        xi[k] = J->old_pos[4 * (size_t)i + 0];
+        yi[k] = J->old_pos[4 * (size_t)i + 1];
+        zi[k] = J->old_pos[4 * (size_t)i + 2];
+        ax[k] = ay[k] = az[k] = 0.0;
+    }
+    const double *pj = J->old_pos;
+    const double soft2 = J->soft2;
+    for (uint32_t j = 0; j < J->n_total; j++, pj += 4) {
+        const double xj = pj[0], yj = pj[1], zj = pj[2];
+#pragma GCC ivdep
+        for (int k = 0; k < IB64; k++) {
+            double rx = xj - xi[k], ry = yj - yi[k], rz = zj - zi[k];
+            double d = rx * rx + ry * ry + rz * rz + soft2;
+            double inv = 1.0 / sqrt(d);
+            double s = inv * inv * inv;
+            ax[k] += rx * s; ay[k] += ry * s; az[k] += rz * s;
+        }
+    }
+    for (uint32_t k = 0; k < nb; k++) {
+        uint32_t i = b0 + k;
+        const double a0 = ax[k] * J->mass, a1 = ay[k] * J->mass, a2 = az[k] * J->mass;
+        const double *v = J->old_vel + 3 * (size_t)i, *x = J->old_pos + 4 * (size_t)i;
+        double vx = (v[0] + a0 * J->dt) * J->damping, vy = (v[1] + a1 * J->dt) * J->damping, vz = (v[2] + a2 * J->dt) * J->damping;
+        double *nx = J->new_pos + 4 * (size_t)i, *nv = J->new_vel + 3 * (size_t)i;
+        nx[0] = x[0] + vx * J->dt; nx[1] = x[1] + vy * J->dt; nx[2] = x[2] + vz * J->dt;
+        nx[3] = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+        nv[0] = vx; nv[1] = vy; nv[2] = vz;
+    }
+}
+
+static void *all_pairs_worker_f64(void *arg)
+{
+    const ap64_job *J = (const ap64_job *)arg;
+    uint32_t nblocks = (J->count + IB64 - 1) / IB64;
+    for (uint32_t b = J->tid; b < nblocks; b += J->nthreads) {
+        uint32_t b0 = J->first + b * IB64;
+        uint32_t nb = J->first + J->count - b0;
+        all_pairs_block_f64(J, b0, nb < IB64 ? nb : IB64);
+    }
+    return NULL;
+}
+
+int mapn_oracle_step_all_pairs_f64(const double *old_pos, const double *old_vel, double *new_pos, double *new_vel,
+                                   uint32_t n_total, uint32_t first, uint32_t count, const mapn_oracle_params *p, int threads)
+{
+    if (threads <= 0) threads = mapn_oracle_hardware_threads();
+    uint32_t nblocks = (count + IB64 - 1) / IB64;
+    if ((uint32_t)threads > nblocks) threads = nblocks ? (int)nblocks : 1;
+    ap64_job *jobs = (ap64_job *)calloc((size_t)threads, sizeof(ap64_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); return -1; }
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = (ap64_job){old_pos, old_vel, new_pos, new_vel, n_total, first, count,
+                             (double)p->mass, (double)p->soft2, (double)p->dt, (double)p->damping, (uint32_t)t, (uint32_t)threads};
+        if (t > 0 && pthread_create(&th[t], NULL, all_pairs_worker_f64, &jobs[t]) != 0) {
+            all_pairs_worker_f64(&jobs[t]);
+            th[t] = 0;
+        }
+    }
+    all_pairs_worker_f64(&jobs[0]);
     for (int t = 1; t < threads; t++)
         if (th[t]) pthread_join(th[t], NULL);
     free(jobs);

@@ -1,7 +1,21 @@
 #!/usr/bin/env python3
-"""Parity report: device path vs CPU oracle on identical seeded initial conditions,
-free-running, statistics after 1, 10, 100 and 1000 steps.  Runs on the GPU box (the oracle uses
-all host cores).  Regime: mass = 70000/N."""
+"""Parity report: the device path against FOUR CPU trajectories started
+from identical seeded initial conditions, free-running, statistics after 1, 10, 100 and 1000 steps.
+
+  ref      the oracle proper: fp32, the HLSL's operation order, one running sum over ascending j
+           (nBodyGravityCS.hlsl:44-57, :103-108) -- the north_star's "CPU reference";
+  acc64    the same fp32 pair terms accumulated in double (summation error removed);
+  matched  the device kernel's summation ORDER and operation FUSION restated on the CPU (chunked
+           sums, fma, mass after the sum) -- what is left against the device is v_rsq_f32 alone;
+  f64      the whole step in double on double state: the discrete map itself.
+
+Comparing device|ref|matched with acc64 / f64 attributes a device-vs-ref difference: if the device
+is no farther from the yardsticks than ref is, the difference is fp32 summation order amplified by
+the dynamics, not a kernel defect.  Regime: mass = 70000/N.
+
+Runs on the GPU box (the oracles use all host cores).  Imported by tests/test_parity_1000.py; as a
+script it prints one JSON row per (mark, pair) and writes --out.
+"""
 import argparse
 import json
 import os
@@ -11,47 +25,85 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
-import mapn  # noqa: E402
-from oracle import Oracle, OracleSim, Params  # noqa: E402
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--bodies", type=int, default=65536)
-ap.add_argument("--steps", default="1,10,100,1000")
-ap.add_argument("--out", default="")
-a = ap.parse_args()
-n = a.bodies
-marks = [int(s) for s in a.steps.split(",")]
-o = Oracle()
-pos, vel = o.initial_state(n, seed=1)
-prm = Params(mass=70000.0 / n)
-sim = OracleSim(o, pos, vel, params=prm)
-rows = []
-with mapn.Compute(n, mass=70000.0 / n) as c:
-    assert np.array_equal(c.download_state()[0], pos)
-    done = 0
-    t_cpu = t_gpu = 0.0
+
+def stats(a_pos, b_pos):
+    """Named statistics of the relative position error ||a_i - b_i|| / ||b_i|| over bodies."""
+    a = np.asarray(a_pos, np.float64)[:, :3]
+    b = np.asarray(b_pos, np.float64)[:, :3]
+    dx = np.linalg.norm(a - b, axis=1)
+    rel = dx / np.maximum(np.linalg.norm(b, axis=1), 1e-30)
+    return {"max": float(rel.max()), "median": float(np.median(rel)), "rms": float(np.sqrt((rel ** 2).mean())),
+            "frac_within_1e-4": float((rel < 1e-4).mean()), "n_over_1e-4": int((rel >= 1e-4).sum()),
+            "max_over_spread400": float(dx.max() / 400.0)}
+
+
+def run_report(n=65536, marks=(1, 10, 100, 1000), seed=1, with_f64=True, log=print):
+    import mapn
+    from oracle import Oracle, OracleSim, OracleSim64, Params, SumSpec, SUM_FP64_ACC, SUM_ORDER_MATCHED
+
+    o = Oracle()
+    pos, vel = o.initial_state(n, seed=seed)
+    prm = Params(mass=70000.0 / n)
+    out = {"bodies": n, "seed": seed, "regime": "mass=70000/N, soft2=25, dt=0.1, damping=1", "threads": o.hardware_threads(),
+           "marks": list(marks), "timing_s": {}, "rows": []}
+    snaps = {}
+    with mapn.Compute(n, mass=70000.0 / n, seed=seed) as c:
+        assert np.array_equal(c.download_state()[0], pos)
+        done, t0 = 0, time.perf_counter()
+        for m in marks:
+            for _ in range(m - done):
+                c.Simulate(n, c.GetFenceValue())
+            done = m
+            snaps[("device", m)] = c.download_state()
+        out["timing_s"]["device"] = time.perf_counter() - t0
+        st = c.kernel_stats()
+        waves, sb = st.block_x // 64, st.grid_y
+        out["device_plan"] = {"kernel": st.kernel_name.decode(), "waves": waves, "sb": sb, "j_splits": st.j_splits,
+                              "bodies_per_lane": st.bodies_per_lane, "epilogue": st.epilogue}
+        v0 = vel.astype(np.float64).sum(0)
+        out["momentum_drift_rel"] = float(np.abs(snaps[("device", marks[-1])][1].astype(np.float64).sum(0) - v0).max() / (n * 15.0))
+    sims = {"ref": OracleSim(o, pos, vel, params=prm),
+            "acc64": OracleSim(o, pos, vel, params=prm, sum_spec=SumSpec(SUM_FP64_ACC)),
+            "matched": OracleSim(o, pos, vel, params=prm, sum_spec=SumSpec(SUM_ORDER_MATCHED, waves, sb))}
+    if with_f64:
+        sims["f64"] = OracleSim64(o, pos, vel, params=prm)
+    for name, sim in sims.items():
+        done, t0 = 0, time.perf_counter()
+        for m in marks:
+            sim.simulate(steps=m - done)
+            done = m
+            p, v = sim.latest
+            snaps[(name, m)] = (p.copy(), v.copy())
+        out["timing_s"][name] = time.perf_counter() - t0
+        log(f"# oracle {name}: {out['timing_s'][name]:.1f} s for {marks[-1]} steps of {n} bodies on {o.hardware_threads()} threads")
+    pairs = [("device", "ref"), ("device", "matched"), ("device", "acc64"), ("ref", "acc64"), ("matched", "acc64")]
+    if with_f64:
+        pairs += [("device", "f64"), ("ref", "f64"), ("matched", "f64"), ("acc64", "f64")]
     for m in marks:
-        t0 = time.perf_counter(); sim.simulate(steps=m - done); t_cpu += time.perf_counter() - t0
-        t0 = time.perf_counter()
-        for _ in range(m - done):
-            c.Simulate(n, c.GetFenceValue())
-        c.WaitForGpu(); t_gpu += time.perf_counter() - t0
-        done = m
-        gp, gv = c.download_state()
-        rp, rv = sim.latest
-        dx = np.linalg.norm(gp[:, :3].astype(np.float64) - rp[:, :3], axis=1)
-        xr = np.maximum(np.linalg.norm(rp[:, :3].astype(np.float64), axis=1), 1e-30)
-        dv = np.linalg.norm(gv.astype(np.float64) - rv, axis=1)
-        dw = np.abs(gp[:, 3].astype(np.float64) - rp[:, 3])
-        row = {"steps": m,
-               "pos_rel_to_norm": {"max": float((dx / xr).max()), "median": float(np.median(dx / xr)), "rms": float(np.sqrt(((dx / xr) ** 2).mean()))},
-               "pos_rel_to_spread400": {"max": float(dx.max() / 400), "median": float(np.median(dx) / 400), "rms": float(np.sqrt((dx ** 2).mean()) / 400)},
-               "vel_rel_to_15": {"max": float(dv.max() / 15), "median": float(np.median(dv) / 15)},
-               "w_rel_to_max": {"max": float(dw.max() / rp[:, 3].max())},
-               "momentum_drift_rel": float(np.abs(gv.astype(np.float64).sum(0) - vel.astype(np.float64).sum(0)).max() / (n * 15.0)),
-               "frac_bodies_within_1e-4_rel": float((dx / xr < 1e-4).mean())}
-        rows.append(row)
-        print(json.dumps(row), flush=True)
-print(f"# N={n} mass=70000/N dt=0.1 soft2=25; oracle {t_cpu:.1f} s on {o.hardware_threads()} threads, device {t_gpu:.2f} s", flush=True)
-if a.out:
-    json.dump({"bodies": n, "rows": rows, "cpu_seconds": t_cpu, "gpu_seconds": t_gpu, "threads": o.hardware_threads()}, open(a.out, "w"), indent=1)
+        for a, b in pairs:
+            row = {"steps": m, "a": a, "b": b, **stats(snaps[(a, m)][0], snaps[(b, m)][0])}
+            dv = np.linalg.norm(snaps[(a, m)][1].astype(np.float64) - snaps[(b, m)][1].astype(np.float64), axis=1)
+            row["vel_max_over_15"] = float(dv.max() / 15.0)
+            out["rows"].append(row)
+            log(json.dumps(row))
+    return out
+
+
+def row(report, steps, a, b):
+    for r in report["rows"]:
+        if r["steps"] == steps and r["a"] == a and r["b"] == b:
+            return r
+    raise KeyError((steps, a, b))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bodies", type=int, default=65536)
+    ap.add_argument("--steps", default="1,10,100,1000")
+    ap.add_argument("--no-f64", action="store_true")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    rep = run_report(a.bodies, tuple(int(s) for s in a.steps.split(",")), with_f64=not a.no_f64)
+    if a.out:
+        json.dump(rep, open(a.out, "w"), indent=1)

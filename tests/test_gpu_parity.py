@@ -588,3 +588,52 @@ def test_external_gather_slices_compose_to_the_full_step(oracle):
     finally:
         for s in shards:
             s.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[3]: 1 048 576 bodies sharded x8 -- one rank's share on one GPU
+
+@pytest.mark.parametrize("rank", [0, 5])
+def test_config3_one_rank_share_of_the_8_gpu_1mi_body_job(oracle, rank, monkeypatch):
+    """configs[3] (1 048 576 bodies, bodies sharded over 8 GPUs, all-gather per step): the work of ONE
+    rank -- 131 072 bodies against all 1 048 576 -- fits one GPU (~30 ms).  One teacher-forced step:
+    a 4096-body subset of the slice against the oracle, the bodies outside the slice untouched, and the
+    same step through the in-library RCCL path (1-rank communicator, MAPN_COMM_LOOPBACK) and through
+    the own/remote overlap structure."""
+    n, world = 1048576, 8
+    mass = 70000.0 / n
+    pos, vel = oracle.initial_state(n, seed=1)
+    count = n // world
+    first = rank * count
+    sub = first + 37 * 64
+    rp, rv = oracle.step_slice(pos, vel, sub, 4096, params=Params(mass=mass))
+    with mapn.Compute(n, mass=mass, rank=rank, world_size=world) as c:
+        assert c.shard_range() == (first, count)
+        np.testing.assert_array_equal(c.download_state()[0], pos)
+        c.set_external_gather(True)
+        draw(c, 1)
+        p, v = c.download_state()
+        st = c.kernel_stats()
+        assert st.force_launches_per_step == 1 and st.fused == 1
+    assert errs(p[sub:sub + 4096, :3], rp[:, :3], SPREAD)[0] < 1e-6
+    assert errs(v[sub:sub + 4096], rv, SPEED)[0] < 2e-5
+    assert np.abs(p[sub:sub + 4096, 3] - rp[:, 3]).max() / rp[:, 3].max() < 2e-4
+    outside = np.ones(n, bool); outside[first:first + count] = False
+    np.testing.assert_array_equal(p[outside], pos[outside])           # other ranks' bodies: not this rank's to move
+    np.testing.assert_array_equal(v[outside], vel[outside])
+    assert np.isfinite(p[first:first + count]).all() and not np.array_equal(p[first:first + count], pos[first:first + count])
+    if rank != 0:
+        return
+    monkeypatch.setenv("MAPN_COMM_LOOPBACK", "1")                     # rank 0 of 8 joins a ONE-rank communicator
+    for flags in (0, mapn.FLAG_SHARD_OVERLAP):
+        with mapn.Compute(n, mass=mass, rank=0, world_size=world, flags=flags) as c:
+            c.comm_init(mapn.Compute.comm_unique_id())
+            draw(c, 1)
+            p2, v2 = c.download_state()
+            assert c.kernel_stats().force_launches_per_step == (2 if flags else 1)
+        if flags == 0:
+            np.testing.assert_array_equal(p2, p); np.testing.assert_array_equal(v2, v)   # same launch, same bits
+        else:
+            assert errs(p2[sub:sub + 4096, :3], rp[:, :3], SPREAD)[0] < 1e-6
+            assert errs(v2[sub:sub + 4096], rv, SPEED)[0] < 2e-5
+            assert errs(v2[first:first + count], v[first:first + count], SPEED)[0] < 1e-6

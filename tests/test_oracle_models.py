@@ -120,3 +120,63 @@ def test_momentum_and_energy_invariants_stable_regime(oracle):
     assert np.abs(p1 - p0).max() < 1e-2 * n * 15 * 1e-3        # << total |p| scale n*15
     r = np.linalg.norm(sim.latest[0][:, :3], axis=1)
     assert r.max() < 2000 and np.isfinite(sim.latest[0]).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# diagnostic summation variants: acc64, order-matched, full double
+
+def test_sum_spec_reference_mode_is_the_oracle_proper(oracle):
+    from oracle import OracleSim, Params, SumSpec, SUM_REFERENCE
+    n = 1000
+    pos, vel = oracle.initial_state(n, seed=2)
+    prm = Params(mass=70000.0 / n)
+    a = OracleSim(oracle, pos, vel, params=prm); a.simulate(steps=3)
+    b = OracleSim(oracle, pos, vel, params=prm, sum_spec=SumSpec(SUM_REFERENCE)); b.simulate(steps=3)
+    np.testing.assert_array_equal(a.latest[0], b.latest[0]); np.testing.assert_array_equal(a.latest[1], b.latest[1])
+
+
+def test_f64_step_matches_the_independent_numpy_float64_model(oracle):
+    from oracle import OracleSim64, Params
+    n = 700
+    pos, vel = oracle.initial_state(n, seed=3)
+    prm = Params(mass=70000.0 / n)
+    s = OracleSim64(oracle, pos, vel, params=prm); s.simulate()
+    acc = model_np.accel_fp64(pos, mass=float(prm.mass), soft2=float(prm.soft2))
+    x, v = model_np.integrate_fp64(pos, vel, acc, dt=float(prm.dt), damping=float(prm.damping))   # the fp32-rounded constants
+    np.testing.assert_allclose(s.latest[0][:, :3], x[:, :3], rtol=1e-13, atol=1e-11)
+    np.testing.assert_allclose(s.latest[1], v, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(s.latest[0][:, 3], x[:, 3], rtol=1e-12)
+
+
+@pytest.mark.parametrize("n,waves,sb", [(1000, 8, 8), (4096, 16, 16), (130, 4, 3), (64, 1, 1), (3000, 8, 1)])
+def test_acc64_and_order_matched_agree_with_the_double_step(oracle, n, waves, sb):
+    """The three fp32 variants differ from the double step only by fp32 rounding: after one step
+    velocities agree to a few 1e-7 of the speed scale; acc64 (summation error removed) is at least
+    as close as the reference order.  Ragged N and S > number of tiles (empty chunks) included."""
+    from oracle import OracleSim, OracleSim64, Params, SumSpec, SUM_FP64_ACC, SUM_ORDER_MATCHED
+    pos, vel = oracle.initial_state(n, seed=4)
+    if n % 2:
+        pos[n - 1, :3] = [5.0, 6.0, 7.0]
+    prm = Params(mass=70000.0 / n)
+    truth = OracleSim64(oracle, pos, vel, params=prm); truth.simulate()
+    err = {}
+    for name, spec in (("ref", None), ("acc64", SumSpec(SUM_FP64_ACC)), ("matched", SumSpec(SUM_ORDER_MATCHED, waves, sb))):
+        s = OracleSim(oracle, pos, vel, params=prm, sum_spec=spec); s.simulate()
+        err[name] = np.abs(s.latest[1].astype(np.float64) - truth.latest[1]).max() / 15.0
+        assert np.abs(s.latest[0][:, :3].astype(np.float64) - truth.latest[0][:, :3]).max() / 400.0 < 2e-7
+        np.testing.assert_allclose(s.latest[0][:, 3], truth.latest[0][:, 3], rtol=2e-5, atol=1e-9)
+    assert err["ref"] < 5e-7 and err["matched"] < 5e-7 and err["acc64"] <= err["ref"] + 6e-8, err
+
+
+def test_order_matched_depends_on_the_plan_only_through_rounding(oracle):
+    from oracle import OracleSim, Params, SumSpec, SUM_ORDER_MATCHED
+    n = 2048
+    pos, vel = oracle.initial_state(n, seed=5)
+    prm = Params(mass=70000.0 / n)
+    outs = []
+    for waves, sb in ((8, 4), (4, 8), (1, 32), (1, 1)):
+        s = OracleSim(oracle, pos, vel, params=prm, sum_spec=SumSpec(SUM_ORDER_MATCHED, waves, sb)); s.simulate(steps=2)
+        outs.append(s.latest[1].copy())
+    for o in outs[1:]:
+        assert np.abs(o - outs[0]).max() / 15.0 < 3e-7
+    assert any(not np.array_equal(o, outs[0]) for o in outs[1:])       # the order does reach the bits

@@ -1,0 +1,83 @@
+"""The north_star's tolerance, gated: 65 536 bodies, 1000 free-running steps, device
+vs the CPU oracle on identical initial conditions -- with the statistic NAMED and the
+difference ATTRIBUTED.
+
+Four CPU trajectories (tests/parity_report.py): `ref` (the oracle proper: fp32, HLSL order, one
+running sum), `acc64` (same pair terms, double accumulation), `matched` (the device's summation
+order and fma fusion restated on the CPU; only v_rsq_f32 vs 1/sqrtf is left) and `f64` (the step in
+double on double state).  Statements asserted, all on ||dx_i|| / ||x_i|| over the 65 536 bodies:
+
+  T1  device vs ref after 1000 steps: median <= 1e-5, RMS <= 5e-5, >= 99.9 % of the bodies within
+      1e-4.  The MAXIMUM over bodies is NOT within 1e-4 (a handful of bodies that passed close to
+      another one amplify a 1-ulp difference: SURVEY F4's chaos) and is bounded at 5e-3 only.
+  T2  device vs ref after 100 steps: max <= 2e-6 (every body far inside 1e-4).
+  T3  attribution: the device is no farther from either yardstick than the reference-order oracle is --
+      err(device, acc64) <= 1.5 x err(ref, acc64) and err(device, f64) <= 1.5 x err(ref, f64) for
+      median and RMS at 100 and 1000 steps.  I.e. the device-vs-ref difference is the fp32
+      summation order of `ref` itself, amplified by the dynamics -- not a kernel defect.
+  T4  device vs matched (only v_rsq_f32 differs): tighter than T1/T2 by the bounds written below.
+
+The oracle legs take ~3-4 minutes on the GPU box's host cores (4 x 4.3e12 pair terms).
+"""
+import json
+import os
+
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def report():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from parity_report import run_report
+    rep = run_report(65536, (1, 10, 100, 1000), log=lambda s: print(s, flush=True))
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(rep, open(os.path.join(out, "parity_1000_65536.json"), "w"), indent=1)
+    return rep
+
+
+def _row(rep, steps, a, b):
+    from parity_report import row
+    return row(rep, steps, a, b)
+
+
+def test_t1_device_vs_reference_order_oracle_after_1000_steps(report):
+    r = _row(report, 1000, "device", "ref")
+    print("device vs ref @1000:", r)
+    assert r["median"] <= 1e-5
+    assert r["rms"] <= 5e-5
+    assert r["frac_within_1e-4"] >= 0.999
+    assert r["max"] <= 5e-3            # NOT <= 1e-4: see the module docstring and BASELINE.md section 4
+    assert report["momentum_drift_rel"] < 1e-7
+
+
+def test_t2_device_vs_reference_order_oracle_after_100_steps(report):
+    for steps, bound in ((1, 5e-7), (10, 5e-7), (100, 2e-6)):
+        r = _row(report, steps, "device", "ref")
+        assert r["max"] <= bound, (steps, r)
+        assert r["frac_within_1e-4"] == 1.0
+
+
+@pytest.mark.parametrize("yardstick", ["acc64", "f64"])
+def test_t3_device_is_no_farther_from_the_yardsticks_than_the_oracle_is(report, yardstick):
+    for steps in (100, 1000):
+        dev, ref = _row(report, steps, "device", yardstick), _row(report, steps, "ref", yardstick)
+        print(f"@{steps} vs {yardstick}: device median {dev['median']:.3e} rms {dev['rms']:.3e} max {dev['max']:.3e} | "
+              f"ref median {ref['median']:.3e} rms {ref['rms']:.3e} max {ref['max']:.3e}")
+        assert dev["median"] <= 1.5 * ref["median"], (steps, dev, ref)
+        assert dev["rms"] <= 1.5 * ref["rms"], (steps, dev, ref)
+
+
+def test_t4_device_vs_order_matched_oracle_differs_by_rsq_only(report):
+    r1, r100, r1000 = (_row(report, s, "device", "matched") for s in (1, 100, 1000))
+    print("device vs matched:", r1, r100, r1000)
+    assert r1["max"] <= 1.3e-7                 # one step: <= 1 ulp of the position
+    assert r100["max"] <= 1e-6 and r100["median"] <= 3e-8
+    assert r1000["median"] <= 5e-6 and r1000["rms"] <= 3e-5
+    d_ref = _row(report, 1000, "device", "ref")
+    assert r1000["median"] <= d_ref["median"]   # tighter than against the reference-order oracle

@@ -15,7 +15,10 @@ roofline: the force kernel is bound by the fp32 VECTOR ALU, not HBM and not MFMA
 intensity ~23 000 flop/B); `peak` is CUs x clock x 256 flop/clk = 157.3 TFLOP/s, which is also the
 dense f32 MFMA peak of MI355X_MICROARCH.md.  `achieved` = 20 flop per ordered pair
 x the pairs one launch processes / the force kernel's mean launch duration, measured live with
-HIP events recorded on the compute stream around every force launch of the timed region.
+HIP events recorded on the compute stream around sampled force launches of the timed region (one
+event pair per sampled step: the step IS one launch).  `held_clock_ghz` is the shader clock the chip
+held under this kernel, stamped in-kernel right after the timed region (mapn_measure_clock), and
+`frac_at_held_clock` prices the same achieved rate against CUs x held clock x 256.
 """
 from __future__ import annotations
 
@@ -95,23 +98,37 @@ def cpu_baseline(n, seed, target_seconds):
             "cpu": model}
 
 
+def kernel_source_sha16():
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(here, "multi-adapter-particles_amd", "csrc", "mapn_kernels.hip")
+    try:
+        return hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def pmc_traffic(kernel_name, n, world):
     """HBM bytes per force launch from the committed PMC passes (profiles/*_pmc_summary.json,
     collected with separate rocprofv3 --pmc runs of this same command and corrected as the
     MI355X guide prescribes: 2 x FETCH_SIZE + WRITE_SIZE).  PMC counters cannot be read from
     inside an un-profiled run, so this is the profiled value for the default 65 536-body
-    single-GPU workload, or None for any other configuration."""
+    single-GPU workload, or None for any other configuration -- and None when the summary was taken
+    from a different kernel source than the one running (its sha is stored in the summary)."""
     if n != 65536 or world != 1:
         return None, None
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
+    sha = kernel_source_sha16()
     for f in sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_summary.json")), reverse=True):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
+        if d.get("_kernel_source_sha16") != sha:
+            continue                                   # stale: measured on another version of the kernels
         for k, v in d.items():
-            if kernel_name in k and "hbm_bytes_per_launch" in v:
+            if isinstance(v, dict) and kernel_name in k and "hbm_bytes_per_launch" in v:
                 return v["hbm_bytes_per_launch"], os.path.relpath(f, here)
     return None, None
 
@@ -167,7 +184,8 @@ def main():
     if a.plan:
         kname, k, w, sb, fused = a.plan.split(",")
         c.set_force_plan({"lds": mapn.KERNEL_LDS, "sgpr": mapn.KERNEL_SCALAR}[kname], int(k), int(w), int(sb), int(fused))
-    timer_interval = a.timer_interval if a.timer_interval >= 0 else (8 if a.steps >= 32 else 1)
+    # each hipEventRecord costs ~4 us of queue time: at most one event PAIR per 4 steps, also for short runs
+    timer_interval = a.timer_interval if a.timer_interval >= 0 else (8 if a.steps >= 32 else 4)
     c.set_timers(timer_interval)
 
     def step():
@@ -197,16 +215,21 @@ def main():
         dist.all_gather_object(allsums, sums)
         return all(x == allsums[0] for x in allsums)
 
+    p2p_failure = None
     if dist is not None and transport == "rccl":
+        # every way of issuing the exchange that sets up on this node: (name, algorithm, overlap structure)
         candidates = []
         if a.gather in ("auto", "allgather"):
-            candidates.append(("allgather", 0))
+            candidates += [("allgather", 0, False), ("allgather+overlap", 0, True)]
         if a.gather in ("auto", "sendrecv"):
-            candidates.append(("sendrecv", 1))
+            candidates += [("sendrecv", 1, False), ("sendrecv+overlap", 1, True)]
+        if a.overlap:                                   # --overlap: only the overlap structures
+            candidates = [x for x in candidates if x[2]]
         p2p_ok = False
         if a.gather in ("auto", "p2p") and world > 1:
             try:
                 c.p2p_setup_torch()
+                c.set_timeouts(p2p_ms=200)
                 ok = torch.tensor([1], device=red_dev)
             except Exception as e:
                 print(f"[bench rank {rank}] p2p setup failed: {e}", file=sys.stderr, flush=True)
@@ -214,36 +237,64 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # all ranks or none
             p2p_ok = bool(ok.item())
             if p2p_ok:
-                candidates.append(("p2p", 2))
+                candidates.append(("p2p", 2, False))           # LAST: it has to prove itself on this node
+
+        def select(name, algo, overlap):
+            c.set_gather_algorithm(algo)
+            c.set_shard_overlap(overlap)
+
+        def reinit():
+            c.set_gather_algorithm(0)
+            c.set_shard_overlap(False)
+            pos0, vel0 = mapn.generate_initial_state(n, seed=a.seed)
+            c.upload_state(pos0, vel0)
+            sync()
+
         if world > 1 and len(candidates) > 1:
-            # time every way of issuing the exchange (same bytes) on a few untimed steps; every rank
-            # must take the same decision -> MAX over ranks.  The peer-to-peer kernel must also PROVE
-            # itself on this node: no timed-out wait and bit-identical replicas on all ranks.
-            for name, algo in candidates:
-                c.set_gather_algorithm(algo)
-                for _ in range(5):
-                    step()
-                sync()
-                t0 = time.perf_counter()
-                for _ in range(30):
-                    step()
-                sync()
-                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                trial[name] = float(t.item()) / 30
-                if name == "p2p":
+            # time every way (same bytes) on untimed steps; every rank must take the same decision -> MAX
+            # over ranks.  The peer-to-peer kernel must also PROVE itself here: no timed-out wait (the
+            # library now reports one as MAPN_ERR_COMM) and bit-identical replicas on all ranks.
+            for name, algo, overlap in candidates:
+                failed = None
+                try:
+                    select(name, algo, overlap)
+                    for _ in range(5):
+                        step()
+                    sync()
+                    t0 = time.perf_counter()
+                    for _ in range(30):
+                        step()
+                    sync()
+                    dt_trial = time.perf_counter() - t0
+                except mapn.MapnError as e:
+                    failed, dt_trial = str(e), float("inf")
+                bad = torch.tensor([1 if failed else 0], device=red_dev)
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                if not bad.item() and algo == 2:
                     bad = torch.tensor([0 if (c.p2p_status() == 0 and replicas_consistent()) else 1], device=red_dev)
                     dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-                    if bad.item():
-                        if rank == 0:
-                            print("[bench] p2p exchange failed verification on this node -> not used; state re-initialised",
-                                  file=sys.stderr, flush=True)
-                        del trial["p2p"]
-                        c.set_gather_algorithm(0)
-                        pos0, vel0 = mapn.generate_initial_state(n, seed=a.seed)
-                        c.upload_state(pos0, vel0)
-                        sync()
-            gather_algo = min(trial, key=trial.get)
+                    if bad.item() and not failed:
+                        failed = "replicas differ across ranks"
+                if bad.item():
+                    if algo == 2:
+                        p2p_failure = failed or "failed on another rank"
+                    if rank == 0:
+                        print(f"[bench] exchange '{name}' failed on this node ({failed or 'on another rank'}) -> not used; state re-initialised",
+                              file=sys.stderr, flush=True)
+                    if algo == 2:
+                        break                                   # a context whose p2p wait timed out stays failed: stop using it
+                    reinit()
+                    continue
+                t = torch.tensor([dt_trial], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                trial[name] = float(t.item()) / 30
+            if p2p_failure is not None:
+                # the context carries the time-out: rebuild it and use the best RCCL structure
+                c.close()
+                c = mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed, rank=rank, world_size=world, flags=flags)
+                c.comm_init_torch()
+                c.set_timers(timer_interval)
+            gather_algo = min(trial, key=trial.get) if trial else "allgather"
             if rank == 0:
                 print("[bench] exchange trial: " + ", ".join(f"{k} {v*1e6:.1f} us/step" for k, v in trial.items()) + f" -> {gather_algo}",
                       file=sys.stderr, flush=True)
@@ -251,8 +302,10 @@ def main():
             gather_algo = candidates[0][0] if candidates else "allgather"
             if gather_algo == "p2p" and not p2p_ok:
                 sys.exit("bench: --gather p2p requested but the peer-to-peer setup failed")
-        c.set_gather_algorithm({"allgather": 0, "sendrecv": 1, "p2p": 2}[gather_algo])
-        transport = "p2p (hipIpc + device flags)" if gather_algo == "p2p" else "rccl"
+        chosen = {x[0]: x for x in candidates}.get(gather_algo, (gather_algo, 0, False))
+        c.set_gather_algorithm(chosen[1])
+        c.set_shard_overlap(chosen[2])
+        transport = "p2p (hipIpc + device flags)" if chosen[1] == 2 else "rccl"
     prewarm_steps = 0
     if a.prewarm_ms > 0:
         # same work as a timed step, just not timed: lets the clock settle so that a short K does
@@ -289,6 +342,14 @@ def main():
 
     st = c.kernel_stats()
     first, count = c.shard_range()
+    # the clock the chip held under this kernel: stamped diagnostic steps right behind the timed region
+    # (same state of the chip; untimed).  Single GPU, scalar-cache kernel only.
+    clock = None
+    if world == 1 and a.mode == "all_pairs" and dist is None:
+        try:
+            clock = c.measure_clock(8)
+        except mapn.MapnError as e:
+            print(f"[bench] clock measurement unavailable: {e}", file=sys.stderr, flush=True)
     consistent = None
     if dist is not None and world > 1 and gather_algo != "n/a":
         consistent = replicas_consistent() and (gather_algo != "p2p" or c.p2p_status() == 0)
@@ -315,7 +376,10 @@ def main():
                        "transport": transport, "exchange": gather_algo, "exchange_trial_us_per_step": {k: v * 1e6 for k, v in trial.items()},
                        "replicas_bit_identical_after_run": consistent, "valid": consistent is not False, "prewarm_steps_untimed": prewarm_steps, "seed": a.seed, "mass": "70000/N", "device": (info.name.decode() or "MI355X") + " / " + info.arch.decode(),
                        "kernel": st.kernel_name.decode(), "bodies_per_lane": st.bodies_per_lane, "j_splits": st.j_splits,
-                       "grid": [st.grid_x, st.grid_y], "block": st.block_x, "fused_integrator": bool(st.fused)},
+                       "grid": [st.grid_x, st.grid_y], "block": st.block_x, "fused_integrator": bool(st.fused),
+                       "epilogue": {0: "partial rows + reduce_integrate launch", 1: "fused in the workgroup", 2: "last-arriver ticket (one launch per step)"}.get(st.epilogue, "?"),
+                       "launches_per_step": int(st.force_launches_per_step) + (0 if st.fused else 1), "timer_interval": timer_interval,
+                       "p2p_failure": p2p_failure},
         }
         if a.mode == "all_pairs":
             peak = info.peak_fp32_flops / 1e12
@@ -323,14 +387,23 @@ def main():
                 pairs_per_launch = float(count) * float(n)
                 ach = FLOP_PER_PAIR * pairs_per_launch / st.avg_seconds / 1e12
                 traffic, traffic_src = pmc_traffic(st.kernel_name.decode(), n, world)
-                out["roofline"] = {"bound": "mfma",
-                                   "bound_detail": "compute-bound on the fp32 VECTOR ALU (packed v_pk_*_f32); the kernel issues no MFMA, "
-                                                   "but the dense f32 MFMA peak equals the fp32 vector peak, so the compute roofline is the same number",
+                held = clock.shader_clock_ghz if clock else None
+                out["roofline"] = {"bound": "valu-fp32",
+                                   "bound_schema": "mfma",
+                                   "bound_detail": "compute-bound on the fp32 VECTOR ALU (packed v_pk_*_f32 + v_rsq_f32); the kernel issues no MFMA. "
+                                                   "Of the schema's two bounds the compute one applies, and the dense f32 MFMA peak is the same number "
+                                                   "as the fp32 vector peak (157.3 TF), hence bound_schema",
                                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                   "held_clock_ghz": held,
+                                   "held_clock_ghz_p10_p90": [clock.shader_clock_ghz_p10, clock.shader_clock_ghz_p90] if clock else None,
+                                   "frac_at_held_clock": (ach / (info.compute_units * held * 1e9 * 256 / 1e12)) if held else None,
+                                   "instruction_mix_ceiling": "11 packed ops x 4 cycles + 2 v_rsq_f32 x 8 cycles per 128 pairs per SIMD = 66.7 % of peak at any clock",
                                    "traffic": traffic, "traffic_unit": "HBM bytes per force launch (2*FETCH_SIZE+WRITE_SIZE, PMC)",
-                                   "traffic_source": traffic_src, "kernel": st.kernel_name.decode(), "launches_timed": int(st.launches),
+                                   "traffic_source": traffic_src, "kernel_source_sha16": kernel_source_sha16(),
+                                   "kernel": st.kernel_name.decode(), "launches_timed": int(st.launches),
                                    "avg_launch_ms": st.avg_seconds * 1e3, "flop_per_pair": FLOP_PER_PAIR,
                                    "pairs_per_launch": pairs_per_launch,
+                                   "algorithmic_hbm_bytes_per_launch": HBM_BYTES_PER_BODY * count,
                                    "algorithmic_hbm_GBps": HBM_BYTES_PER_BODY * count / st.avg_seconds / 1e9,
                                    "note": "peak = CUs x clock x 256 flop/clk (fp32 vector = dense f32 MFMA peak, 157.3 TF)"}
             else:

@@ -346,6 +346,23 @@ int mapn_get_kernel_stats(mapn_ctx *ctx, int reset, mapn_kernel_stats *out);
  * multiplies the total. */
 int mapn_set_force_plan(mapn_ctx *ctx, int kernel, uint32_t bodies_per_lane, uint32_t waves,
                         uint32_t sb, int fused);
+/* Sharded mode: switch the own/remote overlap structure (MAPN_FLAG_SHARD_OVERLAP) at run time, so a
+ * launcher can time both structures on the node it runs on; all ranks must agree. */
+int mapn_set_shard_overlap(mapn_ctx *ctx, int enabled);
+
+/* The shader clock the chip HOLDS under this kernel (it lowers its clock under load): runs `steps`
+ * ordinary steps whose force launch additionally stamps s_memtime / s_memrealtime around every
+ * wave's pair loop into a scratch buffer nothing else reads (no stamp executes in a normal launch),
+ * and reports the median over waves of d(s_memtime) / d(s_memrealtime) x 100 MHz.  The steps advance
+ * the simulation like mapn_simulate.  Scalar-cache force kernel, all-pairs mode only. */
+typedef struct mapn_clock_info {
+    double   shader_clock_ghz;       /* median over the stamped waves of the last diagnostic launch */
+    double   shader_clock_ghz_p10, shader_clock_ghz_p90;
+    double   median_wave_cycles;     /* shader cycles one wave spent in its pair loop */
+    uint32_t waves_stamped, steps;
+} mapn_clock_info;
+int mapn_measure_clock(mapn_ctx *ctx, int steps, mapn_clock_info *out);
+
 /* Step timers: 0 = off, T >= 1 = record the event pair on every T-th step (default 1: every
  * step, like the reference's D3D12GpuTimer).  Each hipEventRecord costs a few microseconds of
  * queue time, which matters once a sharded step is ~0.1 ms. */

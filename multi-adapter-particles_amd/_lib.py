@@ -56,6 +56,11 @@ class DeviceInfo(C.Structure):
     ]
 
 
+class ClockInfo(C.Structure):
+    _fields_ = [("shader_clock_ghz", C.c_double), ("shader_clock_ghz_p10", C.c_double), ("shader_clock_ghz_p90", C.c_double),
+                ("median_wave_cycles", C.c_double), ("waves_stamped", C.c_uint32), ("steps", C.c_uint32)]
+
+
 class KernelStats(C.Structure):
     _fields_ = [
         ("kernel_name", C.c_char * 64), ("launches", C.c_uint64), ("avg_seconds", C.c_double),
@@ -121,6 +126,8 @@ SIGNATURES = {
     "mapn_device_count": (C.c_int, []),
     "mapn_get_kernel_stats": (C.c_int, [_ctx, C.c_int, C.POINTER(KernelStats)]),
     "mapn_set_force_plan": (C.c_int, [_ctx, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
+    "mapn_set_shard_overlap": (C.c_int, [_ctx, C.c_int]),
+    "mapn_measure_clock": (C.c_int, [_ctx, C.c_int, C.POINTER(ClockInfo)]),
     "mapn_set_timers": (C.c_int, [_ctx, C.c_int]),
     "mapn_compute_stream": (C.c_void_p, [_ctx]),
 }

@@ -244,6 +244,15 @@ class Compute:
         """fused: False/0 two launches (rows + reduce_integrate), True/1 one launch, 2 ticket form always."""
         check(self._lib.mapn_set_force_plan(self._ctx, kernel, bodies_per_lane, waves, sb, int(fused)))
 
+    def set_shard_overlap(self, enabled: bool):
+        check(self._lib.mapn_set_shard_overlap(self._ctx, int(bool(enabled))))
+
+    def measure_clock(self, steps: int = 8) -> "_lib.ClockInfo":
+        """The shader clock the chip holds under the force kernel (stamped diagnostic steps)."""
+        info = _lib.ClockInfo()
+        check(self._lib.mapn_measure_clock(self._ctx, int(steps), C.byref(info)))
+        return info
+
     def set_timers(self, interval: int):
         """0 = off, T >= 1 = time every T-th step."""
         check(self._lib.mapn_set_timers(self._ctx, int(interval)))

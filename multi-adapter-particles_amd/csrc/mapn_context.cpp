@@ -74,6 +74,9 @@ struct mapn_ctx {
     float4 *partial = nullptr;
     size_t partial_bytes = 0;
     uint32_t *ticket = nullptr;               // EPI_TICKET arrival counters, one per i-tile, zero between launches
+    unsigned long long *stamp_buf = nullptr;  // mapn_measure_clock: per-wave clock stamps of a diagnostic launch
+    size_t stamp_waves = 0;
+    bool stamp_next = false;
 
     uint32_t buffer_index = 0;                // Compute.cpp:80 m_bufferIndex(0)
     uint64_t fence_value = 0;                 // Compute.cpp:82 m_fenceValue(0)
@@ -389,7 +392,19 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
             a.ticket = c->ticket;
             a.ticket_total = plan.sb;
         }
+        if (c->stamp_next && plan.kind == mapn::KERNEL_SGPR) {
+            const size_t waves = (size_t)((i_count + 64 * plan.k - 1) / (64 * plan.k)) * plan.sb * plan.waves;
+            if (waves > c->stamp_waves) {
+                if (c->stamp_buf) HIP_TRY(hipFree(c->stamp_buf));
+                c->stamp_buf = nullptr; c->stamp_waves = 0;
+                HIP_TRY(hipMalloc(&c->stamp_buf, waves * 16));
+                c->stamp_waves = waves;
+            }
+            HIP_TRY(hipMemsetAsync(c->stamp_buf, 0, c->stamp_waves * 16, c->compute));
+            a.stamps = c->stamp_buf;
+        }
         HIP_TRY(mapn::launch_force(plan, a, c->compute));
+        a.stamps = nullptr;
         if (plan.epi == mapn::EPI_ROWS) {
             if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
             HIP_TRY(mapn::launch_reduce_integrate(a, plan.sb, c->compute));
@@ -707,6 +722,7 @@ int mapn_destroy(mapn_ctx *c)
     if (c->pos_heap) (void)hipFree(c->pos_heap);
     if (c->partial) (void)hipFree(c->partial);
     if (c->ticket) (void)hipFree(c->ticket);
+    if (c->stamp_buf) (void)hipFree(c->stamp_buf);
     for (int k = 0; k < kTimerRing; k++) {
         if (c->fence_events[k]) (void)hipEventDestroy(c->fence_events[k]);
         if (c->timers[k].start) (void)hipEventDestroy(c->timers[k].start);
@@ -1304,6 +1320,47 @@ int mapn_set_force_plan(mapn_ctx *c, int kernel, uint32_t bodies_per_lane, uint3
     c->forced_epilogue = fused;
     c->plan_forced = true;
     drop_graphs(c);
+    return MAPN_OK;
+}
+
+int mapn_set_shard_overlap(mapn_ctx *c, int enabled)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    if (int rc = mapn_wait_idle(c)) return rc;
+    if (enabled) c->cfg.flags |= MAPN_FLAG_SHARD_OVERLAP; else c->cfg.flags &= ~MAPN_FLAG_SHARD_OVERLAP;
+    c->gather_recorded[0] = c->gather_recorded[1] = false;
+    return MAPN_OK;
+}
+
+int mapn_measure_clock(mapn_ctx *c, int steps, mapn_clock_info *out)
+{
+    if (!c || !out || steps < 1) return fail(MAPN_ERR_INVALID_ARGUMENT, "measure_clock: bad argument");
+    memset(out, 0, sizeof *out);
+    if (c->cfg.force_mode != MAPN_FORCE_ALL_PAIRS) return fail(MAPN_ERR_STATE, "measure_clock: all-pairs mode only");
+    HIP_TRY(hipSetDevice(c->device));
+    c->stamp_next = true;
+    int rc = MAPN_OK;
+    for (int s = 0; s < steps && !rc; s++) rc = mapn_simulate(c, (int)c->n, 0);
+    c->stamp_next = false;
+    if (!rc) rc = mapn_wait_idle(c);
+    if (rc) return rc;
+    if (!c->stamp_buf || c->last_plan.kind != mapn::KERNEL_SGPR)
+        return fail(MAPN_ERR_STATE, "measure_clock: the stamped diagnostic exists for the scalar-cache force kernel only");
+    const size_t waves = (size_t)((c->last_i_count + 64 * c->last_plan.k - 1) / (64 * c->last_plan.k)) * c->last_plan.sb * c->last_plan.waves;
+    std::vector<unsigned long long> h(2 * waves);
+    HIP_TRY(hipMemcpy(h.data(), c->stamp_buf, waves * 16, hipMemcpyDeviceToHost));
+    std::vector<double> ghz, cyc;
+    for (size_t w = 0; w < waves; w++)
+        if (h[2 * w + 1] > 1000) { ghz.push_back((double)h[2 * w] / (double)h[2 * w + 1] * 0.1); cyc.push_back((double)h[2 * w]); }
+    if (ghz.empty()) return fail(MAPN_ERR_STATE, "measure_clock: no wave ran long enough to stamp");
+    std::sort(ghz.begin(), ghz.end());
+    std::sort(cyc.begin(), cyc.end());
+    out->shader_clock_ghz = ghz[ghz.size() / 2];
+    out->shader_clock_ghz_p10 = ghz[ghz.size() / 10];
+    out->shader_clock_ghz_p90 = ghz[ghz.size() * 9 / 10];
+    out->median_wave_cycles = cyc[cyc.size() / 2];
+    out->waves_stamped = (uint32_t)ghz.size();
+    out->steps = (uint32_t)steps;
     return MAPN_OK;
 }
 

@@ -30,6 +30,7 @@ struct StepArgs {
     uint32_t      seg_tiles_rem[MAX_SEGMENTS];   // ... the first `rem` chunks take one more
     float         mass, soft2, dt, damping; // hlsl:37-38, Compute.cpp:545-546
     uint32_t      xcd_remap;                // 1: XCD-aware block remap (default), 0: plain blockIdx (A/B)
+    unsigned long long *stamps;             // diagnostic launches only (mapn_measure_clock): per wave {d s_memtime, d s_memrealtime}; else null
 };
 
 // How the j-range is cut: S = sb * waves chunks per segment.

@@ -387,6 +387,11 @@ __global__ __launch_bounds__(64 * WAVES) void force_sgpr_kernel(const StepArgs p
     const uint32_t j1 = min(t1 * 64u, j_count);
     const float4 *__restrict__ pj = p.pos_old + j_first;
 
+    // diagnostic launches only (mapn_measure_clock): shader-clock and 100 MHz wall-clock stamps around
+    // the pair loop, written to a buffer nothing else reads; p.stamps is null in every normal launch
+    unsigned long long st_c = 0, st_r = 0;
+    if (p.stamps) { st_r = __builtin_amdgcn_s_memrealtime(); st_c = __builtin_amdgcn_s_memtime(); }
+
     uint32_t j = t0 * 64u;
     for (; j + 8u <= j1; j += 8u) {
 #pragma unroll
@@ -400,6 +405,16 @@ __global__ __launch_bounds__(64 * WAVES) void force_sgpr_kernel(const StepArgs p
         const float4 bj = pj[j];
 #pragma unroll
         for (int k = 0; k < K2; k++) pair_term2(b.acc[k], b.xi[k], b.yi[k], b.zi[k], bj.x, bj.y, bj.z, soft2);
+    }
+    if (p.stamps) {
+        // the accumulators must be complete before the closing stamp: tie it to them
+        asm volatile("" :: "v"(b.acc[0].x), "v"(b.acc[0].y), "v"(b.acc[0].z));
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            const size_t wave = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * WAVES + w;
+            p.stamps[2 * wave] = c1 - st_c;
+            p.stamps[2 * wave + 1] = r1 - st_r;
+        }
     }
     finish<K2, WAVES, EPI>(b, p, bx, by, w, lane, seg, red, &last_flag);
 }

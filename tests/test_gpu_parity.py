@@ -607,6 +607,10 @@ def test_config3_one_rank_share_of_the_8_gpu_1mi_body_job(oracle, rank, monkeypa
     first = rank * count
     sub = first + 37 * 64
     rp, rv = oracle.step_slice(pos, vel, sub, 4096, params=Params(mass=mass))
+    # w = |a| is compared with the fp64-ACCUMULATED oracle: at 1 Mi terms the reference order's single
+    # running fp32 sum is itself ~2e-4 off (measured: device vs reference order 2.4e-4, see below)
+    from oracle import SumSpec, SUM_FP64_ACC
+    rp_acc, _ = oracle.step_slice(pos, vel, sub, 4096, params=Params(mass=mass), sum_spec=SumSpec(SUM_FP64_ACC))
     with mapn.Compute(n, mass=mass, rank=rank, world_size=world) as c:
         assert c.shard_range() == (first, count)
         np.testing.assert_array_equal(c.download_state()[0], pos)
@@ -617,7 +621,8 @@ def test_config3_one_rank_share_of_the_8_gpu_1mi_body_job(oracle, rank, monkeypa
         assert st.force_launches_per_step == 1 and st.fused == 1
     assert errs(p[sub:sub + 4096, :3], rp[:, :3], SPREAD)[0] < 1e-6
     assert errs(v[sub:sub + 4096], rv, SPEED)[0] < 2e-5
-    assert np.abs(p[sub:sub + 4096, 3] - rp[:, 3]).max() / rp[:, 3].max() < 2e-4
+    assert np.abs(p[sub:sub + 4096, 3] - rp_acc[:, 3]).max() / rp_acc[:, 3].max() < 2e-5
+    assert np.abs(p[sub:sub + 4096, 3] - rp[:, 3]).max() / rp[:, 3].max() < 1e-3
     outside = np.ones(n, bool); outside[first:first + count] = False
     np.testing.assert_array_equal(p[outside], pos[outside])           # other ranks' bodies: not this rank's to move
     np.testing.assert_array_equal(v[outside], vel[outside])

@@ -12,12 +12,15 @@ double on double state).  Statements asserted, all on ||dx_i|| / ||x_i|| over th
       another one amplify a 1-ulp difference: SURVEY F4's chaos) and is bounded at 5e-3 only.
   T2  device vs ref after 100 steps: max <= 2e-6 (every body far inside 1e-4).
   T3  attribution: the device is no farther from either yardstick than the reference-order oracle is --
-      err(device, acc64) <= 1.5 x err(ref, acc64) and err(device, f64) <= 1.5 x err(ref, f64) for
-      median and RMS at 100 and 1000 steps.  I.e. the device-vs-ref difference is the fp32
-      summation order of `ref` itself, amplified by the dynamics -- not a kernel defect.
+      err(device, acc64) <= 1.5 x err(ref, acc64) for median, RMS AND max at 100 and 1000 steps, and
+      err(device, f64) <= 1.5 x err(ref, f64) for median and RMS at 100 steps (the double leg stops
+      there: it costs 10x an fp32 leg; its 1000-step numbers are in profiles/r02_parity_1000_65536_all_legs.json).
+      I.e. the device-vs-ref difference is the fp32 summation order of `ref` itself (one running sum
+      over 65 536 terms), amplified by the dynamics -- not a kernel defect.  Measured: device vs acc64
+      after 1000 steps max 9.7e-5 (NO body beyond 1e-4), ref vs acc64 max 4.3e-4 (9 bodies beyond).
   T4  device vs matched (only v_rsq_f32 differs): tighter than T1/T2 by the bounds written below.
 
-The oracle legs take ~3-4 minutes on the GPU box's host cores (4 x 4.3e12 pair terms).
+The oracle legs take ~4 minutes on the GPU box's host cores (ref 42 s, matched 37 s, acc64 122 s, f64 to 100 steps 43 s).
 """
 import json
 import os
@@ -34,7 +37,7 @@ def report():
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from parity_report import run_report
-    rep = run_report(65536, (1, 10, 100, 1000), log=lambda s: print(s, flush=True))
+    rep = run_report(65536, (1, 10, 100, 1000), f64_max_steps=100, log=lambda s: print(s, flush=True))
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         json.dump(rep, open(os.path.join(out, "parity_1000_65536.json"), "w"), indent=1)
@@ -65,12 +68,18 @@ def test_t2_device_vs_reference_order_oracle_after_100_steps(report):
 
 @pytest.mark.parametrize("yardstick", ["acc64", "f64"])
 def test_t3_device_is_no_farther_from_the_yardsticks_than_the_oracle_is(report, yardstick):
-    for steps in (100, 1000):
+    for steps in ((100, 1000) if yardstick == "acc64" else (100,)):     # the double leg stops at 100 steps (cost)
         dev, ref = _row(report, steps, "device", yardstick), _row(report, steps, "ref", yardstick)
         print(f"@{steps} vs {yardstick}: device median {dev['median']:.3e} rms {dev['rms']:.3e} max {dev['max']:.3e} | "
               f"ref median {ref['median']:.3e} rms {ref['rms']:.3e} max {ref['max']:.3e}")
         assert dev["median"] <= 1.5 * ref["median"], (steps, dev, ref)
         assert dev["rms"] <= 1.5 * ref["rms"], (steps, dev, ref)
+        if yardstick == "acc64":
+            # the MAXIMUM too: measured (round 2) device vs acc64 9.7e-5 -- inside 1e-4 -- against 4.3e-4 for the
+            # reference-order oracle vs its own double-accumulated twin: the 4.2e-4 of T1 is the ORACLE's summation error
+            assert dev["max"] <= 1.5 * ref["max"], (steps, dev, ref)
+            if steps == 1000:
+                assert dev["max"] <= 3e-4 and dev["n_over_1e-4"] <= 3, dev
 
 
 def test_t4_device_vs_order_matched_oracle_differs_by_rsq_only(report):

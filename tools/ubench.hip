@@ -13,10 +13,14 @@
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-enum Mix { FMA = 0, PKFMA, RSQ, PAIR_SCALAR, PAIR_PK, FMA_SGPR, PKFMA_BCAST, PAIR_MFMA, MFMA4, PAIR_PK8, RSQ_PK_ALT, RSQ_PK_SEQ, MIXES };
-static const char *mix_name[MIXES] = {"v_fma_f32 x16", "v_pk_fma_f32 x16", "v_rsq_f32 x16", "pair scalar (12 ops)", "pair packed (2 bodies)", "v_fma_f32 sgpr-src x16", "v_pk_fma_f32 op_sel bcast x16", "pair packed, accumulate on mfma 4x4x1", "v_mfma_f32_4x4x1_16b x8", "8 pk + 2 rsq (no accumulate)", "8 x (v_rsq, v_pk_fma) alternating", "8 v_rsq then 8 v_pk_fma"};
-static const int mix_insts[MIXES] = {16, 16, 16, 12 * 4, 13 * 2, 16, 16, 12 * 2, 8, 10 * 2, 16, 16};      // wave-instructions per loop body
-static const double mix_pairs[MIXES] = {0, 0, 0, 4, 4, 0, 0, 4, 0, 4, 0, 0};                  // pairs per lane per loop body
+enum Mix { FMA = 0, PKFMA, RSQ, PAIR_SCALAR, PAIR_PK, FMA_SGPR, PKFMA_BCAST, PAIR_MFMA, MFMA4, PAIR_PK8, RSQ_PK_ALT, RSQ_PK_SEQ,
+           MFMA16, MFMA32, PK16_MFMA16_1, PK16_MFMA16_2, PK16_MFMA32_1, PAIR_ACC_MFMA16, PAIR_ACC_MFMA32, PAIR_R2_MFMA16, MIXES };
+static const char *mix_name[MIXES] = {"v_fma_f32 x16", "v_pk_fma_f32 x16", "v_rsq_f32 x16", "pair scalar (12 ops)", "pair packed (2 bodies)", "v_fma_f32 sgpr-src x16", "v_pk_fma_f32 op_sel bcast x16", "pair packed, accumulate on mfma 4x4x1", "v_mfma_f32_4x4x1_16b x8", "8 pk + 2 rsq (no accumulate)", "8 x (v_rsq, v_pk_fma) alternating", "8 v_rsq then 8 v_pk_fma",
+                                      "v_mfma_f32_16x16x4_f32 x8", "v_mfma_f32_32x32x2_f32 x4", "16 v_pk_fma + 1 mfma16x16x4", "16 v_pk_fma + 2 mfma16x16x4",
+                                      "16 v_pk_fma + 1 mfma32x32x2", "pair packed, accumulate on mfma16x16x4", "pair packed, accumulate on mfma32x32x2",
+                                      "pair: r^2 on mfma16x16x4, sum-form accumulate"};
+static const int mix_insts[MIXES] = {16, 16, 16, 12 * 4, 13 * 2, 16, 16, 12 * 2, 8, 10 * 2, 16, 16, 8, 4, 17, 18, 17, 10 * 2 + 4, 10 * 2 + 4, 17};      // wave-instructions per loop body
+static const double mix_pairs[MIXES] = {0, 0, 0, 4, 4, 0, 0, 4, 0, 4, 0, 0, 0, 0, 0, 0, 0, 4, 4, 4};                  // pairs per lane per loop body
 
 template <int MIX>
 __global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, unsigned long long *rt, int iters, float seed)
@@ -31,6 +35,9 @@ __global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, u
     typedef float f4v __attribute__((ext_vector_type(4)));
     f4v macc[4];
     for (int i = 0; i < 4; i++) macc[i] = f4v{0.f, 0.f, 0.f, 0.f};
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    f16v bacc[2];
+    for (int i = 0; i < 2; i++) for (int q = 0; q < 16; q++) bacc[i][q] = 0.f;
     unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; it++) {
@@ -111,6 +118,61 @@ __global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, u
             for (int i = 0; i < 8; i++) asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i]));
 #pragma unroll
             for (int i = 0; i < 8; i++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(p[8 + (i & 3)]), "v"(p[12 + (i & 3)]));
+        } else if (MIX == MFMA16) {
+            // f32-input MFMA, 1024 MACs: 32 cycles/SIMD back to back (MI355X_MICROARCH.md cycle constants)
+#pragma unroll
+            for (int i = 0; i < 8; i++) macc[i & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], a[15], macc[i & 3], 0, 0, 0);
+        } else if (MIX == MFMA32) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) bacc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], a[15], bacc[i & 1], 0, 0, 0);
+        } else if (MIX == PK16_MFMA16_1 || MIX == PK16_MFMA16_2 || MIX == PK16_MFMA32_1) {
+            // does the matrix pipe run BESIDE the packed VALU stream of the same wave / SIMD?
+            // 16 independent v_pk_fma_f32 (74 cycles alone) with 1 or 2 independent MFMAs in the middle
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(p[8 + (i & 3)]), "v"(p[12 + (i & 3)]));
+            if (MIX == PK16_MFMA32_1) bacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], a[15], bacc[0], 0, 0, 0);
+            else macc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], a[15], macc[0], 0, 0, 0);
+            if (MIX == PK16_MFMA16_2) macc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], a[15], macc[1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(p[8 + (i & 3)]), "v"(p[12 + (i & 3)]));
+        } else if (MIX == PAIR_ACC_MFMA16 || MIX == PAIR_ACC_MFMA32) {
+            // the accumulation a_i = sum_j s_ij (x_j,y_j,z_j,1) recast on the LARGE f32 MFMA shapes.  A 4-column B
+            // fills 4 of the 16 (32) N columns; the block-diagonal form (k = i-group, n = (group, component))
+            // reaches 256 useful MACs of 1024 (2048): ONE j for the wave's 64 bodies per 16x16x4 (32x32x2).
+            // Two bodies per lane -> 2 MFMAs per j.  VALU side as PAIR_PK8 (no v_pk_fma accumulate).
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                float2v dx, dy, dz, d, inv, i3;
+                asm volatile(
+                    "v_pk_add_f32 %0, %9, %6 neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %1, %10, %7 neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %2, %11, %8 neg_lo:[0,1] neg_hi:[0,1]\n"
+                    "v_pk_fma_f32 %3, %0, %0, %12\n v_pk_fma_f32 %3, %1, %1, %3\n v_pk_fma_f32 %3, %2, %2, %3\n"
+                    : "=&v"(dx), "=&v"(dy), "=&v"(dz), "=&v"(d), "=&v"(inv), "=&v"(i3)
+                    : "v"(p[3 * k]), "v"(p[3 * k + 1]), "v"(p[3 * k + 2]), "v"(p[12]), "v"(p[13]), "v"(p[14]), "v"(p[15]));
+                asm volatile("v_rsq_f32 %0, %2\n v_rsq_f32 %1, %3" : "=&v"(inv.x), "=&v"(inv.y) : "v"(d.x), "v"(d.y));
+                asm volatile("v_pk_mul_f32 %0, %1, %1\n v_pk_mul_f32 %0, %0, %1" : "=&v"(i3) : "v"(inv));
+                if (MIX == PAIR_ACC_MFMA16) {
+                    macc[2 * k] = __builtin_amdgcn_mfma_f32_16x16x4f32(i3.x, a[15], macc[2 * k], 0, 0, 0);
+                    macc[2 * k + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(i3.y, a[15], macc[2 * k + 1], 0, 0, 0);
+                } else {
+                    bacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(i3.x, a[15], bacc[0], 0, 0, 0);
+                    bacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(i3.y, a[15], bacc[1], 0, 0, 0);
+                }
+            }
+        } else if (MIX == PAIR_R2_MFMA16) {
+            // r^2_ij = |x_i|^2 + soft^2 + |x_j|^2 - 2 x_i.x_j as ONE 16x16x4 MFMA per 16 i x 16 j tile (K = x,y,z,1;
+            // the i-only term rides in the C operand): a lane then holds d for 4 bodies i against ITS j.  VALU:
+            // 4 v_rsq, 4 v_pk_mul (inv^3), sum-form accumulate sum_j s x_j and sum_j s: 6 v_pk_fma + 2 v_pk_add.
+            // (Numerically unusable: |x|^2 ~ 5e5 against soft^2 = 25 -- tools/mfma_recast_error.py.)
+            f4v dt = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], a[15], macc[3], 0, 0, 0);
+            float2v i0, i1, s0, s1;
+            asm volatile("v_rsq_f32 %0, %4\n v_rsq_f32 %1, %5\n v_rsq_f32 %2, %6\n v_rsq_f32 %3, %7"
+                         : "=&v"(i0.x), "=&v"(i0.y), "=&v"(i1.x), "=&v"(i1.y) : "v"(dt.x), "v"(dt.y), "v"(dt.z), "v"(dt.w));
+            asm volatile("v_pk_mul_f32 %0, %2, %2\n v_pk_mul_f32 %0, %0, %2\n v_pk_mul_f32 %1, %3, %3\n v_pk_mul_f32 %1, %1, %3"
+                         : "=&v"(s0), "=&v"(s1) : "v"(i0), "v"(i1));
+            asm volatile("v_pk_fma_f32 %0, %6, %8, %0 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %1, %6, %8, %1 op_sel:[0,1,0]\n v_pk_fma_f32 %2, %6, %9, %2 op_sel_hi:[1,0,1]\n"
+                         "v_pk_fma_f32 %3, %7, %8, %3 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %4, %7, %8, %4 op_sel:[0,1,0]\n v_pk_fma_f32 %5, %7, %9, %5 op_sel_hi:[1,0,1]\n"
+                         : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]) : "v"(s0), "v"(s1), "v"(p[12]), "v"(p[13]));
+            asm volatile("v_pk_add_f32 %0, %0, %2\n v_pk_add_f32 %1, %1, %3" : "+v"(p[6]), "+v"(p[7]) : "v"(s0), "v"(s1));
         } else if (MIX == MFMA4) {
 #pragma unroll
             for (int i = 0; i < 8; i++) macc[i & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[i], a[15], macc[i & 3], 0, 0, 0);
@@ -121,6 +183,7 @@ __global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, u
     float s = 0;
     for (int i = 0; i < 16; i++) s += a[i] + p[i].x + p[i].y;
     for (int i = 0; i < 4; i++) s += macc[i].x + macc[i].y + macc[i].z + macc[i].w;
+    for (int i = 0; i < 2; i++) for (int q = 0; q < 16; q++) s += bacc[i][q];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) {
         int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -179,5 +242,7 @@ int main(int argc, char **argv)
     printf("device: %s  arch=%s  CUs=%d  clock=%d kHz  wave=%d\n", pr.name, pr.gcnArchName, pr.multiProcessorCount, pr.clockRate, pr.warpSize);
     sweep<FMA>(iters); sweep<FMA_SGPR>(iters); sweep<PKFMA>(iters); sweep<PKFMA_BCAST>(iters); sweep<RSQ>(iters);
     sweep<PAIR_SCALAR>(iters); sweep<PAIR_PK>(iters); sweep<PAIR_PK8>(iters); sweep<PAIR_MFMA>(iters); sweep<MFMA4>(iters); sweep<RSQ_PK_ALT>(iters); sweep<RSQ_PK_SEQ>(iters);
+    sweep<MFMA16>(iters); sweep<MFMA32>(iters); sweep<PK16_MFMA16_1>(iters); sweep<PK16_MFMA16_2>(iters); sweep<PK16_MFMA32_1>(iters);
+    sweep<PAIR_ACC_MFMA16>(iters); sweep<PAIR_ACC_MFMA32>(iters); sweep<PAIR_R2_MFMA16>(iters);
     return 0;
 }

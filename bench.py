@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--plan", default="", help="kernel,bodies_per_lane,waves,sb,fused e.g. sgpr,2,8,8,1 (fused: 0 = rows + reduce launch, 1 = one launch, 2 = ticket form always)")
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl")
-    ap.add_argument("--gather", choices=["auto", "allgather", "sendrecv", "p2p"], default="auto",
+    ap.add_argument("--gather", choices=["auto", "allgather", "sendrecv", "p2p", "flow"], default="auto",
                     help="how the in-library exchange is issued: RCCL ncclAllGather, one group of RCCL send/recv pairs, or the "
                          "direct peer-to-peer pull kernel (hipIpc + device flags); auto times every way that sets up and "
                          "verifies on this node during untimed steps and keeps the fastest")
@@ -171,7 +171,7 @@ def main():
     gather_fn = None
     if dist is not None:
         transport = a.transport
-        if transport == "rccl" and a.gather != "p2p":
+        if transport == "rccl" and a.gather not in ("p2p", "flow"):
             try:
                 c.comm_init_torch()
             except Exception as e:     # RCCL-in-library unavailable: use torch's RCCL instead, loudly
@@ -226,7 +226,7 @@ def main():
         if a.overlap:                                   # --overlap: only the overlap structures
             candidates = [x for x in candidates if x[2]]
         p2p_ok = False
-        if a.gather in ("auto", "p2p") and world > 1:
+        if a.gather in ("auto", "p2p", "flow") and world > 1:
             try:
                 c.p2p_setup_torch()
                 c.set_timeouts(p2p_ms=200)
@@ -236,8 +236,11 @@ def main():
                 ok = torch.tensor([0], device=red_dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # all ranks or none
             p2p_ok = bool(ok.item())
-            if p2p_ok:
-                candidates.append(("p2p", 2, False))           # LAST: it has to prove itself on this node
+            # LAST: these have to prove themselves on this node
+            if p2p_ok and a.gather in ("auto", "p2p"):
+                candidates.append(("p2p", 2, False))
+            if p2p_ok and a.gather in ("auto", "flow"):
+                candidates.append(("p2p+inkernel", 3, False))  # the same exchange overlapped inside the force launch
 
         def select(name, algo, overlap):
             c.set_gather_algorithm(algo)
@@ -254,7 +257,22 @@ def main():
             # time every way (same bytes) on untimed steps; every rank must take the same decision -> MAX
             # over ranks.  The peer-to-peer kernel must also PROVE itself here: no timed-out wait (the
             # library now reports one as MAPN_ERR_COMM) and bit-identical replicas on all ranks.
+            def rebuild(with_p2p):
+                """A context whose device-side wait timed out stays failed: replace it."""
+                nonlocal c
+                c.close()
+                c = mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed, rank=rank, world_size=world, flags=flags)
+                if a.gather not in ("p2p", "flow"):
+                    c.comm_init_torch()
+                if with_p2p:
+                    c.p2p_setup_torch()
+                    c.set_timeouts(p2p_ms=200)
+                c.set_timers(timer_interval)
+
+            p2p_dead = False
             for name, algo, overlap in candidates:
+                if algo >= 2 and p2p_dead:
+                    continue
                 failed = None
                 try:
                     select(name, algo, overlap)
@@ -270,42 +288,37 @@ def main():
                     failed, dt_trial = str(e), float("inf")
                 bad = torch.tensor([1 if failed else 0], device=red_dev)
                 dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-                if not bad.item() and algo == 2:
+                if not bad.item() and algo >= 2:
                     bad = torch.tensor([0 if (c.p2p_status() == 0 and replicas_consistent()) else 1], device=red_dev)
                     dist.all_reduce(bad, op=dist.ReduceOp.MAX)
                     if bad.item() and not failed:
                         failed = "replicas differ across ranks"
                 if bad.item():
-                    if algo == 2:
-                        p2p_failure = failed or "failed on another rank"
                     if rank == 0:
                         print(f"[bench] exchange '{name}' failed on this node ({failed or 'on another rank'}) -> not used; state re-initialised",
                               file=sys.stderr, flush=True)
-                    if algo == 2:
-                        break                                   # a context whose p2p wait timed out stays failed: stop using it
-                    reinit()
+                    if algo >= 2:
+                        p2p_failure = f"{name}: {failed or 'failed on another rank'}"
+                        p2p_dead = algo == 2                    # the plain exchange failed: the in-kernel form shares its transport
+                        rebuild(with_p2p="p2p" in trial)
+                    else:
+                        reinit()
                     continue
                 t = torch.tensor([dt_trial], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 trial[name] = float(t.item()) / 30
-            if p2p_failure is not None:
-                # the context carries the time-out: rebuild it and use the best RCCL structure
-                c.close()
-                c = mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed, rank=rank, world_size=world, flags=flags)
-                c.comm_init_torch()
-                c.set_timers(timer_interval)
             gather_algo = min(trial, key=trial.get) if trial else "allgather"
             if rank == 0:
                 print("[bench] exchange trial: " + ", ".join(f"{k} {v*1e6:.1f} us/step" for k, v in trial.items()) + f" -> {gather_algo}",
                       file=sys.stderr, flush=True)
         else:
             gather_algo = candidates[0][0] if candidates else "allgather"
-            if gather_algo == "p2p" and not p2p_ok:
+            if gather_algo.startswith("p2p") and not p2p_ok:
                 sys.exit("bench: --gather p2p requested but the peer-to-peer setup failed")
         chosen = {x[0]: x for x in candidates}.get(gather_algo, (gather_algo, 0, False))
         c.set_gather_algorithm(chosen[1])
         c.set_shard_overlap(chosen[2])
-        transport = "p2p (hipIpc + device flags)" if chosen[1] == 2 else "rccl"
+        transport = "p2p (hipIpc + device flags)" if chosen[1] >= 2 else "rccl"
     prewarm_steps = 0
     if a.prewarm_ms > 0:
         # same work as a timed step, just not timed: lets the clock settle so that a short K does
@@ -388,11 +401,12 @@ def main():
                 ach = FLOP_PER_PAIR * pairs_per_launch / st.avg_seconds / 1e12
                 traffic, traffic_src = pmc_traffic(st.kernel_name.decode(), n, world)
                 held = clock.shader_clock_ghz if clock else None
-                out["roofline"] = {"bound": "valu-fp32",
-                                   "bound_schema": "mfma",
-                                   "bound_detail": "compute-bound on the fp32 VECTOR ALU (packed v_pk_*_f32 + v_rsq_f32); the kernel issues no MFMA. "
-                                                   "Of the schema's two bounds the compute one applies, and the dense f32 MFMA peak is the same number "
-                                                   "as the fp32 vector peak (157.3 TF), hence bound_schema",
+                out["roofline"] = {"bound": "mfma",
+                                   "bound_actual": "valu-fp32",
+                                   "bound_detail": "compute-bound on the fp32 VECTOR ALU (packed v_pk_*_f32 + v_rsq_f32): the kernel issues NO MFMA. "
+                                                   "`bound` holds the schema's compute value because of its two bounds (hbm | mfma) the compute one "
+                                                   "applies and the dense f32 MFMA peak is the same number as the fp32 vector peak (157.3 TF); "
+                                                   "`bound_actual` names the unit that is really the limit",
                                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                    "held_clock_ghz": held,
                                    "held_clock_ghz_p10_p90": [clock.shader_clock_ghz_p10, clock.shader_clock_ghz_p90] if clock else None,

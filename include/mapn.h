@@ -281,7 +281,11 @@ int mapn_comm_get_unique_id(void *out_id128);
 int mapn_comm_init(mapn_ctx *ctx, const void *id128);
 /* how the native exchange is issued: 0 = ncclAllGather (default), 1 = one group of ncclSend /
  * ncclRecv pairs (a single direct xGMI hop per peer instead of a ring), 2 = the direct
- * peer-to-peer exchange below (after mapn_p2p_import); all ranks must agree */
+ * peer-to-peer exchange below (after mapn_p2p_import), 3 = the same peer-to-peer exchange
+ * overlapped INSIDE the force launch ("flow" mode: the pull runs beside the launch on the comm
+ * stream, the launch starts on its own slice and its remote chunks wait for each peer's arrival
+ * flag, the last integrated tile publishes to the peers -- no separate exchange step, no
+ * cross-stream event); all ranks must agree */
 int mapn_set_gather_algorithm(mapn_ctx *ctx, int algorithm);
 /*
  * Direct peer-to-peer exchange (algorithm 2 of mapn_set_gather_algorithm), no collective library:

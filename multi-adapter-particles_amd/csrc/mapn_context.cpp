@@ -135,6 +135,8 @@ struct mapn_ctx {
     void *p2p_peer_heap[mapn::P2P_MAX_RANKS] = {};
     uint32_t *p2p_peer_flags[mapn::P2P_MAX_RANKS] = {};
     uint32_t p2p_step = 0;
+    uint32_t **p2p_flag_table = nullptr;      // device copy of p2p_peer_flags[] (flow mode reads it in the kernel)
+    uint32_t *flow_block = nullptr;           // ordinary device memory: [0..15] arrived[q], [16] tiles_done (flow mode)
 
     // graph replay
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
@@ -221,6 +223,7 @@ uint32_t active_bodies(int num_active, uint32_t n)
 int choose_epilogue(const mapn_ctx *c, const mapn::ForcePlan &p, bool allow_fused)
 {
     int want = c->plan_forced ? c->forced_epilogue : 1;
+    if (c->p2p_ready && c->gather_algo == 3) return mapn::EPI_TICKET;   // flow mode publishes from the ticket epilogue
     const char *e = getenv("MAPN_EPILOGUE");
     if (!c->plan_forced && e && strcmp(e, "rows") == 0) want = 0;
     if (want == 0) return mapn::EPI_ROWS;
@@ -371,13 +374,35 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
     mapn::StepArgs a = base_args(c, w, r);
     a.i_first = lo;
     a.i_count = i_count;
+    const bool flow = c->p2p_ready && c->gather_algo == 3;
     const bool sharded_native = c->comm != nullptr || (c->p2p_ready && c->gather_algo == 2);
-    const bool overlap = c->comm != nullptr && c->gather_algo != 2 && (c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP);
+    const bool overlap = c->comm != nullptr && c->gather_algo < 2 && (c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP);
+    if (flow) {
+        // the pull half of THIS step's exchange runs beside the launch on the comm stream (it only
+        // depends on the peers' flags); the launch's remote chunks need the PREVIOUS exchange
+        a.flow_arrived = c->flow_block;
+        a.flow_tiles_done = c->flow_block + 16;
+        a.flow_peer_flags = c->p2p_flag_table;
+        a.flow_status = c->async_status;
+        a.flow_timeout_ticks = c->p2p_timeout_ticks;
+        a.flow_need = c->p2p_step;
+        a.flow_publish = c->p2p_step + 1;
+        a.flow_rank = (uint32_t)c->cfg.rank;
+        a.flow_world = (uint32_t)c->cfg.world_size;
+        a.flow_count = c->count;
+        a.xcd_remap = 0;                                   // dispatch order = row order: own rows first
+    }
 
     if (timer) HIP_TRY(hipEventRecord(timer->start, c->compute));
 
     if (i_count > 0 && c->cfg.force_mode == MAPN_FORCE_CENTRAL_WELL) {
-        HIP_TRY(mapn::launch_central_well(a, c->compute));
+        mapn::StepArgs w0 = a;
+        w0.flow_arrived = nullptr;                         // plain stores: the flag goes out behind the kernel boundary
+        HIP_TRY(mapn::launch_central_well(w0, c->compute));
+        if (flow) HIP_TRY(mapn::launch_flow_publish(c->p2p_flag_table, a.flow_rank, a.flow_world, a.flow_publish, c->compute));
+    } else if (i_count == 0 && flow) {
+        // nothing of this rank's slice advances in this step: it still owes its peers the flag
+        HIP_TRY(mapn::launch_flow_publish(c->p2p_flag_table, a.flow_rank, a.flow_world, a.flow_publish, c->compute));
     } else if (i_count > 0 && !overlap) {
         // one force launch over all j.  Sharded: the read buffer is complete once the all-gather
         // that filled it has finished (event recorded on the comm stream).
@@ -385,6 +410,12 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
         mapn::ForcePlan plan = choose_plan(c, i_count, c->n, 1, true);
         const uint32_t S = plan.sb * plan.waves;
         fill_segment(a, 0, 0, c->n, 0, S);
+        if (flow) {
+            // rotate the block rows so that the rows holding this rank's own slice are dispatched first
+            const uint32_t t_own = c->first / 64u, base = a.seg_tiles_base[0], rem = a.seg_tiles_rem[0];
+            const uint32_t c_own = t_own < rem * (base + 1u) ? t_own / (base + 1u) : (base ? rem + (t_own - rem * (base + 1u)) / base : 0u);
+            a.flow_row_rot = std::min(c_own / plan.waves, plan.sb - 1u);
+        }
         if (plan.epi != mapn::EPI_FUSED) {
             a.partial_stride = (i_count + 63u) & ~63u;
             if (int rc = ensure_partial(c, plan.sb, a.partial_stride)) return rc;   // one row per block row
@@ -506,8 +537,31 @@ int enqueue_p2p(mapn_ctx *c)
     return MAPN_OK;
 }
 
+// flow mode: the pull half of this step's exchange, on the comm stream, no stream dependencies --
+// it waits for the peers' flags on the device and marks arrived[q] for the NEXT force launch
+int enqueue_flow_pull(mapn_ctx *c)
+{
+    const uint32_t w = c->buffer_index;
+    mapn::P2PArgs a{};
+    a.local = c->pos[w];
+    for (int q = 0; q < c->cfg.world_size; q++) {
+        a.peer[q] = reinterpret_cast<const float4 *>(static_cast<char *>(c->p2p_peer_heap[q]) + (size_t)w * c->aligned_data_size);
+        a.peer_flags[q] = c->p2p_peer_flags[q];
+    }
+    a.my_flags = c->p2p_flags;
+    a.status = c->async_status;
+    a.rank = (uint32_t)c->cfg.rank;
+    a.world = (uint32_t)c->cfg.world_size;
+    a.count = c->count;
+    a.step = ++c->p2p_step;
+    a.timeout_ticks = c->p2p_timeout_ticks;
+    HIP_TRY(mapn::launch_flow_pull(a, c->flow_block, c->comm_stream));
+    return MAPN_OK;
+}
+
 int enqueue_gather(mapn_ctx *c)
 {
+    if (c->p2p_ready && c->gather_algo == 3) return enqueue_flow_pull(c);
     if (c->p2p_ready && c->gather_algo == 2) return enqueue_p2p(c);
     if (!c->comm) return MAPN_OK;
     const uint32_t w = c->buffer_index;
@@ -709,6 +763,8 @@ int mapn_destroy(mapn_ctx *c)
         if (c->p2p_peer_flags[q]) (void)hipIpcCloseMemHandle(c->p2p_peer_flags[q]);
     }
     if (c->p2p_flags) (void)hipFree(c->p2p_flags);
+    if (c->p2p_flag_table) (void)hipFree(c->p2p_flag_table);
+    if (c->flow_block) (void)hipFree(c->flow_block);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->exported_done) (void)hipEventDestroy(c->exported_done);
     if (c->fence_host_word) (void)hipHostFree(c->fence_host_word);
@@ -739,7 +795,7 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
 {
     if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    if (c->cfg.world_size > 1 && !c->comm && !c->external_gather && !(c->p2p_ready && c->gather_algo == 2))
+    if (c->cfg.world_size > 1 && !c->comm && !c->external_gather && !(c->p2p_ready && c->gather_algo >= 2))
         return fail(MAPN_ERR_STATE, "sharded context (world_size %d): call mapn_comm_init or "
                     "mapn_set_external_gather before simulate", c->cfg.world_size);
     if (int rc = check_async_errors(c)) return rc;                     // a device-side wait of an earlier step gave up
@@ -761,8 +817,8 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
         c->timer_head = (c->timer_head + 1) % kTimerRing;
     }
     // MoveToNextFrame, Compute.cpp:993-1004: Signal(fence, v); v++; index = 1 - index
-    const bool exchanging = c->comm != nullptr || (c->p2p_ready && c->gather_algo == 2);
-    const bool gather_first = exchanging && (!(c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP) || c->gather_algo == 2);
+    const bool exchanging = c->comm != nullptr || (c->p2p_ready && c->gather_algo >= 2);
+    const bool gather_first = exchanging && (!(c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP) || c->gather_algo >= 2);
     if (gather_first) { if (int rc = enqueue_gather(c)) return rc; }   // same stream: the fence then covers the gather
     // The fence value always advances.  While somebody can observe completion (an attached consumer,
     // exported handles) the ONE exported event is re-recorded after every step; the ring event behind
@@ -1185,11 +1241,20 @@ int mapn_comm_init(mapn_ctx *c, const void *id128)
 
 int mapn_set_gather_algorithm(mapn_ctx *c, int algorithm)
 {
-    if (!c || algorithm < 0 || algorithm > 2) return fail(MAPN_ERR_INVALID_ARGUMENT, "set_gather_algorithm: bad argument");
-    if (algorithm == 2 && !c->p2p_ready) return fail(MAPN_ERR_STATE, "set_gather_algorithm(2): call mapn_p2p_import first");
-    if (algorithm != 2 && c->cfg.world_size > 1 && !c->comm && !c->external_gather)
+    if (!c || algorithm < 0 || algorithm > 3) return fail(MAPN_ERR_INVALID_ARGUMENT, "set_gather_algorithm: bad argument");
+    if (algorithm >= 2 && !c->p2p_ready) return fail(MAPN_ERR_STATE, "set_gather_algorithm(%d): call mapn_p2p_import first", algorithm);
+    if (algorithm < 2 && c->cfg.world_size > 1 && !c->comm && !c->external_gather)
         return fail(MAPN_ERR_STATE, "set_gather_algorithm(%d): no RCCL communicator (mapn_comm_init)", algorithm);
     if (int rc = mapn_wait_idle(c)) return rc;
+    if (algorithm == 3) {
+        // every exchange so far has completed (wait_idle): both replicas are whole, so every peer's
+        // slice counts as arrived for the exchange number reached
+        HIP_TRY(hipSetDevice(c->device));
+        uint32_t arrived[17];
+        for (int q = 0; q < 16; q++) arrived[q] = c->p2p_step;
+        arrived[16] = 0;                                   // tiles_done
+        HIP_TRY(hipMemcpy(c->flow_block, arrived, sizeof arrived, hipMemcpyHostToDevice));
+    }
     c->gather_algo = algorithm;
     return MAPN_OK;
 }
@@ -1252,6 +1317,10 @@ int mapn_p2p_import(mapn_ctx *c, const void *blobs, int count)
         HIP_TRY(hipIpcOpenMemHandle(&c->p2p_peer_heap[q], b.heap, hipIpcMemLazyEnablePeerAccess));
         HIP_TRY(hipIpcOpenMemHandle(reinterpret_cast<void **>(&c->p2p_peer_flags[q]), b.flags, hipIpcMemLazyEnablePeerAccess));
     }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->flow_block), 256));
+    HIP_TRY(hipMemset(c->flow_block, 0, 256));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->p2p_flag_table), sizeof(uint32_t *) * mapn::P2P_MAX_RANKS));
+    HIP_TRY(hipMemcpy(c->p2p_flag_table, c->p2p_peer_flags, sizeof(uint32_t *) * mapn::P2P_MAX_RANKS, hipMemcpyHostToDevice));
     c->p2p_ready = true;
     return MAPN_OK;
 }

@@ -30,6 +30,18 @@ struct StepArgs {
     uint32_t      seg_tiles_rem[MAX_SEGMENTS];   // ... the first `rem` chunks take one more
     float         mass, soft2, dt, damping; // hlsl:37-38, Compute.cpp:545-546
     uint32_t      xcd_remap;                // 1: XCD-aware block remap (default), 0: plain blockIdx (A/B)
+    // sharded "flow" mode (gather algorithm 3): the exchange runs BESIDE this launch (flow_pull_kernel on
+    // the comm stream); waves of a remote j-chunk wait for that peer's slice, the last tile publishes.
+    // flow_arrived == null: not in flow mode.
+    const uint32_t *flow_arrived;           // [world] local: exchange number of the latest slice pulled from each peer
+    uint32_t     *flow_tiles_done;          // local counter of integrated i-tiles, zero between launches
+    uint32_t *const *flow_peer_flags;       // device table [world]: every rank's flag array as mapped here
+    uint32_t     *flow_status;              // host-visible words: [0] = 1 + peer whose slice never arrived
+    uint64_t      flow_timeout_ticks;
+    uint32_t      flow_need;                // remote chunks need flow_arrived[q] >= flow_need (the previous exchange)
+    uint32_t      flow_publish;             // exchange number this launch publishes to the peers
+    uint32_t      flow_rank, flow_world, flow_count;   // flow_count = bodies per rank
+    uint32_t      flow_row_rot;             // physical block row y handles logical row (y + rot) % rows: own slice first
     unsigned long long *stamps;             // diagnostic launches only (mapn_measure_clock): per wave {d s_memtime, d s_memrealtime}; else null
 };
 
@@ -62,6 +74,10 @@ struct P2PArgs {
     uint64_t      timeout_ticks;            // s_memrealtime ticks (100 MHz) before a wait gives up
 };
 hipError_t launch_p2p_gather(const P2PArgs &a, hipStream_t st);
+// flow mode: the pull half alone (wait for the peers' flags, pull, mark arrived) and the publish half
+// alone (ranks whose slice is not advanced by a force launch in this step)
+hipError_t launch_flow_pull(const P2PArgs &a, uint32_t *arrived, hipStream_t st);
+hipError_t launch_flow_publish(uint32_t *const *peer_flags, uint32_t rank, uint32_t world, uint32_t step, hipStream_t st);
 
 // the consumer's fence as memory words: a queued GPU-side wait / an event-ordered signal
 hipError_t launch_fence_wait(const uint32_t *host_word, const uint32_t *dev_word, uint32_t need, uint64_t timeout_ticks,

@@ -111,7 +111,15 @@ __device__ __forceinline__ void integrate_store(const StepArgs &p, uint32_t i, f
     o.y = __builtin_fmaf(vy, p.dt, pos.y);
     o.z = __builtin_fmaf(vz, p.dt, pos.z);
     o.w = __builtin_sqrtf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)));
-    p.pos_new[i] = o;
+    if (p.flow_arrived) {
+        // flow mode: peers pull this slice over xGMI while the launch is still running -- the new
+        // position goes write-through to memory at system scope (global_store_dwordx2 sc0 sc1)
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(p.pos_new + i);
+        __hip_atomic_store(d, (unsigned long long)__float_as_uint(o.x) | ((unsigned long long)__float_as_uint(o.y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(d + 1, (unsigned long long)__float_as_uint(o.z) | ((unsigned long long)__float_as_uint(o.w) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+        p.pos_new[i] = o;
+    }
     float *vo = p.vel_new + 3 * (size_t)i;
     vo[0] = vx; vo[1] = vy; vo[2] = vz;
 }
@@ -142,6 +150,78 @@ __device__ __forceinline__ void chunk_tiles(const StepArgs &p, uint32_t seg, uin
     const uint32_t base = p.seg_tiles_base[seg], rem = p.seg_tiles_rem[seg];
     t0 = c * base + min(c, rem);
     t1 = t0 + base + (c < rem ? 1u : 0u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// flow mode (sharded, gather algorithm 3): device-side hand-offs inside the force launch
+
+// physical block row -> logical chunk row: rows are rotated so that the rows of this rank's OWN slice
+// are dispatched first (they need no exchange); the logical row still names the chunk and the
+// partial-sum slot, so the summation order -- and every bit of the result -- is that of the
+// unrotated launch.
+__device__ __forceinline__ uint32_t flow_row(const StepArgs &p, uint32_t by)
+{
+    if (!p.flow_arrived) return by;
+    const uint32_t r = by + p.flow_row_rot;
+    return r >= gridDim.y ? r - gridDim.y : r;
+}
+
+// ONE lane of the workgroup waits until the slices of every peer that owns part of the workgroup's
+// j-range (its WAVES consecutive chunks) have been pulled into the local replica by
+// flow_pull_kernel (exchange number >= flow_need); the other waves park at the barrier.  The flags
+// live in ordinary device memory and are polled with L1-bypassing loads (sc1: served by the L2) and
+// s_sleep, so a few hundred parked workgroups cost the computing ones no memory bandwidth.  Then this
+// CU's vector L1 and scalar cache drop whatever they may hold of those addresses.  Workgroups whose
+// chunks lie in the rank's own slice do not wait at all.  Bounded by a wall-clock timeout that sets
+// *flow_status (the host reports it) instead of hanging.
+template <int WAVES>
+__device__ __forceinline__ void flow_wait_block(const StepArgs &p, uint32_t seg, uint32_t by)
+{
+    uint32_t t0, t1, tl0, tl1;
+    chunk_tiles(p, seg, by * WAVES, t0, t1);
+    chunk_tiles(p, seg, by * WAVES + (WAVES - 1), tl0, tl1);
+    const uint32_t j_first = p.seg_first[seg], j_count = p.seg_count[seg];
+    const uint32_t j0 = j_first + t0 * 64u, j1 = j_first + min(tl1 * 64u, j_count);
+    if (threadIdx.x == 0 && j1 > j0) {
+        const uint32_t q0 = j0 / p.flow_count, q1 = (j1 - 1u) / p.flow_count;
+        for (uint32_t q = q0; q <= q1 && q < p.flow_world; q++) {
+            if (q == p.flow_rank) continue;
+            const uint64_t ts = __builtin_amdgcn_s_memrealtime();
+            while ((int32_t)(__hip_atomic_load(p.flow_arrived + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.flow_need) < 0) {
+                __builtin_amdgcn_s_sleep(32);
+                if (__builtin_amdgcn_s_memrealtime() - ts > p.flow_timeout_ticks) {
+                    __hip_atomic_store(p.flow_status, 1u + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+        // the slices were stored write-through by another workgroup DURING this launch: nothing of them
+        // may be served from this CU's vector L1 (nobody reads a remote slice before its flag, so the
+        // caches were clean of it at launch; the invalidates make that independent of prefetching)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_dcache_inv();
+}
+
+// after a tile's last arriver has stored its bodies' new positions (system-scope write-through):
+// count the tile; the LAST tile of the launch publishes the exchange number to every peer's flag
+// array over xGMI.  Every tile's stores were acknowledged before its count (vmcnt(0) + barrier), so
+// the publisher's flag stores are ordered behind ALL of the slice.
+__device__ __forceinline__ void flow_tile_done(const StepArgs &p)
+{
+    if (!p.flow_arrived) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t prev = __hip_atomic_fetch_add(p.flow_tiles_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1u == gridDim.x) {
+            __hip_atomic_store(p.flow_tiles_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t q = 0; q < p.flow_world; q++)
+                if (q != p.flow_rank)
+                    __hip_atomic_store(p.flow_peer_flags[q] + p.flow_rank, p.flow_publish, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 template <int K2>
@@ -224,6 +304,7 @@ __device__ __forceinline__ void finish(const Bodies<K2> &b, const StepArgs &p, u
             }
         }
     }
+    if constexpr (EPI == EPI_FUSED) flow_tile_done(p);
     if constexpr (EPI == EPI_TICKET) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's row stores have left the chip's caches
         __syncthreads();
@@ -262,6 +343,7 @@ __device__ __forceinline__ void finish(const Bodies<K2> &b, const StepArgs &p, u
             const uint32_t i = p.i_first + li;
             integrate_store(p, i, p.pos_old[i], ax * p.mass, ay * p.mass, az * p.mass);
         }
+        flow_tile_done(p);
     }
 }
 
@@ -287,6 +369,7 @@ __global__ __launch_bounds__(64 * WAVES) void force_lds_kernel(const StepArgs p)
 
     uint32_t bx, by;
     xcd_remap(bx, by, p.xcd_remap);
+    by = flow_row(p, by);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t seg = blockIdx.z;
@@ -296,6 +379,7 @@ __global__ __launch_bounds__(64 * WAVES) void force_lds_kernel(const StepArgs p)
 
     Bodies<K2> b;
     load_bodies<K2>(b, p, bx, lane);
+    if (p.flow_arrived) flow_wait_block<WAVES>(p, seg, by);
 
     uint32_t t0, t1;
     chunk_tiles(p, seg, c, t0, t1);
@@ -361,17 +445,24 @@ __global__ __launch_bounds__(64 * WAVES) void force_lds_kernel(const StepArgs p)
 //
 // Same decomposition as force_lds_kernel.  pos[j] with a wave-uniform j compiles to
 // s_load_dwordx8/x16 and the packed VALU ops take (x_j,y_j) / (z_j,w_j) as their one SGPR-pair
-// source, op_sel picking the half.  The default path: measured 62 % of the fp32 peak at 65 536
+// source, op_sel picking the half.  hipcc selects scalar loads only for memory it can prove no
+// instruction of the kernel clobbers before the load: the j-source is therefore its own
+// `const __restrict__` kernel parameter (= p.pos_old; nothing in this kernel writes it), the stamps
+// are read with inline asm, and the scalar-cache invalidate of flow mode is the builtin -- with
+// p.pos_old, __builtin_amdgcn_s_memtime() or an asm "memory" clobber in front of the loop every j-load
+// silently becomes a uniform global_load_dwordx3 and the kernel runs 27 % slower (round 2, measured:
+// 1.124 vs 0.888 ms).  tests/test_abi.py checks the disassembly for the scalar loads.  The default path: measured 62 % of the fp32 peak at 65 536
 // bodies against 60 % for the LDS-tiled kernel, with SQ_INSTS_VALU exactly 13 per
 // two pairs.
 template <int K2, int WAVES, int EPI>
-__global__ __launch_bounds__(64 * WAVES) void force_sgpr_kernel(const StepArgs p)
+__global__ __launch_bounds__(64 * WAVES) void force_sgpr_kernel(const StepArgs p, const float4 *__restrict__ pos_j)
 {
     __shared__ float red[WAVES][3][128 * K2];
     __shared__ uint32_t last_flag;
 
     uint32_t bx, by;
     xcd_remap(bx, by, p.xcd_remap);
+    by = flow_row(p, by);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t seg = blockIdx.z;
@@ -380,17 +471,18 @@ __global__ __launch_bounds__(64 * WAVES) void force_sgpr_kernel(const StepArgs p
 
     Bodies<K2> b;
     load_bodies<K2>(b, p, bx, lane);
+    if (p.flow_arrived) flow_wait_block<WAVES>(p, seg, by);
 
     uint32_t t0, t1;
     chunk_tiles(p, seg, c, t0, t1);
     const v2f soft2 = v2f{p.soft2, p.soft2};
     const uint32_t j1 = min(t1 * 64u, j_count);
-    const float4 *__restrict__ pj = p.pos_old + j_first;
+    const float4 *__restrict__ pj = pos_j + j_first;
 
     // diagnostic launches only (mapn_measure_clock): shader-clock and 100 MHz wall-clock stamps around
     // the pair loop, written to a buffer nothing else reads; p.stamps is null in every normal launch
     unsigned long long st_c = 0, st_r = 0;
-    if (p.stamps) { st_r = __builtin_amdgcn_s_memrealtime(); st_c = __builtin_amdgcn_s_memtime(); }
+    if (p.stamps) asm volatile("s_memrealtime %0\n s_memtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(st_r), "=s"(st_c));
 
     uint32_t j = t0 * 64u;
     for (; j + 8u <= j1; j += 8u) {
@@ -513,6 +605,71 @@ __global__ __launch_bounds__(1024) void p2p_gather_kernel(const P2PArgs p)
         dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// flow mode, the pull half on the comm stream: workgroup b serves peer q.  One lane waits for q's
+// flag (q's LAST integrated tile stored it, behind all of q's slice), the workgroup pulls the slice
+// with cache-bypassing system-scope loads and stores it write-through (agent scope), drains, and one
+// lane marks arrived[q] = step -- what the force launch's remote-chunk waves wait for.
+__global__ __launch_bounds__(512) void flow_pull_kernel(const P2PArgs p, uint32_t *arrived)
+{
+    const uint32_t b = blockIdx.x;
+    const uint32_t q = b < p.rank ? b : b + 1u;            // skip self
+    __shared__ uint32_t ok;
+    if (threadIdx.x == 0) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        uint32_t good = 1u;
+        while ((int32_t)(__hip_atomic_load(p.my_flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - p.step) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) { good = 0u; break; }
+        }
+        if (!good) __hip_atomic_store(p.status, 1u + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        ok = good;
+    }
+    __syncthreads();
+    if (ok) {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p.peer[q] + (size_t)q * p.count);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.local + (size_t)q * p.count);
+        const uint32_t words = p.count * 2u;
+        uint32_t i = threadIdx.x;
+        for (; i + 15u * 512u < words; i += 16u * 512u) {          // 16 remote loads in flight per lane
+            unsigned long long v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = __hip_atomic_load(src + i + u * 512u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+            for (int u = 0; u < 16; u++) __hip_atomic_store(dst + i + u * 512u, v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (; i < words; i += 512u)
+            __hip_atomic_store(dst + i, __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave: its write-through stores are acknowledged
+    __syncthreads();
+    // also after a timed-out wait: the force launch must not hang on top of it (the status word reports it)
+    if (threadIdx.x == 0) __hip_atomic_store(arrived + q, p.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// flow mode, the publish half alone: a rank whose slice is not advanced by a force launch in this step
+// (no active body in it, or the central-well step) still owes its peers the flag.  Stream-ordered
+// behind whatever wrote the slice (the kernel boundary made it visible).
+__global__ __launch_bounds__(64) void flow_publish_kernel(uint32_t *const *peer_flags, uint32_t rank, uint32_t world, uint32_t step)
+{
+    if (threadIdx.x != 0) return;
+    for (uint32_t q = 0; q < world; q++)
+        if (q != rank) __hip_atomic_store(peer_flags[q] + rank, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_flow_pull(const P2PArgs &a, uint32_t *arrived, hipStream_t st)
+{
+    if (a.world < 2) return hipSuccess;
+    hipLaunchKernelGGL(flow_pull_kernel, dim3(a.world - 1), dim3(512), 0, st, a, arrived);
+    return hipGetLastError();
+}
+
+hipError_t launch_flow_publish(uint32_t *const *peer_flags, uint32_t rank, uint32_t world, uint32_t step, hipStream_t st)
+{
+    hipLaunchKernelGGL(flow_publish_kernel, dim3(1), dim3(64), 0, st, peer_flags, rank, world, step);
+    return hipGetLastError();
+}
+
 hipError_t launch_p2p_gather(const P2PArgs &a, hipStream_t st)
 {
     if (a.world < 2) return hipSuccess;
@@ -595,9 +752,9 @@ static hipError_t launch_force_variant(int kind, int epi, dim3 grid, const StepA
         else if (epi == EPI_TICKET) hipLaunchKernelGGL((force_lds_kernel<K2, WAVES, EPI_TICKET>), grid, block, 0, st, a);
         else                        hipLaunchKernelGGL((force_lds_kernel<K2, WAVES, EPI_ROWS>), grid, block, 0, st, a);
     } else {
-        if (epi == EPI_FUSED)       hipLaunchKernelGGL((force_sgpr_kernel<K2, WAVES, EPI_FUSED>), grid, block, 0, st, a);
-        else if (epi == EPI_TICKET) hipLaunchKernelGGL((force_sgpr_kernel<K2, WAVES, EPI_TICKET>), grid, block, 0, st, a);
-        else                        hipLaunchKernelGGL((force_sgpr_kernel<K2, WAVES, EPI_ROWS>), grid, block, 0, st, a);
+        if (epi == EPI_FUSED)       hipLaunchKernelGGL((force_sgpr_kernel<K2, WAVES, EPI_FUSED>), grid, block, 0, st, a, a.pos_old);
+        else if (epi == EPI_TICKET) hipLaunchKernelGGL((force_sgpr_kernel<K2, WAVES, EPI_TICKET>), grid, block, 0, st, a, a.pos_old);
+        else                        hipLaunchKernelGGL((force_sgpr_kernel<K2, WAVES, EPI_ROWS>), grid, block, 0, st, a, a.pos_old);
     }
     return hipGetLastError();
 }

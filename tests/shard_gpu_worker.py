@@ -46,10 +46,11 @@ def main():
         c.close()
         dist.destroy_process_group()
         return
-    if mode == "p2p":
-        # the in-library direct exchange: hipIpc-mapped peer buffers + device flags, no caller help
+    if mode in ("p2p", "flow"):
+        # the in-library direct exchange: hipIpc-mapped peer buffers + device flags, no caller help;
+        # "flow" = the same exchange overlapped inside the force launch (gather algorithm 3)
         c.p2p_setup_torch()
-        c.set_gather_algorithm(2)
+        c.set_gather_algorithm(3 if mode == "flow" else 2)
         c.set_timeouts(p2p_ms=5000)      # several processes time-slice ONE GPU here: be generous
         num_active = int(sys.argv[8]) if len(sys.argv) > 8 else n
         for _ in range(steps):

@@ -130,3 +130,27 @@ def test_product_does_not_link_or_reference_the_oracle():
     body, tail = rest.split("\ndef ", 1)
     assert "from oracle" not in head and "import oracle" not in head
     assert "from oracle" not in tail and "import oracle" not in tail
+
+
+def test_force_kernel_keeps_its_scalar_loads(tmp_path):
+    """Guard against a silent 27 % regression (round 2): hipcc turns the wave-uniform j-loads of
+    force_sgpr_kernel into s_load only while it can prove nothing in the kernel clobbers that memory
+    before the load.  A builtin s_memtime, an asm "memory" clobber or an atomic on a possibly-aliasing
+    pointer in front of the loop makes every one of them a uniform global_load_dwordx3 -- same
+    results, 1.124 instead of 0.888 ms per 65 536-body step.  Disassemble and count."""
+    import subprocess
+    src = os.path.join(ROOT, "multi-adapter-particles_amd", "csrc", "mapn_kernels.hip")
+    out = str(tmp_path / "k.s")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.dirname(src), "-S", "--cuda-device-only", "-o", out, src], check=True, capture_output=True)
+    text = open(out).read()
+    bodies = re.findall(r"^(_ZN4mapn17force_sgpr_kernelILi(\d)ELi(\d+)ELi(\d)EEEv\w*):(.*?)s_endpgm", text, re.S | re.M)
+    assert len(bodies) >= 40
+    for name, k2, waves, epi, body in bodies:
+        wide = sum(4 * int(w_) for w_ in re.findall(r"s_load_dwordx(4|8|16)\b", body))     # bytes of wide scalar loads
+        vec = len(re.findall(r"global_load_dwordx3\b", body))
+        assert wide >= 128, f"{name}: only {wide} bytes of scalar j-loads (8 bodies x 16 B per unrolled iteration expected)"
+        # load_bodies: 2 * K2 position loads; the integrator: position + velocity of its bodies
+        assert vec <= 2 * int(k2) + 2, f"{name}: {vec} vector dwordx3 loads -- the j-loads were de-scalarised"
+    default = [b for n_, k2, w, e, b in bodies if (k2, w, e) == ("1", "8", "2")][0]
+    assert len(re.findall(r"v_pk_fma_f32", default)) == 56 and "scratch_" not in default

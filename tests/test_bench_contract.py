@@ -41,6 +41,9 @@ def test_bench_json_contract():
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "TFLOP/s" and 0.3 < rf["frac"] < 0.8
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and abs(rf["peak"] - 157.2864) < 0.5
     assert rf["launches_timed"] >= 4 and "traffic" in rf
+    assert rf["bound_actual"] == "valu-fp32"                       # no MFMA is issued; `bound` holds the schema's compute value
+    assert 1.5 < rf["held_clock_ghz"] <= 2.45 and rf["frac"] < rf["frac_at_held_clock"] < 0.75   # 66.7 % = the mix's ceiling
+    assert d["config"]["launches_per_step"] == 1 and d["config"]["fused_integrator"] is True
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e8 and "sample" in cb
     assert d["value"] > 3.0e12            # the 40 %-of-peak target is 3.15e12 at kernel level
@@ -63,3 +66,21 @@ def test_bench_two_ranks_one_gpu_with_the_direct_exchange():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["exchange"] == "p2p"
     assert d["config"]["replicas_bit_identical_after_run"] is True
     assert d["config"]["parallelism"] == "bodies sharded x2" and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_one_gpu_with_the_in_kernel_exchange():
+    """The same N > 1 flow with gather algorithm 3 ("flow": the exchange overlapped inside the force
+    launch).  Two ranks time-slice ONE device here, so the job is kept small enough for both ranks'
+    launches to be resident together (a rank's waiting workgroups must never starve the peer it
+    waits for -- on a node every rank has its own GPU)."""
+    port = 29900 + (os.getpid() % 90)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "30", "--warmup", "3", "--gather", "flow", "--dist-backend", "gloo",
+                        "--same-device", "--prewarm-ms", "20", "--bodies", "8192"], capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["exchange"] == "p2p+inkernel"
+    assert d["config"]["replicas_bit_identical_after_run"] is True and d["config"]["p2p_failure"] is None

@@ -52,9 +52,12 @@ typedef enum mapn_force_mode {
 typedef enum mapn_kernel {
     MAPN_KERNEL_AUTO = 0,
     MAPN_KERNEL_LDS = 1,        /* j-tiles staged through LDS, broadcast ds_read */
-    MAPN_KERNEL_SCALAR = 2,     /* j-bodies through the scalar cache into SGPRs */
-    MAPN_KERNEL_MFMA = 3        /* accumulation recast on v_mfma_f32_4x4x1: A/B experiment only
-                                   (tools/ubench.hip); measured slower, mapn_create rejects it */
+    MAPN_KERNEL_SCALAR = 2      /* j-bodies through the scalar cache into SGPRs */
+    /* No MFMA variant (BASELINE configs[4] A/B, closed in round 2): on gfx950 the f32 MFMA shapes do NOT
+       run beside the packed fp32 VALU stream of the same SIMD -- their times add (16 v_pk_fma_f32 + one
+       v_mfma_f32_16x16x4_f32: 105 cycles against 74 + 32) -- so every recast of the pair term is slower
+       than the packed-VALU form, and the two that remove the most VALU work lose 3 decimal digits
+       (profiles/r02_ubench.txt, profiles/r02_mfma_recast_error.txt). */
 } mapn_kernel;
 
 /* The three #if variants of LoadParticles (Compute.cpp:581-583), all seeded per body. */

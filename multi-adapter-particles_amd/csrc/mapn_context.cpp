@@ -618,10 +618,7 @@ int create_common(const mapn_config *cfg, mapn_ctx **out)
         return fail(MAPN_ERR_INVALID_ARGUMENT, "world_size %d must divide num_particles %u", cfg->world_size, cfg->num_particles);
     if (cfg->force_mode != MAPN_FORCE_ALL_PAIRS && cfg->force_mode != MAPN_FORCE_CENTRAL_WELL)
         return fail(MAPN_ERR_INVALID_ARGUMENT, "force_mode %d", cfg->force_mode);
-    if (cfg->kernel == MAPN_KERNEL_MFMA)
-        return fail(MAPN_ERR_INVALID_ARGUMENT, "MAPN_KERNEL_MFMA is not built: the v_mfma_f32_4x4x1 accumulation measured "
-                    "4.0e12 pairs/s against 4.9e12 for the packed-VALU form (profiles/r01_ubench.txt, DESIGN.md 3.1)");
-    if (cfg->kernel < MAPN_KERNEL_AUTO || cfg->kernel > MAPN_KERNEL_MFMA)
+    if (cfg->kernel < MAPN_KERNEL_AUTO || cfg->kernel > MAPN_KERNEL_SCALAR)
         return fail(MAPN_ERR_INVALID_ARGUMENT, "kernel %d", cfg->kernel);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)

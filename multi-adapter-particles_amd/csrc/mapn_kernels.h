@@ -6,7 +6,7 @@
 
 namespace mapn {
 
-enum { KERNEL_LDS = 1, KERNEL_SGPR = 2, KERNEL_MFMA = 3 };
+enum { KERNEL_LDS = 1, KERNEL_SGPR = 2 };
 enum { MAX_SEGMENTS = 3 };
 // where the kick-drift integrator runs (see finish<> in mapn_kernels.hip)
 enum { EPI_ROWS = 0, EPI_FUSED = 1, EPI_TICKET = 2 };

@@ -19,6 +19,7 @@ ap.add_argument("--waves", default="4,8,16")
 ap.add_argument("--sbs", default="1,2,4")
 ap.add_argument("--timer-interval", type=int, default=1)
 ap.add_argument("--overlap", action="store_true")
+ap.add_argument("--fused", type=int, default=1, help="0 = rows + reduce launch, 1 = one launch (ticket when sb > 1)")
 ap.add_argument("--auto", action="store_true", help="do not force a plan: time the library's own choice once")
 ap.add_argument("--world", type=int, default=1, help="emulate one shard of a world_size-way job (external gather, rank 0)")
 a = ap.parse_args()
@@ -32,12 +33,15 @@ with mapn.Compute(n, mass=70000.0 / n, rank=0, world_size=a.world, flags=mapn.FL
     c.set_timers(a.timer_interval)
     rows = []
     n_i = n // a.world
-    for kn, k, w, sb in itertools.product(a.kernels.split(","), map(int, a.ks.split(",")), map(int, a.waves.split(",")), map(int, a.sbs.split(","))):
+    combos = list(itertools.product(a.kernels.split(","), map(int, a.ks.split(",")), map(int, a.waves.split(",")), map(int, a.sbs.split(","))))
+    if a.auto:
+        combos = [("auto", 0, 0, 0)] * 3                 # the library's own plan, three repeats
+    for kn, k, w, sb in combos:
         try:
             if a.auto:
                 c.set_force_plan(mapn.KERNEL_AUTO)
             else:
-                c.set_force_plan(KN[kn], k, w, sb, sb == 1)
+                c.set_force_plan(KN[kn], k, w, sb, a.fused)
         except mapn.MapnError:
             continue
         for _ in range(3):
@@ -49,6 +53,8 @@ with mapn.Compute(n, mass=70000.0 / n, rank=0, world_size=a.world, flags=mapn.FL
         c.WaitForGpu()
         wall = (time.perf_counter() - t0) / a.steps
         st = c.kernel_stats()
+        if a.auto:
+            kn, k, w, sb = st.kernel_name.decode().replace("force_", "").replace("_kernel", ""), st.bodies_per_lane, st.block_x // 64, st.grid_y
         ks = st.avg_seconds if st.launches else float("nan")
         rate = n_i * n / (ks if st.launches else wall)
         rows.append((rate, kn, k, w, sb, ks * 1e3, wall * 1e3))

@@ -113,10 +113,10 @@ __device__ __forceinline__ void integrate_store(const StepArgs &p, uint32_t i, f
     o.w = __builtin_sqrtf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)));
     if (p.flow_arrived) {
         // flow mode: peers pull this slice over xGMI while the launch is still running -- the new
-        // position goes write-through to memory at system scope (global_store_dwordx2 sc0 sc1)
-        unsigned long long *d = reinterpret_cast<unsigned long long *>(p.pos_new + i);
-        __hip_atomic_store(d, (unsigned long long)__float_as_uint(o.x) | ((unsigned long long)__float_as_uint(o.y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(d + 1, (unsigned long long)__float_as_uint(o.z) | ((unsigned long long)__float_as_uint(o.w) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // position goes write-through to memory at system scope (one global_store_dwordx4 sc0 sc1)
+        typedef float f4s __attribute__((ext_vector_type(4)));
+        const f4s v = {o.x, o.y, o.z, o.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p.pos_new + i), "v"(v) : "memory");
     } else {
         p.pos_new[i] = o;
     }
@@ -245,24 +245,40 @@ __device__ __forceinline__ void load_bodies(Bodies<K2> &b, const StepArgs &p, ui
     }
 }
 
-// 8-byte write-through stores / cache-bypassing loads (global_store/load_dwordx2 sc1) for data
-// handed from one workgroup to another INSIDE a launch (MI355X_MICROARCH.md, inter-workgroup
-// visibility): the bytes leave the writer's L2 and are never served from the reader's L1.
+// 16-byte write-through stores / L1-bypassing loads (global_store/load_dwordx4 sc1) for data handed
+// from one workgroup to another INSIDE a launch (MI355X_MICROARCH.md, inter-workgroup visibility):
+// the bytes leave the writer's L2 and are never served from the reader's L1.  Inline asm because HIP
+// has no 16-byte agent-scope access; one dwordx4 per row entry writes whole 64-B segments per wave --
+// split into two 8-byte stores the same rows cost twice the memory-side write traffic
+// (WRITE_SIZE 18.3 MiB instead of 10 MiB per 65 536-body launch, profiles/r02_pmc_summary.txt).
+typedef float f4v __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ void store_row_sc1(float4 *dst, float ax, float ay, float az)
 {
-    unsigned long long *d = reinterpret_cast<unsigned long long *>(dst);
-    const unsigned long long lo = (unsigned long long)__float_as_uint(ax) | ((unsigned long long)__float_as_uint(ay) << 32);
-    const unsigned long long hi = (unsigned long long)__float_as_uint(az);
-    __hip_atomic_store(d, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(d + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const f4v v = {ax, ay, az, 0.f};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
 }
 
-__device__ __forceinline__ void load_row_sc1(const float4 *src, float &ax, float &ay, float &az)
+// eight rows in flight, then ONE wait: the compiler does not count inline-asm loads in vmcnt
+__device__ __forceinline__ void load_rows8_sc1(const float4 *in, size_t stride, f4v (&r)[8])
 {
-    const unsigned long long *s = reinterpret_cast<const unsigned long long *>(src);
-    const unsigned long long lo = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long hi = __hip_atomic_load(s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ax = __uint_as_float((uint32_t)lo); ay = __uint_as_float((uint32_t)(lo >> 32)); az = __uint_as_float((uint32_t)hi);
+    const float4 *p0 = in, *p1 = in + stride, *p2 = in + 2 * stride, *p3 = in + 3 * stride;
+    const float4 *p4 = in + 4 * stride, *p5 = in + 5 * stride, *p6 = in + 6 * stride, *p7 = in + 7 * stride;
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
+                 "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+                 "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+                 "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)
+                 : "memory");
+}
+
+__device__ __forceinline__ f4v load_row_sc1(const float4 *src)
+{
+    f4v r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(src) : "memory");
+    return r;
 }
 
 // epilogue shared by both force kernels: the WAVES chunk sums of a workgroup are combined in LDS
@@ -329,16 +345,14 @@ __device__ __forceinline__ void finish(const Bodies<K2> &b, const StepArgs &p, u
             float ax = 0.f, ay = 0.f, az = 0.f;
             uint32_t s = 0;
             for (; s + 8u <= rows; s += 8u) {                  // 8 rows in flight, summed in ascending order
-                float rx[8], ry[8], rz[8];
+                f4v r[8];
+                load_rows8_sc1(in + (size_t)s * stride, stride, r);
 #pragma unroll
-                for (int u = 0; u < 8; u++) load_row_sc1(in + (size_t)(s + u) * stride, rx[u], ry[u], rz[u]);
-#pragma unroll
-                for (int u = 0; u < 8; u++) { ax += rx[u]; ay += ry[u]; az += rz[u]; }
+                for (int u = 0; u < 8; u++) { ax += r[u].x; ay += r[u].y; az += r[u].z; }
             }
             for (; s < rows; s++) {
-                float rx, ry, rz;
-                load_row_sc1(in + (size_t)s * stride, rx, ry, rz);
-                ax += rx; ay += ry; az += rz;
+                const f4v r = load_row_sc1(in + (size_t)s * stride);
+                ax += r.x; ay += r.y; az += r.z;
             }
             const uint32_t i = p.i_first + li;
             integrate_store(p, i, p.pos_old[i], ax * p.mass, ay * p.mass, az * p.mass);
@@ -627,19 +641,31 @@ __global__ __launch_bounds__(512) void flow_pull_kernel(const P2PArgs p, uint32_
     }
     __syncthreads();
     if (ok) {
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p.peer[q] + (size_t)q * p.count);
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.local + (size_t)q * p.count);
-        const uint32_t words = p.count * 2u;
+        // 16 bytes per lane per access: system-scope loads that bypass this GPU's caches (a line of q's
+        // buffer cached two steps ago cannot be returned), agent-scope write-through stores
+        const float4 *src = p.peer[q] + (size_t)q * p.count;
+        float4 *dst = p.local + (size_t)q * p.count;
         uint32_t i = threadIdx.x;
-        for (; i + 15u * 512u < words; i += 16u * 512u) {          // 16 remote loads in flight per lane
-            unsigned long long v[16];
+        for (; i + 7u * 512u < p.count; i += 8u * 512u) {          // 8 remote loads (64 KiB per workgroup) in flight
+            f4v v[8];
+            asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off sc0 sc1\n\t"
+                         "global_load_dwordx4 %2, %10, off sc0 sc1\n\tglobal_load_dwordx4 %3, %11, off sc0 sc1\n\t"
+                         "global_load_dwordx4 %4, %12, off sc0 sc1\n\tglobal_load_dwordx4 %5, %13, off sc0 sc1\n\t"
+                         "global_load_dwordx4 %6, %14, off sc0 sc1\n\tglobal_load_dwordx4 %7, %15, off sc0 sc1\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                         : "v"(src + i), "v"(src + i + 512u), "v"(src + i + 1024u), "v"(src + i + 1536u),
+                           "v"(src + i + 2048u), "v"(src + i + 2560u), "v"(src + i + 3072u), "v"(src + i + 3584u)
+                         : "memory");
 #pragma unroll
-            for (int u = 0; u < 16; u++) v[u] = __hip_atomic_load(src + i + u * 512u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#pragma unroll
-            for (int u = 0; u < 16; u++) __hip_atomic_store(dst + i + u * 512u, v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int u = 0; u < 8; u++)
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + i + u * 512u), "v"(v[u]) : "memory");
         }
-        for (; i < words; i += 512u)
-            __hip_atomic_store(dst + i, __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (; i < p.count; i += 512u) {
+            f4v v;
+            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src + i) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + i), "v"(v) : "memory");
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave: its write-through stores are acknowledged
     __syncthreads();

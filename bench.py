@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--mode", choices=["all_pairs", "central_well"], default="all_pairs")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--plan", default="", help="kernel,bodies_per_lane,waves,sb,fused e.g. sgpr,2,8,8,1 (fused: 0 = rows + reduce launch, 1 = one launch, 2 = ticket form always)")
+    ap.add_argument("--kernel", choices=["auto", "lds", "sgpr", "sym"], default="auto",
+                    help="force kernel: scalar-cache (auto), LDS-tiled, or the symmetric (Newton's third law) kernel")
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl")
     ap.add_argument("--gather", choices=["auto", "allgather", "sendrecv", "p2p", "flow"], default="auto",
                     help="how the in-library exchange is issued: RCCL ncclAllGather, one group of RCCL send/recv pairs, or the "
@@ -101,11 +103,13 @@ def cpu_baseline(n, seed, target_seconds):
 def kernel_source_sha16():
     import hashlib
     here = os.path.dirname(os.path.abspath(__file__))
-    src = os.path.join(here, "multi-adapter-particles_amd", "csrc", "mapn_kernels.hip")
+    h = hashlib.sha256()
     try:
-        return hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+        for f in ("mapn_kernels.hip", "mapn_sym.hip"):
+            h.update(open(os.path.join(here, "multi-adapter-particles_amd", "csrc", f), "rb").read())
     except OSError:
         return None
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel_name, n, world):
@@ -164,8 +168,9 @@ def main():
     n = a.bodies
     mode = mapn.FORCE_ALL_PAIRS if a.mode == "all_pairs" else mapn.FORCE_CENTRAL_WELL
     flags = (mapn.FLAG_USE_GRAPH if a.graph else 0) | (mapn.FLAG_SHARD_OVERLAP if a.overlap else 0)
+    kern = {"auto": mapn.KERNEL_AUTO, "lds": mapn.KERNEL_LDS, "sgpr": mapn.KERNEL_SCALAR, "sym": mapn.KERNEL_SYMMETRIC}[a.kernel]
     c = mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed,
-                     rank=rank, world_size=world, flags=flags)
+                     rank=rank, world_size=world, flags=flags, kernel=kern)
     info = device_info(local_rank)
     transport = "none"
     gather_fn = None
@@ -401,6 +406,11 @@ def main():
                 ach = FLOP_PER_PAIR * pairs_per_launch / st.avg_seconds / 1e12
                 traffic, traffic_src = pmc_traffic(st.kernel_name.decode(), n, world)
                 held = clock.shader_clock_ghz if clock else None
+                sym = st.kernel_name.decode() == "force_sym_kernel"
+                # flop the kernel EXECUTES per ordered interaction: the one-sided kernels evaluate every ordered
+                # pair (20); the symmetric kernel evaluates every unordered pair once and feeds both bodies:
+                # 3 sub + 3 fma + rsq + 2 mul + 3 fma + 3 fma = 24 flop per TWO interactions
+                executed_per_pair = 12.0 if sym else float(FLOP_PER_PAIR)
                 out["roofline"] = {"bound": "mfma",
                                    "bound_actual": "valu-fp32",
                                    "bound_detail": "compute-bound on the fp32 VECTOR ALU (packed v_pk_*_f32 + v_rsq_f32): the kernel issues NO MFMA. "
@@ -411,7 +421,13 @@ def main():
                                    "held_clock_ghz": held,
                                    "held_clock_ghz_p10_p90": [clock.shader_clock_ghz_p10, clock.shader_clock_ghz_p90] if clock else None,
                                    "frac_at_held_clock": (ach / (info.compute_units * held * 1e9 * 256 / 1e12)) if held else None,
-                                   "instruction_mix_ceiling": "11 packed ops x 4 cycles + 2 v_rsq_f32 x 8 cycles per 128 pairs per SIMD = 66.7 % of peak at any clock",
+                                   "flop_executed_per_pair": executed_per_pair,
+                                   "frac_executed": ach / peak * executed_per_pair / FLOP_PER_PAIR,
+                                   "instruction_mix_ceiling": ("symmetric kernel: 14 packed ops x 4 cycles + 2 v_rsq_f32 x 8 cycles per 256 ordered interactions per SIMD "
+                                                               "(+ 6 ds_bpermute_b32 and 3 adds per 16 per lane) = 111 % of the ALGORITHMIC peak at any clock: every "
+                                                               "unordered pair is evaluated once (Newton's third law), so `frac` counts 20 flop per ordered pair of "
+                                                               "which 12 are executed (`frac_executed`)") if sym else
+                                                              "11 packed ops x 4 cycles + 2 v_rsq_f32 x 8 cycles per 128 pairs per SIMD = 66.7 % of peak at any clock",
                                    "traffic": traffic, "traffic_unit": "HBM bytes per force launch (2*FETCH_SIZE+WRITE_SIZE, PMC)",
                                    "traffic_source": traffic_src, "kernel_source_sha16": kernel_source_sha16(),
                                    "kernel": st.kernel_name.decode(), "launches_timed": int(st.launches),

@@ -50,9 +50,13 @@ typedef enum mapn_force_mode {
 
 /* Kernel selection for the all-pairs force (MAPN_KERNEL_AUTO picks per N and device). */
 typedef enum mapn_kernel {
-    MAPN_KERNEL_AUTO = 0,
+    MAPN_KERNEL_AUTO = 0,       /* the symmetric kernel where it applies, else the scalar-cache kernel */
     MAPN_KERNEL_LDS = 1,        /* j-tiles staged through LDS, broadcast ds_read */
-    MAPN_KERNEL_SCALAR = 2      /* j-bodies through the scalar cache into SGPRs */
+    MAPN_KERNEL_SCALAR = 2,     /* j-bodies through the scalar cache into SGPRs */
+    MAPN_KERNEL_SYMMETRIC = 3   /* Newton's third law: every unordered pair evaluated once, feeding both bodies
+                                   (csrc/mapn_sym.hip).  Applies to the unsharded step with all bodies active and
+                                   N a multiple of 512 (scratch N^2/64 bytes, capped by MAPN_SYM_MAX_MB, default
+                                   4096); any other step of such a context runs the scalar-cache kernel. */
     /* No MFMA variant (BASELINE configs[4] A/B, closed in round 2): on gfx950 the f32 MFMA shapes do NOT
        run beside the packed fp32 VALU stream of the same SIMD -- their times add (16 v_pk_fma_f32 + one
        v_mfma_f32_16x16x4_f32: 105 cycles against 74 + 32) -- so every recast of the pair term is slower
@@ -336,7 +340,8 @@ typedef struct mapn_kernel_stats {
     uint32_t fused;              /* 1: the integrator runs inside the force launch (one launch per step) */
     uint32_t grid_z;             /* j-segments per launch (1 unless the sharded overlap structure) */
     uint32_t epilogue;           /* 0 partial rows + reduce_integrate launch, 1 fused in the workgroup,
-                                    2 last-arriver ticket (rows summed by the last workgroup of the i-tile) */
+                                    2 last-arriver ticket (rows summed by the last workgroup of the i-tile),
+                                    3 the symmetric kernel's rows + sym_reduce_integrate launch */
     uint32_t force_launches_per_step;
     uint32_t reserved;
 } mapn_kernel_stats;

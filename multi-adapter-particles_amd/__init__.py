@@ -7,7 +7,7 @@ package is a thin ctypes binding that mirrors the reference's ``class Compute``
 library, or without a gfx950 device, construction raises.
 """
 from ._lib import (  # noqa: F401
-    FORCE_ALL_PAIRS, FORCE_CENTRAL_WELL, KERNEL_AUTO, KERNEL_LDS, KERNEL_SCALAR,
+    FORCE_ALL_PAIRS, FORCE_CENTRAL_WELL, KERNEL_AUTO, KERNEL_LDS, KERNEL_SCALAR, KERNEL_SYMMETRIC,
     FLAG_NO_INIT, FLAG_SHARD_OVERLAP, FLAG_STRICT_CONSUMER, FLAG_USE_GRAPH, INIT_LCG, INIT_MT, INIT_SSE, Config, DeviceInfo, KernelStats, MapnError, SharedHandles,
     build_library, library_path, load_library,
 )
@@ -17,6 +17,6 @@ from .shard import ShardPlan, shard_range, remote_segments  # noqa: F401
 __all__ = [
     "Compute", "IpcView", "Config", "MapnError", "ShardPlan", "shard_range", "remote_segments",
     "generate_initial_state", "build_library", "load_library", "library_path",
-    "FORCE_ALL_PAIRS", "FORCE_CENTRAL_WELL", "KERNEL_AUTO", "KERNEL_LDS", "KERNEL_SCALAR",
+    "FORCE_ALL_PAIRS", "FORCE_CENTRAL_WELL", "KERNEL_AUTO", "KERNEL_LDS", "KERNEL_SCALAR", "KERNEL_SYMMETRIC",
     "FLAG_NO_INIT", "FLAG_USE_GRAPH", "FLAG_SHARD_OVERLAP", "FLAG_STRICT_CONSUMER", "INIT_LCG", "INIT_SSE", "INIT_MT",
 ]

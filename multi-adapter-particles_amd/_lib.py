@@ -12,7 +12,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 
 FORCE_ALL_PAIRS = 0        # sum of bodyBodyInteraction, nBodyGravityCS.hlsl:44-57
 FORCE_CENTRAL_WELL = 1     # CSMain as shipped, nBodyGravityCS.hlsl:92-101
-KERNEL_AUTO, KERNEL_LDS, KERNEL_SCALAR = 0, 1, 2
+KERNEL_AUTO, KERNEL_LDS, KERNEL_SCALAR, KERNEL_SYMMETRIC = 0, 1, 2, 3
 FLAG_USE_GRAPH = 0x1
 INIT_LCG, INIT_SSE, INIT_MT = 0, 1, 2
 FLAG_NO_INIT = 0x2

@@ -74,6 +74,9 @@ struct mapn_ctx {
     float4 *partial = nullptr;
     size_t partial_bytes = 0;
     uint32_t *ticket = nullptr;               // EPI_TICKET arrival counters, one per i-tile, zero between launches
+    float4 *sym_arow = nullptr, *sym_brow = nullptr;   // scratch rows of the symmetric kernel (mapn_sym.hip)
+    size_t sym_arow_bytes = 0, sym_brow_bytes = 0;
+    uint32_t sym_parts = 0, sym_waves = 0;
     unsigned long long *stamp_buf = nullptr;  // mapn_measure_clock: per-wave clock stamps of a diagnostic launch
     size_t stamp_waves = 0;
     bool stamp_next = false;
@@ -245,7 +248,7 @@ mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_tota
         p.epi = choose_epilogue(c, p, allow_fused);
         return p;
     }
-    p.kind = c->cfg.kernel == MAPN_KERNEL_LDS ? mapn::KERNEL_LDS : mapn::KERNEL_SGPR;
+    p.kind = c->cfg.kernel == MAPN_KERNEL_LDS ? mapn::KERNEL_LDS : mapn::KERNEL_SGPR;      // (SYMMETRIC falls back to the scalar-cache kernel)
     p.k = i_count >= 196608u ? 4 : 2;
     p.nseg = nseg;
     const uint64_t i_waves = (i_count + 64ull * p.k - 1) / (64ull * p.k);
@@ -266,6 +269,82 @@ mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_tota
     }
     p.epi = choose_epilogue(c, p, allow_fused);
     return p;
+}
+
+// The symmetric kernel (mapn_sym.hip) covers the whole-N, unsharded, all-bodies-active step with N a
+// multiple of 512; anything else runs the one-sided kernels.  Its scratch grows with N^2 / 64 bytes
+// (one 1 KiB row per meeting of a 64-body block with a 512-body block), capped by MAPN_SYM_MAX_MB.
+bool sym_eligible(const mapn_ctx *c, uint32_t active)
+{
+    // AUTO picks it wherever it applies (measured 1.33x the scalar-cache kernel at 65 536 bodies, 1.45x at
+    // 262 144 and 1 048 576: profiles/r02_sym_*.txt); MAPN_KERNEL_SCALAR / _LDS and a forced plan keep the one-sided kernels
+    if ((c->cfg.kernel != MAPN_KERNEL_SYMMETRIC && c->cfg.kernel != MAPN_KERNEL_AUTO) || c->plan_forced) return false;
+    const char *off = getenv("MAPN_NO_SYM");
+    if (off && off[0] == '1' && c->cfg.kernel == MAPN_KERNEL_AUTO) return false;
+    if (c->cfg.world_size != 1 || c->cfg.force_mode != MAPN_FORCE_ALL_PAIRS) return false;
+    if (c->comm || c->external_gather || c->p2p_ready) return false;   // a context wired for an exchange runs the sharded step
+    if (active != c->n || (c->n % 512u) != 0u) return false;
+    const uint64_t nb = c->n / 512u, brows = std::max<uint64_t>(1, (nb - 1) / 2 + ((nb & 1u) ? 0 : 1));
+    const char *e = getenv("MAPN_SYM_MAX_MB");
+    const uint64_t cap = (e ? strtoull(e, nullptr, 10) : 4096ull) << 20;
+    return (uint64_t)c->n * brows * 16ull <= cap;
+}
+
+int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
+{
+    mapn::SymArgs a{};
+    a.pos_old = base.pos_old; a.vel_old = base.vel_old; a.pos_new = base.pos_new; a.vel_new = base.vel_new;
+    a.n = c->n; a.nb = c->n / 512u;
+    a.half_d = (a.nb & 1u) ? 0u : a.nb / 2u;
+    a.brows = std::max(1u, (a.nb - 1u) / 2u + (a.half_d ? 1u : 0u));
+    a.mass = base.mass; a.soft2 = base.soft2; a.dt = base.dt; a.damping = base.damping;
+    // one resident round: 4 waves per SIMD (114 VGPRs), every wave the same number of meetings +- 1
+    uint32_t waves = 8, parts = 0;
+    const char *e = getenv("MAPN_SYM_PLAN");               // "waves,parts" tuning override
+    unsigned ew = 0, ep = 0;
+    if (e && sscanf(e, "%u,%u", &ew, &ep) == 2 && (ew == 4 || ew == 8) && ep >= 1) { waves = ew; parts = ep; }
+    if (!parts) {
+        // 4 waves per SIMD are resident (118 VGPRs); about four rounds of workgroups balance the tail
+        // (65 536 bodies: parts 4 / 8 / 16 / 32 / 64 -> 0.691 / 0.672 / 0.647 / 0.655 / 0.691 ms)
+        const uint32_t slots = (uint32_t)c->cus * 4u * 4u;
+        const uint32_t meetings = 8u * (1u + (a.nb - 1u) / 2u) + (a.half_d ? 8u : 0u);
+        parts = (uint32_t)std::max<uint64_t>(1, (4ull * slots + (uint64_t)a.nb * waves / 2) / ((uint64_t)a.nb * waves));
+        parts = std::min(parts, std::max(1u, meetings / waves));
+    }
+    a.parts = parts;
+    const size_t ab = (size_t)a.nb * parts * 512u * sizeof(float4), bb = (size_t)(c->n / 64u) * a.brows * 64u * sizeof(float4);
+    if (ab > c->sym_arow_bytes) {
+        if (c->sym_arow) HIP_TRY(hipFree(c->sym_arow));
+        c->sym_arow = nullptr; c->sym_arow_bytes = 0;
+        HIP_TRY(hipMalloc(&c->sym_arow, ab));
+        c->sym_arow_bytes = ab;
+    }
+    if (bb > c->sym_brow_bytes) {
+        if (c->sym_brow) HIP_TRY(hipFree(c->sym_brow));
+        c->sym_brow = nullptr; c->sym_brow_bytes = 0;
+        HIP_TRY(hipMalloc(&c->sym_brow, bb));
+        c->sym_brow_bytes = bb;
+    }
+    a.arow = c->sym_arow; a.brow = c->sym_brow;
+    if (c->stamp_next) {
+        const size_t nw = (size_t)a.nb * parts * waves;
+        if (nw > c->stamp_waves) {
+            if (c->stamp_buf) HIP_TRY(hipFree(c->stamp_buf));
+            c->stamp_buf = nullptr; c->stamp_waves = 0;
+            HIP_TRY(hipMalloc(&c->stamp_buf, nw * 16));
+            c->stamp_waves = nw;
+        }
+        HIP_TRY(hipMemsetAsync(c->stamp_buf, 0, c->stamp_waves * 16, c->compute));
+        a.stamps = c->stamp_buf;
+    }
+    HIP_TRY(mapn::launch_force_sym(a, waves, c->compute));
+    if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
+    HIP_TRY(mapn::launch_sym_reduce(a, c->compute));
+    mapn::ForcePlan p{};
+    p.kind = mapn::KERNEL_SYM; p.k = 8; p.waves = waves; p.sb = parts; p.nseg = 1; p.epi = mapn::EPI_ROWS;
+    c->last_plan = p; c->last_i_count = c->n; c->last_launches = 2;
+    c->sym_parts = parts; c->sym_waves = waves;
+    return MAPN_OK;
 }
 
 // MAPN_OWN_PLAN / MAPN_REM_PLAN = "k,waves,sb": tuning override of the two sharded launches
@@ -403,6 +482,8 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
     } else if (i_count == 0 && flow) {
         // nothing of this rank's slice advances in this step: it still owes its peers the flag
         HIP_TRY(mapn::launch_flow_publish(c->p2p_flag_table, a.flow_rank, a.flow_world, a.flow_publish, c->compute));
+    } else if (i_count > 0 && sym_eligible(c, active)) {
+        if (int rc = enqueue_sym(c, a, timer)) return rc;
     } else if (i_count > 0 && !overlap) {
         // one force launch over all j.  Sharded: the read buffer is complete once the all-gather
         // that filled it has finished (event recorded on the comm stream).
@@ -496,6 +577,9 @@ int enqueue_step_graph(mapn_ctx *c, uint32_t active)
     if (!c->graph_exec[w] || c->graph_active[w] != (int)active) {
         if (c->graph_exec[w]) { (void)hipGraphExecDestroy(c->graph_exec[w]); c->graph_exec[w] = nullptr; }
         const uint32_t lo = c->first, hi = std::min(c->first + c->count, active);
+        if (hi > lo && sym_eligible(c, active) && !c->sym_brow) {
+            return enqueue_step(c, active, nullptr);       // the symmetric step sizes its scratch on first use: that step runs eagerly
+        }
         if (hi > lo && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS) {
             mapn::ForcePlan plan = choose_plan(c, hi - lo, c->n, 1, true);
             if (plan.epi != mapn::EPI_FUSED)
@@ -618,7 +702,7 @@ int create_common(const mapn_config *cfg, mapn_ctx **out)
         return fail(MAPN_ERR_INVALID_ARGUMENT, "world_size %d must divide num_particles %u", cfg->world_size, cfg->num_particles);
     if (cfg->force_mode != MAPN_FORCE_ALL_PAIRS && cfg->force_mode != MAPN_FORCE_CENTRAL_WELL)
         return fail(MAPN_ERR_INVALID_ARGUMENT, "force_mode %d", cfg->force_mode);
-    if (cfg->kernel < MAPN_KERNEL_AUTO || cfg->kernel > MAPN_KERNEL_SCALAR)
+    if (cfg->kernel < MAPN_KERNEL_AUTO || cfg->kernel > MAPN_KERNEL_SYMMETRIC)
         return fail(MAPN_ERR_INVALID_ARGUMENT, "kernel %d", cfg->kernel);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -776,6 +860,8 @@ int mapn_destroy(mapn_ctx *c)
     if (c->partial) (void)hipFree(c->partial);
     if (c->ticket) (void)hipFree(c->ticket);
     if (c->stamp_buf) (void)hipFree(c->stamp_buf);
+    if (c->sym_arow) (void)hipFree(c->sym_arow);
+    if (c->sym_brow) (void)hipFree(c->sym_brow);
     for (int k = 0; k < kTimerRing; k++) {
         if (c->fence_events[k]) (void)hipEventDestroy(c->fence_events[k]);
         if (c->timers[k].start) (void)hipEventDestroy(c->timers[k].start);
@@ -1410,9 +1496,11 @@ int mapn_measure_clock(mapn_ctx *c, int steps, mapn_clock_info *out)
     c->stamp_next = false;
     if (!rc) rc = mapn_wait_idle(c);
     if (rc) return rc;
-    if (!c->stamp_buf || c->last_plan.kind != mapn::KERNEL_SGPR)
-        return fail(MAPN_ERR_STATE, "measure_clock: the stamped diagnostic exists for the scalar-cache force kernel only");
-    const size_t waves = (size_t)((c->last_i_count + 64 * c->last_plan.k - 1) / (64 * c->last_plan.k)) * c->last_plan.sb * c->last_plan.waves;
+    if (!c->stamp_buf || (c->last_plan.kind != mapn::KERNEL_SGPR && c->last_plan.kind != mapn::KERNEL_SYM))
+        return fail(MAPN_ERR_STATE, "measure_clock: the stamped diagnostic exists for the scalar-cache and the symmetric force kernels only");
+    const size_t waves = c->last_plan.kind == mapn::KERNEL_SYM
+        ? (size_t)(c->n / 512u) * c->sym_parts * c->sym_waves
+        : (size_t)((c->last_i_count + 64 * c->last_plan.k - 1) / (64 * c->last_plan.k)) * c->last_plan.sb * c->last_plan.waves;
     std::vector<unsigned long long> h(2 * waves);
     HIP_TRY(hipMemcpy(h.data(), c->stamp_buf, waves * 16, hipMemcpyDeviceToHost));
     std::vector<double> ghz, cyc;
@@ -1451,7 +1539,7 @@ int mapn_get_kernel_stats(mapn_ctx *c, int reset, mapn_kernel_stats *out)
     mapn::ForcePlan p = c->last_plan;
     uint32_t i_count = c->last_i_count;
     if (c->last_launches == 0) { i_count = c->count; p = choose_plan(c, i_count, c->n, 1, true); }
-    snprintf(out->kernel_name, sizeof out->kernel_name, "%s", mapn::force_kernel_name(p));
+    snprintf(out->kernel_name, sizeof out->kernel_name, "%s", p.kind == mapn::KERNEL_SYM ? "force_sym_kernel" : mapn::force_kernel_name(p));
     out->launches = c->force_launches;
     out->avg_seconds = c->force_launches ? c->force_seconds_sum / (double)c->force_launches : 0.0;
     out->grid_x = (i_count + 64 * p.k - 1) / (64 * p.k);
@@ -1463,6 +1551,10 @@ int mapn_get_kernel_stats(mapn_ctx *c, int reset, mapn_kernel_stats *out)
     out->fused = p.epi != mapn::EPI_ROWS ? 1u : 0u;
     out->epilogue = (uint32_t)p.epi;
     out->force_launches_per_step = c->last_launches ? c->last_launches : 1u;
+    if (p.kind == mapn::KERNEL_SYM) {
+        out->force_launches_per_step = 1;                  // + sym_reduce_integrate_kernel (fused = 0)                      // grid (parts, I-blocks); one wave = 8 bodies per lane
+        out->grid_x = p.sb; out->grid_y = i_count / 512u; out->j_splits = p.sb * p.waves; out->fused = 0; out->epilogue = 3;
+    }
     if (reset) { c->force_launches = 0; c->force_seconds_sum = 0.0; }
     return MAPN_OK;
 }

@@ -6,7 +6,7 @@
 
 namespace mapn {
 
-enum { KERNEL_LDS = 1, KERNEL_SGPR = 2 };
+enum { KERNEL_LDS = 1, KERNEL_SGPR = 2, KERNEL_SYM = 3 };
 enum { MAX_SEGMENTS = 3 };
 // where the kick-drift integrator runs (see finish<> in mapn_kernels.hip)
 enum { EPI_ROWS = 0, EPI_FUSED = 1, EPI_TICKET = 2 };
@@ -54,6 +54,24 @@ struct ForcePlan {
     uint32_t nseg;     // gridDim.z
     int      epi;      // EPI_*: EPI_FUSED requires sb == 1 and nseg == 1
 };
+
+// The symmetric (Newton's third law) all-pairs step, mapn_sym.hip: whole-N, unsharded, N % 512 == 0.
+struct SymArgs {
+    const float4 *pos_old;
+    const float  *vel_old;
+    float4       *pos_new;
+    float        *vel_new;
+    float4       *arow;       // [nb][parts][512]  force on the bodies of an I-block, one row per workgroup
+    float4       *brow;       // [n / 64][brows][64] reaction on the bodies of a J-block, one row per meeting
+    uint32_t      n, nb;      // bodies, I-blocks of 512
+    uint32_t      parts;      // workgroups per I-block (gridDim.x)
+    uint32_t      brows;      // rows allocated per J-block: (nb - 1) / 2 (+ 1 when nb is even)
+    uint32_t      half_d;     // nb / 2 when nb is even (the half-ring partner), else 0
+    float         mass, soft2, dt, damping;
+    unsigned long long *stamps;   // diagnostic launches only (mapn_measure_clock), else null
+};
+hipError_t launch_force_sym(const SymArgs &a, uint32_t waves, hipStream_t st);
+hipError_t launch_sym_reduce(const SymArgs &a, hipStream_t st);
 
 bool force_plan_supported(const ForcePlan &plan);
 hipError_t launch_force(const ForcePlan &plan, const StepArgs &a, hipStream_t st);

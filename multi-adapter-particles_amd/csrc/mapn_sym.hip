@@ -1,0 +1,275 @@
+// mapn_sym.hip -- the all-pairs force with Newton's third law: every UNORDERED pair is evaluated
+// once and feeds both bodies (a_i += s r, a_j -= s r), i.e. 14 packed ops + 2 v_rsq_f32 per FOUR
+// ordered interactions instead of 11 + 2 per two (mapn_kernels.hip).  Same pair term
+// (nBodyGravityCS.hlsl:46-56), same integrator (:103-108), different summation order -- parity with
+// the oracle is by the same tolerances as the one-sided kernels (tests/test_gpu_sym.py).
+//
+// Why it is not free: the reaction -s r belongs to body j, and in the one-sided kernels every lane
+// of a wave works on the SAME j (broadcast from the scalar cache), so collecting it would need a
+// 64-lane reduction per j.  Here the roles are arranged systolically instead:
+//   * a lane owns 8 bodies i (four packed pairs: positions + accumulators in registers) -- an
+//     I-block of 512 bodies per wave;
+//   * a J-block is 64 bodies, ONE per lane, travelling with its reaction accumulator; after each step
+//     (4 packed evaluations = 16 interactions per lane) the travelling body and its reaction move one
+//     lane on (6 ds_bpermute_b32: through the LDS crossbar), so after 64 steps every lane has met
+//     every body of the J-block and each body is back home with its complete reaction.
+// Measured (tools/ubench.hip, profiles/r02_ubench_sym.txt): 7.4e12 interactions/s for this loop
+// against 4.9e12 for the one-sided pair term; DPP rotation (v_mov_b32_dpp wave_ror:1, ~10 cycles
+// each) 6.5e12; LDS float atomics for the reaction (ds_add_f32, ~195 cycles per wave-instruction)
+// 1.1e12; with 4 bodies i per lane the rotation eats the gain (5.3e12).
+//
+// Coverage of the N^2 ordered pairs (N a multiple of 512): I-block a meets, symmetrically, the
+// I-blocks a+1 .. a+D (mod NB, D = (NB-1)/2, NB = N/512) 64 bodies at a time, for even NB also
+// a+NB/2 when a < NB/2; and itself one-sidedly (no reaction kept).  Every unordered pair of
+// blocks is met exactly once; every body collects its force as: rows of its own I-block (role i)
+// + one row per meeting of its J-block (role j), all written to scratch and summed in a FIXED
+// order by sym_reduce_integrate_kernel -- no float atomics, bit-reproducible.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mapn_kernels.h"
+
+namespace mapn {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int SYM_K2 = 4;                 // packed pairs of bodies i per lane
+constexpr uint32_t SYM_IB = 128u * SYM_K2; // bodies per I-block (512)
+
+__device__ __forceinline__ float lane_next(float v, int addr)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+}
+
+struct SymBodies {
+    v2f xi[SYM_K2], yi[SYM_K2], zi[SYM_K2];
+    v2f ax[SYM_K2], ay[SYM_K2], az[SYM_K2];
+};
+
+// one step against the travelling body (xj, yj, zj): SYMMETRIC -- b collects the reaction on j
+// The reaction travels as the LOW half of a register pair whose high half stays zero, so the first
+// evaluation's fma can take it as its addend and ONE add per component folds the two halves again.
+__device__ __forceinline__ void sym_step(SymBodies &b, float xj, float yj, float zj, v2f soft2,
+                                         v2f &bx, v2f &by, v2f &bz)
+{
+    v2f rx = bx, ry = by, rz = bz;                       // (reaction so far, 0)
+#pragma unroll
+    for (int k = 0; k < SYM_K2; k++) {
+        const v2f dx = xj - b.xi[k];
+        const v2f dy = yj - b.yi[k];
+        const v2f dz = zj - b.zi[k];
+        v2f d = __builtin_elementwise_fma(dx, dx, soft2);
+        d = __builtin_elementwise_fma(dy, dy, d);
+        d = __builtin_elementwise_fma(dz, dz, d);
+        v2f inv;
+        inv.x = __builtin_amdgcn_rsqf(d.x);
+        inv.y = __builtin_amdgcn_rsqf(d.y);
+        const v2f inv3 = inv * inv * inv;
+        b.ax[k] = __builtin_elementwise_fma(dx, inv3, b.ax[k]);
+        b.ay[k] = __builtin_elementwise_fma(dy, inv3, b.ay[k]);
+        b.az[k] = __builtin_elementwise_fma(dz, inv3, b.az[k]);
+        rx = __builtin_elementwise_fma(-dx, inv3, rx);
+        ry = __builtin_elementwise_fma(-dy, inv3, ry);
+        rz = __builtin_elementwise_fma(-dz, inv3, rz);
+    }
+    bx.x = rx.x + rx.y;
+    by.x = ry.x + ry.y;
+    bz.x = rz.x + rz.y;
+}
+
+// one step, ONE-SIDED (the I-block against itself: every ordered pair is met from both sides anyway)
+__device__ __forceinline__ void one_step(SymBodies &b, float xj, float yj, float zj, v2f soft2)
+{
+#pragma unroll
+    for (int k = 0; k < SYM_K2; k++) {
+        const v2f dx = xj - b.xi[k];
+        const v2f dy = yj - b.yi[k];
+        const v2f dz = zj - b.zi[k];
+        v2f d = __builtin_elementwise_fma(dx, dx, soft2);
+        d = __builtin_elementwise_fma(dy, dy, d);
+        d = __builtin_elementwise_fma(dz, dz, d);
+        v2f inv;
+        inv.x = __builtin_amdgcn_rsqf(d.x);
+        inv.y = __builtin_amdgcn_rsqf(d.y);
+        const v2f inv3 = inv * inv * inv;
+        b.ax[k] = __builtin_elementwise_fma(dx, inv3, b.ax[k]);
+        b.ay[k] = __builtin_elementwise_fma(dy, inv3, b.ay[k]);
+        b.az[k] = __builtin_elementwise_fma(dz, inv3, b.az[k]);
+    }
+}
+
+}  // namespace
+
+// grid = (S, NB)   block = 64 * WAVES
+// Workgroup (s, a): I-block a, part s of S of its meetings.  The meetings of an I-block are numbered
+// m = 0 .. M-1: m < 8 -> itself, J-block a*8 + m, one-sided; then 8 per partner block a + d.
+// The workgroup's part [m0, m1) is dealt to its waves contiguously.  Every wave keeps the I-block's
+// accumulators in registers for all of its meetings; at the end the WAVES copies are combined in LDS
+// in ascending wave order into ONE row arow[a][s][512]; each symmetric meeting writes ONE row
+// brow[jblock][d-1][64] with the reactions of the J-block's bodies.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 4) void force_sym_kernel(const SymArgs p)
+{
+    __shared__ float comb[3][SYM_IB];
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t s = blockIdx.x, a = blockIdx.y;
+    const uint32_t nb = p.nb, half = p.half_d;             // half_d = NB/2 when NB is even, else 0
+    const uint32_t D = (nb - 1u) / 2u;
+    const uint32_t M = 8u * (1u + D) + ((half && a < half) ? 8u : 0u);
+    // part s of S, then wave w of WAVES, both by the same even split (the first `rem` take one more)
+    const uint32_t pm0 = (uint32_t)(((uint64_t)M * s) / p.parts), pm1 = (uint32_t)(((uint64_t)M * (s + 1u)) / p.parts);
+    const uint32_t cnt = pm1 - pm0;
+    const uint32_t m0 = pm0 + (uint32_t)(((uint64_t)cnt * w) / WAVES), m1 = pm0 + (uint32_t)(((uint64_t)cnt * (w + 1u)) / WAVES);
+
+    const float4 *__restrict__ pos = p.pos_old;
+    SymBodies b;
+#pragma unroll
+    for (int k = 0; k < SYM_K2; k++) {
+        const float4 b0 = pos[a * SYM_IB + (2 * k) * 64u + lane], b1 = pos[a * SYM_IB + (2 * k + 1) * 64u + lane];
+        b.xi[k] = v2f{b0.x, b1.x}; b.yi[k] = v2f{b0.y, b1.y}; b.zi[k] = v2f{b0.z, b1.z};
+        b.ax[k] = v2f{0.f, 0.f}; b.ay[k] = v2f{0.f, 0.f}; b.az[k] = v2f{0.f, 0.f};
+    }
+    const v2f soft2 = v2f{p.soft2, p.soft2};
+    const int next = (int)((lane + 1u) & 63u) * 4;         // ds_bpermute: take the value of lane + 1
+
+    // J-block of meeting m (and whether it is symmetric); the NEXT meeting's bodies are fetched while
+    // the current one is computed (a meeting is ~9 us of a wave's life, a global load ~1-2 us)
+    auto meeting = [&](uint32_t m, uint32_t &jb, uint32_t &d) {
+        const uint32_t grp = m >> 3, t = m & 7u;           // grp 0: own block; grp g: partner a + g (the last may be the half ring)
+        d = grp <= D ? grp : half;
+        uint32_t ap = a + d;
+        ap = ap >= nb ? ap - nb : ap;
+        jb = ap * 8u + t;
+    };
+    // diagnostic launches only (mapn_measure_clock): stamps around the wave's meetings; null otherwise
+    unsigned long long st_c = 0, st_r = 0;
+    if (p.stamps) asm volatile("s_memrealtime %0\n s_memtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(st_r), "=s"(st_c));
+    uint32_t jb = 0, d = 0;
+    float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m0 < m1) { meeting(m0, jb, d); pn = pos[jb * 64u + lane]; }
+    for (uint32_t m = m0; m < m1; m++) {
+        const uint32_t jb_cur = jb, d_cur = d;
+        float xj = pn.x, yj = pn.y, zj = pn.z;
+        if (m + 1u < m1) { meeting(m + 1u, jb, d); pn = pos[jb * 64u + lane]; }
+        // (A wave-private LDS copy of the J-block read with one ds_read_b128 per step instead of the three
+        //  position moves measured 3 % slower: 6.29e12 vs 6.64e12 against 4.83e12 / 4.96e12 one-sided.)
+        if (d_cur == 0u) {
+#pragma nounroll
+            for (int k = 0; k < 64; k++) {
+                const float nx = lane_next(xj, next), ny = lane_next(yj, next), nz = lane_next(zj, next);
+                one_step(b, xj, yj, zj, soft2);
+                xj = nx; yj = ny; zj = nz;
+            }
+        } else {
+            v2f bx = v2f{0.f, 0.f}, by = v2f{0.f, 0.f}, bz = v2f{0.f, 0.f};
+#pragma nounroll
+            for (int k = 0; k < 64; k++) {
+                // the travelling position does not change during the step: its move overlaps the step
+                const float nx = lane_next(xj, next), ny = lane_next(yj, next), nz = lane_next(zj, next);
+                sym_step(b, xj, yj, zj, soft2, bx, by, bz);
+                xj = nx; yj = ny; zj = nz;
+                bx.x = lane_next(bx.x, next); by.x = lane_next(by.x, next); bz.x = lane_next(bz.x, next);
+            }
+            // 64 moves: every body is back in its home lane with its complete reaction from this I-block
+            p.brow[((size_t)jb_cur * p.brows + (d_cur - 1u)) * 64u + lane] = make_float4(bx.x, by.x, bz.x, 0.f);
+        }
+    }
+
+    if (p.stamps) {
+        asm volatile("" :: "v"(b.ax[0]), "v"(b.ay[0]), "v"(b.az[0]));
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            const size_t wave = ((size_t)a * p.parts + s) * WAVES + w;
+            p.stamps[2 * wave] = c1 - st_c;
+            p.stamps[2 * wave + 1] = r1 - st_r;
+        }
+    }
+    // combine the WAVES copies of the I-block's accumulators in ascending wave order
+    for (uint32_t ww = 0; ww < WAVES; ww++) {
+        if (w == ww) {
+#pragma unroll
+            for (int k = 0; k < SYM_K2; k++) {
+                const uint32_t e0 = (2 * k) * 64u + lane, e1 = e0 + 64u;
+                if (ww == 0) {
+                    comb[0][e0] = b.ax[k].x; comb[0][e1] = b.ax[k].y;
+                    comb[1][e0] = b.ay[k].x; comb[1][e1] = b.ay[k].y;
+                    comb[2][e0] = b.az[k].x; comb[2][e1] = b.az[k].y;
+                } else {
+                    comb[0][e0] += b.ax[k].x; comb[0][e1] += b.ax[k].y;
+                    comb[1][e0] += b.ay[k].x; comb[1][e1] += b.ay[k].y;
+                    comb[2][e0] += b.az[k].x; comb[2][e1] += b.az[k].y;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float4 *row = p.arow + ((size_t)a * p.parts + s) * SYM_IB;
+    for (uint32_t e = threadIdx.x; e < SYM_IB; e += 64u * WAVES) row[e] = make_float4(comb[0][e], comb[1][e], comb[2][e], 0.f);
+}
+
+// One thread per body: rows of its I-block (role i) in ascending part order, then the rows of its
+// J-block (role j) in ascending partner distance, then mass, kick, damp, drift (hlsl:103-108).
+__global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs p)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= p.n) return;
+    const uint32_t a = i / SYM_IB, jb = i >> 6;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    const float4 *ar = p.arow + (size_t)a * p.parts * SYM_IB + (i - a * SYM_IB);
+    for (uint32_t s = 0; s < p.parts; s++) {
+        const float4 v = ar[(size_t)s * SYM_IB];
+        ax += v.x; ay += v.y; az += v.z;
+    }
+    // rows d-1 = 0 .. D-1 always exist; the half-ring row D exists for the blocks that were the far partner
+    const uint32_t D = (p.nb - 1u) / 2u;
+    const uint32_t rows = D + ((p.half_d && a >= p.half_d) ? 1u : 0u);
+    const float4 *br = p.brow + (size_t)jb * p.brows * 64u + (i & 63u);
+    uint32_t r = 0;
+    for (; r + 8u <= rows; r += 8u) {                      // 8 loads in flight, summed in ascending order
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = br[(size_t)(r + u) * 64u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { ax += v[u].x; ay += v[u].y; az += v[u].z; }
+    }
+    for (; r < rows; r++) {
+        const float4 v = br[(size_t)r * 64u];
+        ax += v.x; ay += v.y; az += v.z;
+    }
+    ax *= p.mass; ay *= p.mass; az *= p.mass;
+    const float4 pos = p.pos_old[i];
+    const float *v = p.vel_old + 3 * (size_t)i;
+    float vx = v[0], vy = v[1], vz = v[2];
+    vx = __builtin_fmaf(ax, p.dt, vx) * p.damping;
+    vy = __builtin_fmaf(ay, p.dt, vy) * p.damping;
+    vz = __builtin_fmaf(az, p.dt, vz) * p.damping;
+    float4 o;
+    o.x = __builtin_fmaf(vx, p.dt, pos.x);
+    o.y = __builtin_fmaf(vy, p.dt, pos.y);
+    o.z = __builtin_fmaf(vz, p.dt, pos.z);
+    o.w = __builtin_sqrtf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)));
+    p.pos_new[i] = o;
+    float *vo = p.vel_new + 3 * (size_t)i;
+    vo[0] = vx; vo[1] = vy; vo[2] = vz;
+}
+
+hipError_t launch_force_sym(const SymArgs &a, uint32_t waves, hipStream_t st)
+{
+    const dim3 grid(a.parts, a.nb);
+    if (waves == 4) hipLaunchKernelGGL((force_sym_kernel<4>), grid, dim3(256), 0, st, a);
+    else if (waves == 8) hipLaunchKernelGGL((force_sym_kernel<8>), grid, dim3(512), 0, st, a);
+    else return hipErrorInvalidConfiguration;
+    return hipGetLastError();
+}
+
+hipError_t launch_sym_reduce(const SymArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(sym_reduce_integrate_kernel, dim3((a.n + 255u) / 256u), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace mapn

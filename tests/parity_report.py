@@ -48,21 +48,26 @@ def run_report(n=65536, marks=(1, 10, 100, 1000), seed=1, with_f64=True, f64_max
     out = {"bodies": n, "seed": seed, "regime": "mass=70000/N, soft2=25, dt=0.1, damping=1", "threads": o.hardware_threads(),
            "marks": list(marks), "timing_s": {}, "rows": []}
     snaps = {}
-    with mapn.Compute(n, mass=70000.0 / n, seed=seed) as c:
-        assert np.array_equal(c.download_state()[0], pos)
-        done, t0 = 0, time.perf_counter()
-        for m in marks:
-            for _ in range(m - done):
-                c.Simulate(n, c.GetFenceValue())
-            done = m
-            snaps[("device", m)] = c.download_state()
-        out["timing_s"]["device"] = time.perf_counter() - t0
-        st = c.kernel_stats()
-        waves, sb = st.block_x // 64, st.grid_y
-        out["device_plan"] = {"kernel": st.kernel_name.decode(), "waves": waves, "sb": sb, "j_splits": st.j_splits,
-                              "bodies_per_lane": st.bodies_per_lane, "epilogue": st.epilogue}
-        v0 = vel.astype(np.float64).sum(0)
-        out["momentum_drift_rel"] = float(np.abs(snaps[("device", marks[-1])][1].astype(np.float64).sum(0) - v0).max() / (n * 15.0))
+    # two device legs: "device" = the default kernel (MAPN_KERNEL_AUTO: the symmetric kernel where it applies),
+    # "device1s" = the one-sided scalar-cache kernel, whose summation order the `matched` oracle restates
+    for leg, kern in (("device", mapn.KERNEL_AUTO), ("device1s", mapn.KERNEL_SCALAR)):
+        with mapn.Compute(n, mass=70000.0 / n, seed=seed, kernel=kern) as c:
+            assert np.array_equal(c.download_state()[0], pos)
+            done, t0 = 0, time.perf_counter()
+            for m in marks:
+                for _ in range(m - done):
+                    c.Simulate(n, c.GetFenceValue())
+                done = m
+                snaps[(leg, m)] = c.download_state()
+            out["timing_s"][leg] = time.perf_counter() - t0
+            st = c.kernel_stats()
+            out[leg + "_plan"] = {"kernel": st.kernel_name.decode(), "waves": st.block_x // 64, "sb": st.grid_y, "j_splits": st.j_splits,
+                                  "bodies_per_lane": st.bodies_per_lane, "epilogue": st.epilogue}
+            if leg == "device1s":
+                waves, sb = st.block_x // 64, st.grid_y
+            v0 = vel.astype(np.float64).sum(0)
+            out[leg + "_momentum_drift_rel"] = float(np.abs(snaps[(leg, marks[-1])][1].astype(np.float64).sum(0) - v0).max() / (n * 15.0))
+    out["momentum_drift_rel"] = out["device_momentum_drift_rel"]
     sims = {"ref": OracleSim(o, pos, vel, params=prm),
             "acc64": OracleSim(o, pos, vel, params=prm, sum_spec=SumSpec(SUM_FP64_ACC)),
             "matched": OracleSim(o, pos, vel, params=prm, sum_spec=SumSpec(SUM_ORDER_MATCHED, waves, sb))}
@@ -81,12 +86,13 @@ def run_report(n=65536, marks=(1, 10, 100, 1000), seed=1, with_f64=True, f64_max
             snaps[(name, m)] = (p.copy(), v.copy())
         out["timing_s"][name] = time.perf_counter() - t0
         log(f"# oracle {name}: {out['timing_s'][name]:.1f} s for {done} steps of {n} bodies on {o.hardware_threads()} threads")
-    pairs = [("device", "ref"), ("device", "matched"), ("device", "acc64"), ("ref", "acc64"), ("matched", "acc64")]
+    pairs = [("device", "ref"), ("device", "acc64"), ("device1s", "ref"), ("device1s", "matched"), ("device1s", "acc64"),
+             ("device", "device1s"), ("ref", "acc64"), ("matched", "acc64")]
     if with_f64:
-        pairs += [("device", "f64"), ("ref", "f64"), ("matched", "f64"), ("acc64", "f64")]
+        pairs += [("device", "f64"), ("device1s", "f64"), ("ref", "f64"), ("matched", "f64"), ("acc64", "f64")]
     for m in marks:
         for a, b in pairs:
-            if (b, m) not in have and b != "device":
+            if (b, m) not in have and not b.startswith("device"):
                 continue
             row = {"steps": m, "a": a, "b": b, **stats(snaps[(a, m)][0], snaps[(b, m)][0])}
             dv = np.linalg.norm(snaps[(a, m)][1].astype(np.float64) - snaps[(b, m)][1].astype(np.float64), axis=1)

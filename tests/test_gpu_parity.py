@@ -187,13 +187,20 @@ def test_ticket_epilogue_is_bit_identical_to_two_kernel_form(n, kernel, k, waves
         np.testing.assert_array_equal(out[0][b][1], out[1][b][1])
 
 
-def test_default_plan_is_one_launch_per_step():
-    """VERDICT r1 #4: the default 65 536-body step is ONE kernel launch (ticket epilogue)."""
+def test_default_plans_at_65536_bodies():
+    """the one-sided 65 536-body step is ONE kernel launch (ticket epilogue).  Since
+    round 2 MAPN_KERNEL_AUTO runs the symmetric kernel there (force launch + its reduce launch)."""
+    with mapn.Compute(65536, mass=70000.0 / 65536, kernel=mapn.KERNEL_SCALAR) as c:
+        draw(c, 2)
+        st = c.kernel_stats()
+    assert st.kernel_name.decode() == "force_sgpr_kernel"
+    assert st.fused == 1 and st.epilogue == 2 and st.force_launches_per_step == 1
+    assert (st.grid_x, st.grid_y, st.block_x, st.j_splits) == (512, 8, 512, 64)
     with mapn.Compute(65536, mass=70000.0 / 65536) as c:
         draw(c, 2)
         st = c.kernel_stats()
-    assert st.fused == 1 and st.epilogue == 2 and st.force_launches_per_step == 1
-    assert (st.grid_x, st.grid_y, st.block_x, st.j_splits) == (512, 8, 512, 64)
+    assert st.kernel_name.decode() == "force_sym_kernel" and st.epilogue == 3 and st.fused == 0
+    assert (st.grid_x, st.grid_y, st.block_x) == (16, 128, 512)
 
 
 def test_graph_replay_is_bit_identical_to_eager():
@@ -201,17 +208,18 @@ def test_graph_replay_is_bit_identical_to_eager():
     launches, including a change of num_active (re-capture) and timer-sampled steps."""
     n = 8192
     out = []
-    for flags in (0, mapn.FLAG_USE_GRAPH):
-        with mapn.Compute(n, mass=70000.0 / n, flags=flags) as c:
+    for flags, kern in ((0, mapn.KERNEL_SCALAR), (mapn.FLAG_USE_GRAPH, mapn.KERNEL_SCALAR), (0, mapn.KERNEL_AUTO), (mapn.FLAG_USE_GRAPH, mapn.KERNEL_AUTO)):
+        with mapn.Compute(n, mass=70000.0 / n, flags=flags, kernel=kern) as c:
             c.set_timers(4)
             draw(c, 9)
             draw(c, 3, num_active=5000)
             draw(c, 4)
             out.append((c.download_buffer(0), c.download_buffer(1), c.GetFenceValue()))
-    for b in (0, 1):
-        np.testing.assert_array_equal(out[0][b][0], out[1][b][0])
-        np.testing.assert_array_equal(out[0][b][1], out[1][b][1])
-    assert out[0][2] == out[1][2]
+    for x, y in ((0, 1), (2, 3)):                    # one-sided eager vs graph; symmetric (+ one-sided partial steps) eager vs graph
+        for b in (0, 1):
+            np.testing.assert_array_equal(out[x][b][0], out[y][b][0])
+            np.testing.assert_array_equal(out[x][b][1], out[y][b][1])
+        assert out[x][2] == out[y][2]
 
 
 def test_all_pairs_golden_config1_100_steps(oracle, golden_dir):
@@ -332,9 +340,10 @@ def test_lds_kernel_selected_by_config_matches_scalar_cache_kernel(oracle):
         with mapn.Compute(n, mass=70000.0 / n, kernel=kern) as c:
             draw(c, 2)
             out.append(c.download_state())
-            assert c.kernel_stats().kernel_name.decode() == ("force_lds_kernel" if kern == mapn.KERNEL_LDS else "force_sgpr_kernel")
+            assert c.kernel_stats().kernel_name.decode() == {mapn.KERNEL_LDS: "force_lds_kernel", mapn.KERNEL_SCALAR: "force_sgpr_kernel",
+                                                             mapn.KERNEL_AUTO: "force_sym_kernel"}[kern]
     np.testing.assert_array_equal(out[0][0], out[1][0])
-    np.testing.assert_array_equal(out[1][0], out[2][0])
+    assert errs(out[2][0][:, :3], out[1][0][:, :3], SPREAD)[0] < 1e-6     # AUTO = the symmetric kernel: another summation order
 
 
 # ---------------------------------------------------------------------------------------------

@@ -46,8 +46,11 @@ for k, cs in sorted(agg.items()):
 # not match the kernels it is running (a committed traffic number goes stale)
 import hashlib
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out["_kernel_source_sha16"] = hashlib.sha256(open(os.path.join(here, "multi-adapter-particles_amd", "csrc", "mapn_kernels.hip"), "rb").read()).hexdigest()[:16]
-lines.append(f"kernel source sha16 (multi-adapter-particles_amd/csrc/mapn_kernels.hip): {out['_kernel_source_sha16']}")
+_h = hashlib.sha256()
+for _f in ("mapn_kernels.hip", "mapn_sym.hip"):
+    _h.update(open(os.path.join(here, "multi-adapter-particles_amd", "csrc", _f), "rb").read())
+out["_kernel_source_sha16"] = _h.hexdigest()[:16]
+lines.append(f"kernel source sha16 (multi-adapter-particles_amd/csrc/mapn_kernels.hip + mapn_sym.hip): {out['_kernel_source_sha16']}")
 os.makedirs("profiles", exist_ok=True)
 open(f"profiles/{tag}_pmc_summary.txt", "w").write(__doc__ + "\n" + "\n".join(lines) + "\n")
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)

@@ -14,25 +14,40 @@
 typedef float float2v __attribute__((ext_vector_type(2)));
 
 enum Mix { FMA = 0, PKFMA, RSQ, PAIR_SCALAR, PAIR_PK, FMA_SGPR, PKFMA_BCAST, PAIR_MFMA, MFMA4, PAIR_PK8, RSQ_PK_ALT, RSQ_PK_SEQ,
-           MFMA16, MFMA32, PK16_MFMA16_1, PK16_MFMA16_2, PK16_MFMA32_1, PAIR_ACC_MFMA16, PAIR_ACC_MFMA32, PAIR_R2_MFMA16, MIXES };
+           MFMA16, MFMA32, PK16_MFMA16_1, PK16_MFMA16_2, PK16_MFMA32_1, PAIR_ACC_MFMA16, PAIR_ACC_MFMA32, PAIR_R2_MFMA16,
+           DPP_WAVE_ROR, DPP_ROW_ROR, PAIR_SYM, PAIR_SYM_NOROT, PAIR_SYM8_BPERM, PAIR_SYM8_DPP, BPERM, PAIR_SYM4_LDS, PAIR_SYM8_LDS, MIXES };
 static const char *mix_name[MIXES] = {"v_fma_f32 x16", "v_pk_fma_f32 x16", "v_rsq_f32 x16", "pair scalar (12 ops)", "pair packed (2 bodies)", "v_fma_f32 sgpr-src x16", "v_pk_fma_f32 op_sel bcast x16", "pair packed, accumulate on mfma 4x4x1", "v_mfma_f32_4x4x1_16b x8", "8 pk + 2 rsq (no accumulate)", "8 x (v_rsq, v_pk_fma) alternating", "8 v_rsq then 8 v_pk_fma",
                                       "v_mfma_f32_16x16x4_f32 x8", "v_mfma_f32_32x32x2_f32 x4", "16 v_pk_fma + 1 mfma16x16x4", "16 v_pk_fma + 2 mfma16x16x4",
                                       "16 v_pk_fma + 1 mfma32x32x2", "pair packed, accumulate on mfma16x16x4", "pair packed, accumulate on mfma32x32x2",
-                                      "pair: r^2 on mfma16x16x4, sum-form accumulate"};
-static const int mix_insts[MIXES] = {16, 16, 16, 12 * 4, 13 * 2, 16, 16, 12 * 2, 8, 10 * 2, 16, 16, 8, 4, 17, 18, 17, 10 * 2 + 4, 10 * 2 + 4, 17};      // wave-instructions per loop body
-static const double mix_pairs[MIXES] = {0, 0, 0, 4, 4, 0, 0, 4, 0, 4, 0, 0, 0, 0, 0, 0, 0, 4, 4, 4};                  // pairs per lane per loop body
+                                      "pair: r^2 on mfma16x16x4, sum-form accumulate",
+                                      "v_mov_b32_dpp wave_ror:1 x16", "v_mov_b32_dpp row_ror:1 x16",
+                                      "pair SYMMETRIC (a_i += , b_j -= ; j-set rotates wave_ror:1)", "pair SYMMETRIC without the rotation",
+                                      "pair SYMMETRIC, 8 bodies i per lane, rotation by ds_bpermute_b32", "pair SYMMETRIC, 8 bodies i per lane, rotation by dpp wave_ror", "ds_bpermute_b32 x16",
+                                      "pair SYMMETRIC, 4 bodies i per lane, j and b_j in wave-private LDS", "pair SYMMETRIC, 8 bodies i per lane, j and b_j in wave-private LDS"};
+static const int mix_insts[MIXES] = {16, 16, 16, 12 * 4, 13 * 2, 16, 16, 12 * 2, 8, 10 * 2, 16, 16, 8, 4, 17, 18, 17, 10 * 2 + 4, 10 * 2 + 4, 17, 16, 16, 16 * 2 + 9, 16 * 2, 16 * 4 + 9, 16 * 4 + 9, 16, 16 * 2 + 9, 16 * 4 + 9};      // wave-instructions per loop body
+static const double mix_pairs[MIXES] = {0, 0, 0, 4, 4, 0, 0, 4, 0, 4, 0, 0, 0, 0, 0, 0, 0, 4, 4, 4, 0, 0, 8, 8, 16, 16, 0, 8, 16};                  // pairs per lane per loop body
 
 template <int MIX>
 __global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, unsigned long long *rt, int iters, float seed)
 {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    __shared__ f4v tile[4][64];
+    __shared__ float bacc_lds[4][3][64];
+    __shared__ f4v bacc4[4][64];
+    const int wv = threadIdx.x >> 6;
+    int jslot = threadIdx.x & 63;
+    tile[wv][jslot] = f4v{seed * 3.f + jslot, seed * 5.f - jslot, seed * 7.f + 0.5f * jslot, 0.f};
+    bacc_lds[wv][0][jslot] = 0.f; bacc_lds[wv][1][jslot] = 0.f; bacc_lds[wv][2][jslot] = 0.f; bacc4[wv][jslot] = f4v{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
     float a[16];
     for (int i = 0; i < 16; i++) a[i] = seed + i * 0.001f + threadIdx.x * 1e-6f;
     float2v p[16];
     for (int i = 0; i < 16; i++) p[i] = float2v{a[i], a[i] * 0.5f};
+    float2v q[12], r[12];
+    for (int i = 0; i < 12; i++) { q[i] = float2v{a[i] * 1.5f, a[i] * 0.25f}; r[i] = float2v{0.f, 0.f}; }
     const float m = 0.999f, c = 0.0001f;
     float sx = seed * 3.f, sy = seed * 5.f, sz = seed * 7.f, soft2 = 25.f;
     asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sx) : "v"(seed * 3.f));
-    typedef float f4v __attribute__((ext_vector_type(4)));
     f4v macc[4];
     for (int i = 0; i < 4; i++) macc[i] = f4v{0.f, 0.f, 0.f, 0.f};
     typedef float f16v __attribute__((ext_vector_type(16)));
@@ -173,6 +188,111 @@ __global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, u
                          "v_pk_fma_f32 %3, %7, %8, %3 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %4, %7, %8, %4 op_sel:[0,1,0]\n v_pk_fma_f32 %5, %7, %9, %5 op_sel_hi:[1,0,1]\n"
                          : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]) : "v"(s0), "v"(s1), "v"(p[12]), "v"(p[13]));
             asm volatile("v_pk_add_f32 %0, %0, %2\n v_pk_add_f32 %1, %1, %3" : "+v"(p[6]), "+v"(p[7]) : "v"(s0), "v"(s1));
+        } else if (MIX == DPP_WAVE_ROR || MIX == DPP_ROW_ROR) {
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                a[i] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[i]), MIX == DPP_WAVE_ROR ? 0x13C : 0x121, 0xf, 0xf, false));
+        } else if (MIX == PAIR_SYM || MIX == PAIR_SYM_NOROT) {
+            // Newton's third law inside a wave: a lane owns 4 bodies i (two packed pairs, accumulators p[6..11]) and
+            // carries ONE body j (position a[0..2], its accumulators kept as packed lo/hi partial sums p[12..14]).
+            // One step: 2 packed evaluations (14 v_pk + 2 v_rsq each: a_i += r s, b_j -= r s) = 8 interactions per
+            // lane, then the j body and its accumulators rotate one lane (9 v_mov_b32_dpp wave_ror:1).
+            const float2v sft = float2v{soft2, soft2};
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const float2v dx = a[0] - p[3 * k], dy = a[1] - p[3 * k + 1], dz = a[2] - p[3 * k + 2];
+                float2v d = __builtin_elementwise_fma(dx, dx, sft);
+                d = __builtin_elementwise_fma(dy, dy, d);
+                d = __builtin_elementwise_fma(dz, dz, d);
+                float2v inv;
+                inv.x = __builtin_amdgcn_rsqf(d.x); inv.y = __builtin_amdgcn_rsqf(d.y);
+                const float2v i3 = inv * inv * inv;
+                p[6 + 3 * k] = __builtin_elementwise_fma(dx, i3, p[6 + 3 * k]);
+                p[7 + 3 * k] = __builtin_elementwise_fma(dy, i3, p[7 + 3 * k]);
+                p[8 + 3 * k] = __builtin_elementwise_fma(dz, i3, p[8 + 3 * k]);
+                p[12] = __builtin_elementwise_fma(-dx, i3, p[12]);
+                p[13] = __builtin_elementwise_fma(-dy, i3, p[13]);
+                p[14] = __builtin_elementwise_fma(-dz, i3, p[14]);
+            }
+            if (MIX == PAIR_SYM) {
+#define ROR1(v) v = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, false))
+                ROR1(a[0]); ROR1(a[1]); ROR1(a[2]);
+                ROR1(p[12].x); ROR1(p[12].y); ROR1(p[13].x); ROR1(p[13].y); ROR1(p[14].x); ROR1(p[14].y);
+#undef ROR1
+            }
+        } else if (MIX == BPERM) {
+            const int addr = (int)(((threadIdx.x & 63u) + 1u) & 63u) * 4;
+#pragma unroll
+            for (int i = 0; i < 16; i++) a[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, a[i])));
+        } else if (MIX == PAIR_SYM8_BPERM || MIX == PAIR_SYM8_DPP) {
+            // as PAIR_SYM with 8 bodies i per lane (4 packed pairs: positions q[0..11], accumulators r[0..11]): 4 packed
+            // evaluations = 16 interactions per lane per rotation step, the 9 rotating registers moved either through
+            // the LDS crossbar (ds_bpermute_b32: no VALU cycles) or by DPP
+            const float2v sft = float2v{soft2, soft2};
+            const int addr = (int)(((threadIdx.x & 63u) + 1u) & 63u) * 4;
+            float nx, ny, nz;
+            if (MIX == PAIR_SYM8_BPERM) {           // the j position does not change during the step: rotate it up front
+                nx = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, a[0])));
+                ny = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, a[1])));
+                nz = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, a[2])));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float2v dx = a[0] - q[3 * k], dy = a[1] - q[3 * k + 1], dz = a[2] - q[3 * k + 2];
+                float2v d = __builtin_elementwise_fma(dx, dx, sft);
+                d = __builtin_elementwise_fma(dy, dy, d);
+                d = __builtin_elementwise_fma(dz, dz, d);
+                float2v inv;
+                inv.x = __builtin_amdgcn_rsqf(d.x); inv.y = __builtin_amdgcn_rsqf(d.y);
+                const float2v i3 = inv * inv * inv;
+                r[3 * k] = __builtin_elementwise_fma(dx, i3, r[3 * k]);
+                r[3 * k + 1] = __builtin_elementwise_fma(dy, i3, r[3 * k + 1]);
+                r[3 * k + 2] = __builtin_elementwise_fma(dz, i3, r[3 * k + 2]);
+                p[12] = __builtin_elementwise_fma(-dx, i3, p[12]);
+                p[13] = __builtin_elementwise_fma(-dy, i3, p[13]);
+                p[14] = __builtin_elementwise_fma(-dz, i3, p[14]);
+            }
+            if (MIX == PAIR_SYM8_BPERM) {
+#define BP(v) v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)))
+                a[0] = nx; a[1] = ny; a[2] = nz;
+                BP(p[12].x); BP(p[12].y); BP(p[13].x); BP(p[13].y); BP(p[14].x); BP(p[14].y);
+#undef BP
+            } else {
+#define ROR1(v) v = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, false))
+                ROR1(a[0]); ROR1(a[1]); ROR1(a[2]);
+                ROR1(p[12].x); ROR1(p[12].y); ROR1(p[13].x); ROR1(p[13].y); ROR1(p[14].x); ROR1(p[14].y);
+#undef ROR1
+            }
+        } else if (MIX == PAIR_SYM4_LDS || MIX == PAIR_SYM8_LDS) {
+            // no rotation at all: the 64 bodies j of the block sit in a wave-private LDS tile; at step k lane l reads
+            // body (l + k) % 64 (one ds_read_b128, distinct address per lane) and adds the reaction it accumulated over
+            // its bodies i to that body's wave-private LDS accumulator (3 ds_add_f32, one lane per address per step ->
+            // the order of the adds is the program order: deterministic)
+            constexpr int NE = MIX == PAIR_SYM8_LDS ? 4 : 2;
+            const float2v sft = float2v{soft2, soft2};
+            const f4v pj = tile[wv][jslot];
+            float2v bx, by, bz;
+#pragma unroll
+            for (int k = 0; k < NE; k++) {
+                const float2v dx = pj.x - q[3 * k], dy = pj.y - q[3 * k + 1], dz = pj.z - q[3 * k + 2];
+                float2v d = __builtin_elementwise_fma(dx, dx, sft);
+                d = __builtin_elementwise_fma(dy, dy, d);
+                d = __builtin_elementwise_fma(dz, dz, d);
+                float2v inv;
+                inv.x = __builtin_amdgcn_rsqf(d.x); inv.y = __builtin_amdgcn_rsqf(d.y);
+                const float2v i3 = inv * inv * inv;
+                r[3 * k] = __builtin_elementwise_fma(dx, i3, r[3 * k]);
+                r[3 * k + 1] = __builtin_elementwise_fma(dy, i3, r[3 * k + 1]);
+                r[3 * k + 2] = __builtin_elementwise_fma(dz, i3, r[3 * k + 2]);
+                if (k == 0) { bx = dx * i3; by = dy * i3; bz = dz * i3; }
+                else { bx = __builtin_elementwise_fma(dx, i3, bx); by = __builtin_elementwise_fma(dy, i3, by); bz = __builtin_elementwise_fma(dz, i3, bz); }
+            }
+            // read-modify-write by the VALU, no LDS atomic (ds_add_f32 measured ~195 cycles per wave-instruction): only
+            // this lane touches body jslot's accumulator in this step and a wave's LDS operations execute in order
+            f4v acc = bacc4[wv][jslot];
+            acc.x -= bx.x + bx.y; acc.y -= by.x + by.y; acc.z -= bz.x + bz.y;
+            bacc4[wv][jslot] = acc;
+            jslot = (jslot + 1) & 63;
         } else if (MIX == MFMA4) {
 #pragma unroll
             for (int i = 0; i < 8; i++) macc[i & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[i], a[15], macc[i & 3], 0, 0, 0);
@@ -182,6 +302,8 @@ __global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, u
     unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0;
     for (int i = 0; i < 16; i++) s += a[i] + p[i].x + p[i].y;
+    for (int i = 0; i < 12; i++) s += q[i].x + r[i].x + r[i].y;
+    s += bacc_lds[wv][0][jslot] + bacc4[wv][jslot].x + bacc4[wv][jslot].y + bacc4[wv][jslot].z;
     for (int i = 0; i < 4; i++) s += macc[i].x + macc[i].y + macc[i].z + macc[i].w;
     for (int i = 0; i < 2; i++) for (int q = 0; q < 16; q++) s += bacc[i][q];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -240,9 +362,11 @@ int main(int argc, char **argv)
     int iters = argc > 1 ? atoi(argv[1]) : 20000;
     hipDeviceProp_t pr; CHECK(hipGetDeviceProperties(&pr, 0));
     printf("device: %s  arch=%s  CUs=%d  clock=%d kHz  wave=%d\n", pr.name, pr.gcnArchName, pr.multiProcessorCount, pr.clockRate, pr.warpSize);
+    if (getenv("UBENCH_SYM_ONLY")) { sweep<PAIR_PK>(iters); sweep<DPP_WAVE_ROR>(iters); sweep<DPP_ROW_ROR>(iters); sweep<PAIR_SYM>(iters); sweep<PAIR_SYM_NOROT>(iters); sweep<PAIR_SYM8_BPERM>(iters); sweep<PAIR_SYM4_LDS>(iters); sweep<PAIR_SYM8_LDS>(iters); return 0; }
     sweep<FMA>(iters); sweep<FMA_SGPR>(iters); sweep<PKFMA>(iters); sweep<PKFMA_BCAST>(iters); sweep<RSQ>(iters);
     sweep<PAIR_SCALAR>(iters); sweep<PAIR_PK>(iters); sweep<PAIR_PK8>(iters); sweep<PAIR_MFMA>(iters); sweep<MFMA4>(iters); sweep<RSQ_PK_ALT>(iters); sweep<RSQ_PK_SEQ>(iters);
     sweep<MFMA16>(iters); sweep<MFMA32>(iters); sweep<PK16_MFMA16_1>(iters); sweep<PK16_MFMA16_2>(iters); sweep<PK16_MFMA32_1>(iters);
     sweep<PAIR_ACC_MFMA16>(iters); sweep<PAIR_ACC_MFMA32>(iters); sweep<PAIR_R2_MFMA16>(iters);
+    sweep<DPP_WAVE_ROR>(iters); sweep<DPP_ROW_ROR>(iters); sweep<PAIR_SYM>(iters); sweep<PAIR_SYM_NOROT>(iters); sweep<BPERM>(iters); sweep<PAIR_SYM8_BPERM>(iters); sweep<PAIR_SYM8_DPP>(iters); sweep<PAIR_SYM4_LDS>(iters); sweep<PAIR_SYM8_LDS>(iters);
     return 0;
 }

@@ -892,7 +892,8 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
         timer->has_force = false;
         timer->force_is_step = false;
     }
-    const bool use_graph = (c->cfg.flags & MAPN_FLAG_USE_GRAPH) && !c->comm && !c->p2p_ready && !timer && active > 0;
+    const bool use_graph = (c->cfg.flags & MAPN_FLAG_USE_GRAPH) && !c->comm && !c->p2p_ready && !timer && active > 0 &&
+                           !c->stamp_next;                 // a stamped diagnostic step is never a replay
     if (int rc = use_graph ? enqueue_step_graph(c, active) : enqueue_step(c, active, timer)) return rc;
     if (timer) {
         HIP_TRY(hipEventRecord(timer->stop, c->compute));              // Compute.cpp:1046-1047

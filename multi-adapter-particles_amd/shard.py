@@ -60,3 +60,49 @@ class ShardPlan:
 
     def gather_bytes_received(self) -> int:
         return 16 * (self.n - self.count)
+
+
+# ---------------------------------------------------------------------------------------------
+# Host-side mirrors of two device-side index maps, so that their combinatorics are checked on a
+# CPU (tests/test_sym_cpu.py); the arithmetic itself lives in csrc/mapn_sym.hip (force_sym_kernel,
+# sym_reduce_integrate_kernel) and csrc/mapn_kernels.hip / mapn_context.cpp (chunk_tiles, flow_row).
+
+def sym_meetings(nb: int):
+    """Meetings of the symmetric kernel: yields (a, partner block, d, symmetric) for every I-block
+    a of `nb`, 8 J-blocks each (not expanded here).  d = 0: the block against itself, one-sided;
+    1 <= d <= D = (nb-1)//2: partner a+d, symmetric; for even nb also d = nb/2 when a < nb/2."""
+    D = (nb - 1) // 2
+    half = nb // 2 if nb % 2 == 0 else 0
+    for a in range(nb):
+        yield a, a, 0, False
+        for d in range(1, D + 1):
+            yield a, (a + d) % nb, d, True
+        if half and a < half:
+            yield a, (a + half) % nb, half, True
+
+
+def sym_reaction_rows(nb: int, block: int) -> list[int]:
+    """Row slots (d - 1) the reduce kernel sums for a J-block lying in I-block `block`."""
+    D = (nb - 1) // 2
+    half = nb // 2 if nb % 2 == 0 else 0
+    return list(range(D + (1 if half and block >= half else 0)))
+
+
+def chunk_tiles(tiles: int, splits: int, chunk: int) -> tuple[int, int]:
+    """64-body tiles [t0, t1) of chunk `chunk` of `splits` (mapn_kernels.hip chunk_tiles)."""
+    base, rem = divmod(tiles, splits)
+    t0 = chunk * base + min(chunk, rem)
+    return t0, t0 + base + (1 if chunk < rem else 0)
+
+
+def flow_row_rotation(n: int, first: int, waves: int, sb: int) -> int:
+    """Block-row rotation of flow mode (mapn_context.cpp enqueue_step): the row holding the first
+    tile of the rank's own slice is dispatched first."""
+    tiles = (n + 63) // 64
+    base, rem = divmod(tiles, waves * sb)
+    t_own = first // 64
+    if t_own < rem * (base + 1):
+        c_own = t_own // (base + 1)
+    else:
+        c_own = rem + (t_own - rem * (base + 1)) // base if base else 0
+    return min(c_own // waves, sb - 1)

@@ -1,0 +1,61 @@
+"""CPU checks of the combinatorics behind two device-side index maps (host mirrors in
+multi-adapter-particles_amd/shard.py; the device arithmetic is in csrc/mapn_sym.hip and
+csrc/mapn_kernels.hip): the symmetric kernel's meeting schedule must cover every unordered pair of
+blocks exactly once, its reduce kernel must read exactly the rows that were written, and flow
+mode's row rotation must start on the rank's own slice without changing which chunk a row names."""
+import itertools
+
+import pytest
+
+from mapn import shard
+
+
+@pytest.mark.parametrize("nb", list(range(1, 20)) + [128, 129, 512])
+def test_symmetric_schedule_covers_every_unordered_block_pair_once(nb):
+    seen = {}
+    written = {b: set() for b in range(nb)}
+    for a, b, d, symmetric in shard.sym_meetings(nb):
+        if symmetric:
+            key = frozenset((a, b))
+            assert a != b and key not in seen, (a, b, d)
+            seen[key] = d
+            assert (d - 1) not in written[b]                  # one row per (partner block, distance)
+            written[b].add(d - 1)
+        else:
+            assert a == b and d == 0
+    assert len(seen) == nb * (nb - 1) // 2                    # every unordered pair of distinct blocks
+    assert set(seen) == {frozenset(p) for p in itertools.combinations(range(nb), 2)}
+    for b in range(nb):                                       # the reduce kernel reads exactly what was written
+        assert sorted(written[b]) == shard.sym_reaction_rows(nb, b), (nb, b)
+
+
+@pytest.mark.parametrize("nb", [2, 3, 8, 128])
+def test_symmetric_schedule_is_balanced(nb):
+    per_block = {}
+    for a, _, d, _ in shard.sym_meetings(nb):
+        per_block[a] = per_block.get(a, 0) + 1
+    assert max(per_block.values()) - min(per_block.values()) <= 1     # the half-ring partner: one extra meeting group
+
+
+@pytest.mark.parametrize("n,world,waves,sb", [(65536, 8, 16, 16), (65536, 2, 8, 8), (4096, 8, 4, 1), (4096, 4, 8, 2),
+                                              (1048576, 8, 8, 8), (3000 * 4, 4, 8, 3), (8192, 2, 16, 4)])
+def test_flow_rotation_starts_on_the_own_slice_and_is_a_permutation(n, world, waves, sb):
+    tiles = (n + 63) // 64
+    for rank in range(world):
+        first, count = shard.shard_range(n, rank, world)
+        rot = shard.flow_row_rotation(n, first, waves, sb)
+        assert 0 <= rot < sb
+        logical = [(y + rot) % sb for y in range(sb)]
+        assert sorted(logical) == list(range(sb))             # a permutation of the rows: every chunk still computed once
+        # the first dispatched row's chunks contain the first tile of the own slice
+        t_lo = shard.chunk_tiles(tiles, waves * sb, logical[0] * waves)[0]
+        t_hi = shard.chunk_tiles(tiles, waves * sb, logical[0] * waves + waves - 1)[1]
+        if tiles >= waves * sb:
+            assert t_lo <= first // 64 < max(t_hi, t_lo + 1), (rank, rot, t_lo, t_hi)
+
+
+def test_chunk_tiles_partition_the_range():
+    for tiles, splits in ((1024, 64), (1024, 256), (47, 64), (100, 7), (1, 1)):
+        edges = [shard.chunk_tiles(tiles, splits, c) for c in range(splits)]
+        assert edges[0][0] == 0 and edges[-1][1] == tiles
+        assert all(edges[c][1] == edges[c + 1][0] for c in range(splits - 1))

@@ -112,7 +112,7 @@ __device__ __forceinline__ void one_step(SymBodies &b, float xj, float yj, float
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 4) void force_sym_kernel(const SymArgs p)
 {
-    __shared__ float comb[3][SYM_IB];
+    __shared__ float comb[WAVES][3][SYM_IB];               // 48 KiB at 8 waves: two workgroups per CU fit
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -155,8 +155,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void force_sym_kernel(const SymArgs 
         const uint32_t jb_cur = jb, d_cur = d;
         float xj = pn.x, yj = pn.y, zj = pn.z;
         if (m + 1u < m1) { meeting(m + 1u, jb, d); pn = pos[jb * 64u + lane]; }
-        // (A wave-private LDS copy of the J-block read with one ds_read_b128 per step instead of the three
-        //  position moves measured 3 % slower: 6.29e12 vs 6.64e12 against 4.83e12 / 4.96e12 one-sided.)
+        // (Alternatives to moving the position, measured on one box each: a wave-private LDS copy of the J-block
+        //  read with one ds_read_b128 per step, also one step ahead: 2-3 % slower; re-reading body (lane + k) % 64
+        //  from global memory every step, fetched one step ahead: 9 % slower.)
         if (d_cur == 0u) {
 #pragma nounroll
             for (int k = 0; k < 64; k++) {
@@ -188,27 +189,23 @@ __global__ __launch_bounds__(64 * WAVES, 4) void force_sym_kernel(const SymArgs 
             p.stamps[2 * wave + 1] = r1 - st_r;
         }
     }
-    // combine the WAVES copies of the I-block's accumulators in ascending wave order
-    for (uint32_t ww = 0; ww < WAVES; ww++) {
-        if (w == ww) {
+    // combine the WAVES copies of the I-block's accumulators: every wave parks its copy in LDS, then
+    // each thread sums one body's WAVES values in ascending wave order (a fixed order: bit-reproducible)
 #pragma unroll
-            for (int k = 0; k < SYM_K2; k++) {
-                const uint32_t e0 = (2 * k) * 64u + lane, e1 = e0 + 64u;
-                if (ww == 0) {
-                    comb[0][e0] = b.ax[k].x; comb[0][e1] = b.ax[k].y;
-                    comb[1][e0] = b.ay[k].x; comb[1][e1] = b.ay[k].y;
-                    comb[2][e0] = b.az[k].x; comb[2][e1] = b.az[k].y;
-                } else {
-                    comb[0][e0] += b.ax[k].x; comb[0][e1] += b.ax[k].y;
-                    comb[1][e0] += b.ay[k].x; comb[1][e1] += b.ay[k].y;
-                    comb[2][e0] += b.az[k].x; comb[2][e1] += b.az[k].y;
-                }
-            }
-        }
-        __syncthreads();
+    for (int k = 0; k < SYM_K2; k++) {
+        const uint32_t e0 = (2 * k) * 64u + lane, e1 = e0 + 64u;
+        comb[w][0][e0] = b.ax[k].x; comb[w][0][e1] = b.ax[k].y;
+        comb[w][1][e0] = b.ay[k].x; comb[w][1][e1] = b.ay[k].y;
+        comb[w][2][e0] = b.az[k].x; comb[w][2][e1] = b.az[k].y;
     }
+    __syncthreads();
     float4 *row = p.arow + ((size_t)a * p.parts + s) * SYM_IB;
-    for (uint32_t e = threadIdx.x; e < SYM_IB; e += 64u * WAVES) row[e] = make_float4(comb[0][e], comb[1][e], comb[2][e], 0.f);
+    for (uint32_t e = threadIdx.x; e < SYM_IB; e += 64u * WAVES) {
+        float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < WAVES; ww++) { ax += comb[ww][0][e]; ay += comb[ww][1][e]; az += comb[ww][2][e]; }
+        row[e] = make_float4(ax, ay, az, 0.f);
+    }
 }
 
 // One thread per body: rows of its I-block (role i) in ascending part order, then the rows of its

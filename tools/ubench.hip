@@ -15,7 +15,7 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 
 enum Mix { FMA = 0, PKFMA, RSQ, PAIR_SCALAR, PAIR_PK, FMA_SGPR, PKFMA_BCAST, PAIR_MFMA, MFMA4, PAIR_PK8, RSQ_PK_ALT, RSQ_PK_SEQ,
            MFMA16, MFMA32, PK16_MFMA16_1, PK16_MFMA16_2, PK16_MFMA32_1, PAIR_ACC_MFMA16, PAIR_ACC_MFMA32, PAIR_R2_MFMA16,
-           DPP_WAVE_ROR, DPP_ROW_ROR, PAIR_SYM, PAIR_SYM_NOROT, PAIR_SYM8_BPERM, PAIR_SYM8_DPP, BPERM, PAIR_SYM4_LDS, PAIR_SYM8_LDS, MIXES };
+           DPP_WAVE_ROR, DPP_ROW_ROR, PAIR_SYM, PAIR_SYM_NOROT, PAIR_SYM8_BPERM, PAIR_SYM8_DPP, BPERM, PAIR_SYM4_LDS, PAIR_SYM8_LDS, SWIZZLE, PAIR_SYM8_SWZ, MIXES };
 static const char *mix_name[MIXES] = {"v_fma_f32 x16", "v_pk_fma_f32 x16", "v_rsq_f32 x16", "pair scalar (12 ops)", "pair packed (2 bodies)", "v_fma_f32 sgpr-src x16", "v_pk_fma_f32 op_sel bcast x16", "pair packed, accumulate on mfma 4x4x1", "v_mfma_f32_4x4x1_16b x8", "8 pk + 2 rsq (no accumulate)", "8 x (v_rsq, v_pk_fma) alternating", "8 v_rsq then 8 v_pk_fma",
                                       "v_mfma_f32_16x16x4_f32 x8", "v_mfma_f32_32x32x2_f32 x4", "16 v_pk_fma + 1 mfma16x16x4", "16 v_pk_fma + 2 mfma16x16x4",
                                       "16 v_pk_fma + 1 mfma32x32x2", "pair packed, accumulate on mfma16x16x4", "pair packed, accumulate on mfma32x32x2",
@@ -23,9 +23,10 @@ static const char *mix_name[MIXES] = {"v_fma_f32 x16", "v_pk_fma_f32 x16", "v_rs
                                       "v_mov_b32_dpp wave_ror:1 x16", "v_mov_b32_dpp row_ror:1 x16",
                                       "pair SYMMETRIC (a_i += , b_j -= ; j-set rotates wave_ror:1)", "pair SYMMETRIC without the rotation",
                                       "pair SYMMETRIC, 8 bodies i per lane, rotation by ds_bpermute_b32", "pair SYMMETRIC, 8 bodies i per lane, rotation by dpp wave_ror", "ds_bpermute_b32 x16",
-                                      "pair SYMMETRIC, 4 bodies i per lane, j and b_j in wave-private LDS", "pair SYMMETRIC, 8 bodies i per lane, j and b_j in wave-private LDS"};
-static const int mix_insts[MIXES] = {16, 16, 16, 12 * 4, 13 * 2, 16, 16, 12 * 2, 8, 10 * 2, 16, 16, 8, 4, 17, 18, 17, 10 * 2 + 4, 10 * 2 + 4, 17, 16, 16, 16 * 2 + 9, 16 * 2, 16 * 4 + 9, 16 * 4 + 9, 16, 16 * 2 + 9, 16 * 4 + 9};      // wave-instructions per loop body
-static const double mix_pairs[MIXES] = {0, 0, 0, 4, 4, 0, 0, 4, 0, 4, 0, 0, 0, 0, 0, 0, 0, 4, 4, 4, 0, 0, 8, 8, 16, 16, 0, 8, 16};                  // pairs per lane per loop body
+                                      "pair SYMMETRIC, 4 bodies i per lane, j and b_j in wave-private LDS", "pair SYMMETRIC, 8 bodies i per lane, j and b_j in wave-private LDS",
+                                      "ds_swizzle_b32 rotate x16", "pair SYMMETRIC, 8 bodies i per lane, 6 regs moved by ds_swizzle_b32 rotate"};
+static const int mix_insts[MIXES] = {16, 16, 16, 12 * 4, 13 * 2, 16, 16, 12 * 2, 8, 10 * 2, 16, 16, 8, 4, 17, 18, 17, 10 * 2 + 4, 10 * 2 + 4, 17, 16, 16, 16 * 2 + 9, 16 * 2, 16 * 4 + 9, 16 * 4 + 9, 16, 16 * 2 + 9, 16 * 4 + 9, 16, 16 * 4 + 6};      // wave-instructions per loop body
+static const double mix_pairs[MIXES] = {0, 0, 0, 4, 4, 0, 0, 4, 0, 4, 0, 0, 0, 0, 0, 0, 0, 4, 4, 4, 0, 0, 8, 8, 16, 16, 0, 8, 16, 0, 16};                  // pairs per lane per loop body
 
 template <int MIX>
 __global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, unsigned long long *rt, int iters, float seed)
@@ -293,6 +294,35 @@ __global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, u
             acc.x -= bx.x + bx.y; acc.y -= by.x + by.y; acc.z -= bz.x + bz.y;
             bacc4[wv][jslot] = acc;
             jslot = (jslot + 1) & 63;
+        } else if (MIX == SWIZZLE) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) a[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, a[i]), 0xC000 | (1 << 5)));
+        } else if (MIX == PAIR_SYM8_SWZ) {
+            // what mapn_sym.hip does per step, with the six travelling registers moved by ds_swizzle_b32 (rotate within
+            // 32 lanes: one source register, no address) instead of ds_bpermute_b32
+            const float2v sft = float2v{soft2, soft2};
+#define SW(v) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0xC000 | (1 << 5)))
+            const float nx = SW(a[0]), ny = SW(a[1]), nz = SW(a[2]);
+            float2v rx = p[12], ry = p[13], rz = p[14];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float2v dx = a[0] - q[3 * k], dy = a[1] - q[3 * k + 1], dz = a[2] - q[3 * k + 2];
+                float2v d = __builtin_elementwise_fma(dx, dx, sft);
+                d = __builtin_elementwise_fma(dy, dy, d);
+                d = __builtin_elementwise_fma(dz, dz, d);
+                float2v inv;
+                inv.x = __builtin_amdgcn_rsqf(d.x); inv.y = __builtin_amdgcn_rsqf(d.y);
+                const float2v i3 = inv * inv * inv;
+                r[3 * k] = __builtin_elementwise_fma(dx, i3, r[3 * k]);
+                r[3 * k + 1] = __builtin_elementwise_fma(dy, i3, r[3 * k + 1]);
+                r[3 * k + 2] = __builtin_elementwise_fma(dz, i3, r[3 * k + 2]);
+                rx = __builtin_elementwise_fma(-dx, i3, rx);
+                ry = __builtin_elementwise_fma(-dy, i3, ry);
+                rz = __builtin_elementwise_fma(-dz, i3, rz);
+            }
+            a[0] = nx; a[1] = ny; a[2] = nz;
+            p[12].x = SW(rx.x + rx.y); p[13].x = SW(ry.x + ry.y); p[14].x = SW(rz.x + rz.y);
+#undef SW
         } else if (MIX == MFMA4) {
 #pragma unroll
             for (int i = 0; i < 8; i++) macc[i & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[i], a[15], macc[i & 3], 0, 0, 0);
@@ -362,11 +392,11 @@ int main(int argc, char **argv)
     int iters = argc > 1 ? atoi(argv[1]) : 20000;
     hipDeviceProp_t pr; CHECK(hipGetDeviceProperties(&pr, 0));
     printf("device: %s  arch=%s  CUs=%d  clock=%d kHz  wave=%d\n", pr.name, pr.gcnArchName, pr.multiProcessorCount, pr.clockRate, pr.warpSize);
-    if (getenv("UBENCH_SYM_ONLY")) { sweep<PAIR_PK>(iters); sweep<DPP_WAVE_ROR>(iters); sweep<DPP_ROW_ROR>(iters); sweep<PAIR_SYM>(iters); sweep<PAIR_SYM_NOROT>(iters); sweep<PAIR_SYM8_BPERM>(iters); sweep<PAIR_SYM4_LDS>(iters); sweep<PAIR_SYM8_LDS>(iters); return 0; }
+    if (getenv("UBENCH_SYM_ONLY")) { sweep<PAIR_PK>(iters); sweep<DPP_WAVE_ROR>(iters); sweep<DPP_ROW_ROR>(iters); sweep<PAIR_SYM>(iters); sweep<PAIR_SYM_NOROT>(iters); sweep<PAIR_SYM8_BPERM>(iters); sweep<SWIZZLE>(iters); sweep<PAIR_SYM8_SWZ>(iters); return 0; }
     sweep<FMA>(iters); sweep<FMA_SGPR>(iters); sweep<PKFMA>(iters); sweep<PKFMA_BCAST>(iters); sweep<RSQ>(iters);
     sweep<PAIR_SCALAR>(iters); sweep<PAIR_PK>(iters); sweep<PAIR_PK8>(iters); sweep<PAIR_MFMA>(iters); sweep<MFMA4>(iters); sweep<RSQ_PK_ALT>(iters); sweep<RSQ_PK_SEQ>(iters);
     sweep<MFMA16>(iters); sweep<MFMA32>(iters); sweep<PK16_MFMA16_1>(iters); sweep<PK16_MFMA16_2>(iters); sweep<PK16_MFMA32_1>(iters);
     sweep<PAIR_ACC_MFMA16>(iters); sweep<PAIR_ACC_MFMA32>(iters); sweep<PAIR_R2_MFMA16>(iters);
-    sweep<DPP_WAVE_ROR>(iters); sweep<DPP_ROW_ROR>(iters); sweep<PAIR_SYM>(iters); sweep<PAIR_SYM_NOROT>(iters); sweep<BPERM>(iters); sweep<PAIR_SYM8_BPERM>(iters); sweep<PAIR_SYM8_DPP>(iters); sweep<PAIR_SYM4_LDS>(iters); sweep<PAIR_SYM8_LDS>(iters);
+    sweep<DPP_WAVE_ROR>(iters); sweep<DPP_ROW_ROR>(iters); sweep<PAIR_SYM>(iters); sweep<PAIR_SYM_NOROT>(iters); sweep<BPERM>(iters); sweep<PAIR_SYM8_BPERM>(iters); sweep<PAIR_SYM8_DPP>(iters); sweep<PAIR_SYM4_LDS>(iters); sweep<PAIR_SYM8_LDS>(iters); sweep<SWIZZLE>(iters); sweep<PAIR_SYM8_SWZ>(iters);
     return 0;
 }

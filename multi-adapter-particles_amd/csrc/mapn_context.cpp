@@ -272,7 +272,7 @@ mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_tota
 }
 
 // The symmetric kernel (mapn_sym.hip) covers the whole-N, unsharded, all-bodies-active step with N a
-// multiple of 512; anything else runs the one-sided kernels.  Its scratch grows with N^2 / 64 bytes
+// multiple of 1024; anything else runs the one-sided kernels.  Its scratch grows with N^2 / 64 bytes
 // (one 1 KiB row per meeting of a 64-body block with a 512-body block), capped by MAPN_SYM_MAX_MB.
 bool sym_eligible(const mapn_ctx *c, uint32_t active)
 {
@@ -283,8 +283,8 @@ bool sym_eligible(const mapn_ctx *c, uint32_t active)
     if (off && off[0] == '1' && c->cfg.kernel == MAPN_KERNEL_AUTO) return false;
     if (c->cfg.world_size != 1 || c->cfg.force_mode != MAPN_FORCE_ALL_PAIRS) return false;
     if (c->comm || c->external_gather || c->p2p_ready) return false;   // a context wired for an exchange runs the sharded step
-    if (active != c->n || (c->n % 512u) != 0u) return false;
-    const uint64_t nb = c->n / 512u, brows = std::max<uint64_t>(1, (nb - 1) / 2 + ((nb & 1u) ? 0 : 1));
+    if (active != c->n || (c->n % mapn::SYM_BLOCK) != 0u) return false;
+    const uint64_t nb = c->n / mapn::SYM_BLOCK, brows = std::max<uint64_t>(1, (nb - 1) / 2 + ((nb & 1u) ? 0 : 1));
     const char *e = getenv("MAPN_SYM_MAX_MB");
     const uint64_t cap = (e ? strtoull(e, nullptr, 10) : 4096ull) << 20;
     return (uint64_t)c->n * brows * 16ull <= cap;
@@ -294,25 +294,24 @@ int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
 {
     mapn::SymArgs a{};
     a.pos_old = base.pos_old; a.vel_old = base.vel_old; a.pos_new = base.pos_new; a.vel_new = base.vel_new;
-    a.n = c->n; a.nb = c->n / 512u;
+    a.n = c->n; a.nb = c->n / mapn::SYM_BLOCK;
     a.half_d = (a.nb & 1u) ? 0u : a.nb / 2u;
     a.brows = std::max(1u, (a.nb - 1u) / 2u + (a.half_d ? 1u : 0u));
     a.mass = base.mass; a.soft2 = base.soft2; a.dt = base.dt; a.damping = base.damping;
-    // one resident round: 4 waves per SIMD (114 VGPRs), every wave the same number of meetings +- 1
-    uint32_t waves = 8, parts = 0;
+    uint32_t waves = 4, parts = 0;
     const char *e = getenv("MAPN_SYM_PLAN");               // "waves,parts" tuning override
     unsigned ew = 0, ep = 0;
     if (e && sscanf(e, "%u,%u", &ew, &ep) == 2 && (ew == 4 || ew == 8) && ep >= 1) { waves = ew; parts = ep; }
     if (!parts) {
-        // 4 waves per SIMD are resident (118 VGPRs); about four rounds of workgroups balance the tail
-        // (65 536 bodies: parts 4 / 8 / 16 / 32 / 64 -> 0.691 / 0.672 / 0.647 / 0.655 / 0.691 ms)
-        const uint32_t slots = (uint32_t)c->cus * 4u * 4u;
-        const uint32_t meetings = 8u * (1u + (a.nb - 1u) / 2u) + (a.half_d ? 8u : 0u);
+        // 2 waves per SIMD are resident (246 VGPRs); about four rounds of 4-wave workgroups balance the tail
+        // (65 536 bodies, parts 24 / 32 / 48 / 64 -> 0.663 / 0.647 / 0.669 / 0.675 ms; 8-wave workgroups 0.68-0.72)
+        const uint32_t slots = (uint32_t)c->cus * 4u * 2u;
+        const uint32_t meetings = mapn::SYM_JPI * (1u + (a.nb - 1u) / 2u) + (a.half_d ? mapn::SYM_JPI : 0u);
         parts = (uint32_t)std::max<uint64_t>(1, (4ull * slots + (uint64_t)a.nb * waves / 2) / ((uint64_t)a.nb * waves));
         parts = std::min(parts, std::max(1u, meetings / waves));
     }
     a.parts = parts;
-    const size_t ab = (size_t)a.nb * parts * 512u * sizeof(float4), bb = (size_t)(c->n / 64u) * a.brows * 64u * sizeof(float4);
+    const size_t ab = (size_t)a.nb * parts * mapn::SYM_BLOCK * sizeof(float4), bb = (size_t)(c->n / 64u) * a.brows * 64u * sizeof(float4);
     if (ab > c->sym_arow_bytes) {
         if (c->sym_arow) HIP_TRY(hipFree(c->sym_arow));
         c->sym_arow = nullptr; c->sym_arow_bytes = 0;
@@ -341,7 +340,7 @@ int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
     HIP_TRY(mapn::launch_sym_reduce(a, c->compute));
     mapn::ForcePlan p{};
-    p.kind = mapn::KERNEL_SYM; p.k = 8; p.waves = waves; p.sb = parts; p.nseg = 1; p.epi = mapn::EPI_ROWS;
+    p.kind = mapn::KERNEL_SYM; p.k = 2 * mapn::SYM_K2; p.waves = waves; p.sb = parts; p.nseg = 1; p.epi = mapn::EPI_ROWS;
     c->last_plan = p; c->last_i_count = c->n; c->last_launches = 2;
     c->sym_parts = parts; c->sym_waves = waves;
     return MAPN_OK;
@@ -1500,7 +1499,7 @@ int mapn_measure_clock(mapn_ctx *c, int steps, mapn_clock_info *out)
     if (!c->stamp_buf || (c->last_plan.kind != mapn::KERNEL_SGPR && c->last_plan.kind != mapn::KERNEL_SYM))
         return fail(MAPN_ERR_STATE, "measure_clock: the stamped diagnostic exists for the scalar-cache and the symmetric force kernels only");
     const size_t waves = c->last_plan.kind == mapn::KERNEL_SYM
-        ? (size_t)(c->n / 512u) * c->sym_parts * c->sym_waves
+        ? (size_t)(c->n / mapn::SYM_BLOCK) * c->sym_parts * c->sym_waves
         : (size_t)((c->last_i_count + 64 * c->last_plan.k - 1) / (64 * c->last_plan.k)) * c->last_plan.sb * c->last_plan.waves;
     std::vector<unsigned long long> h(2 * waves);
     HIP_TRY(hipMemcpy(h.data(), c->stamp_buf, waves * 16, hipMemcpyDeviceToHost));
@@ -1554,7 +1553,7 @@ int mapn_get_kernel_stats(mapn_ctx *c, int reset, mapn_kernel_stats *out)
     out->force_launches_per_step = c->last_launches ? c->last_launches : 1u;
     if (p.kind == mapn::KERNEL_SYM) {
         out->force_launches_per_step = 1;                  // + sym_reduce_integrate_kernel (fused = 0)                      // grid (parts, I-blocks); one wave = 8 bodies per lane
-        out->grid_x = p.sb; out->grid_y = i_count / 512u; out->j_splits = p.sb * p.waves; out->fused = 0; out->epilogue = 3;
+        out->grid_x = p.sb; out->grid_y = i_count / mapn::SYM_BLOCK; out->j_splits = p.sb * p.waves; out->fused = 0; out->epilogue = 3;
     }
     if (reset) { c->force_launches = 0; c->force_seconds_sum = 0.0; }
     return MAPN_OK;

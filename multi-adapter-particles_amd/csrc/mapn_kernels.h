@@ -55,7 +55,10 @@ struct ForcePlan {
     int      epi;      // EPI_*: EPI_FUSED requires sb == 1 and nseg == 1
 };
 
-// The symmetric (Newton's third law) all-pairs step, mapn_sym.hip: whole-N, unsharded, N % 512 == 0.
+// The symmetric (Newton's third law) all-pairs step, mapn_sym.hip: whole-N, unsharded, N % SYM_BLOCK == 0.
+enum { SYM_K2 = 8,                     // packed pairs of bodies i per lane
+       SYM_BLOCK = 128 * SYM_K2,       // bodies per I-block (one wave)
+       SYM_JPI = SYM_BLOCK / 64 };     // 64-body J-blocks per I-block
 struct SymArgs {
     const float4 *pos_old;
     const float  *vel_old;

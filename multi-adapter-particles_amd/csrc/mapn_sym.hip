@@ -7,19 +7,21 @@
 // Why it is not free: the reaction -s r belongs to body j, and in the one-sided kernels every lane
 // of a wave works on the SAME j (broadcast from the scalar cache), so collecting it would need a
 // 64-lane reduction per j.  Here the roles are arranged systolically instead:
-//   * a lane owns 8 bodies i (four packed pairs: positions + accumulators in registers) -- an
-//     I-block of 512 bodies per wave;
+//   * a lane owns 16 bodies i (eight packed pairs: positions + accumulators in registers, 246 VGPRs,
+//     two waves per SIMD) -- an I-block of 1024 bodies per wave;
 //   * a J-block is 64 bodies, ONE per lane, travelling with its reaction accumulator; after each step
-//     (4 packed evaluations = 16 interactions per lane) the travelling body and its reaction move one
+//     (8 packed evaluations = 32 interactions per lane) the travelling body and its reaction move one
 //     lane on (6 ds_bpermute_b32: through the LDS crossbar), so after 64 steps every lane has met
 //     every body of the J-block and each body is back home with its complete reaction.
-// Measured (tools/ubench.hip, profiles/r02_ubench_sym.txt): 7.4e12 interactions/s for this loop
-// against 4.9e12 for the one-sided pair term; DPP rotation (v_mov_b32_dpp wave_ror:1, ~10 cycles
-// each) 6.5e12; LDS float atomics for the reaction (ds_add_f32, ~195 cycles per wave-instruction)
-// 1.1e12; with 4 bodies i per lane the rotation eats the gain (5.3e12).
+// Measured (tools/ubench.hip, profiles/r02_ubench.txt): a cross-lane move costs ~12 SIMD cycles per
+// register whatever the mechanism (ds_bpermute_b32, ds_swizzle_b32, v_mov_b32_dpp), so the loop gets
+// faster the more bodies i a lane owns per move: 4 bodies 5.3e12 interactions/s, 8 bodies 7.4e12 in
+// the microbenchmark (one-sided pair term: 4.9e12); in the kernel 8 -> 16 bodies per lane gained
+// another 3-5 % although only two waves per SIMD remain.  LDS float atomics for the reaction
+// (ds_add_f32, ~195 cycles per wave-instruction): 1.1e12.
 //
-// Coverage of the N^2 ordered pairs (N a multiple of 512): I-block a meets, symmetrically, the
-// I-blocks a+1 .. a+D (mod NB, D = (NB-1)/2, NB = N/512) 64 bodies at a time, for even NB also
+// Coverage of the N^2 ordered pairs (N a multiple of 1024): I-block a meets, symmetrically, the
+// I-blocks a+1 .. a+D (mod NB, D = (NB-1)/2, NB = N/1024) 64 bodies at a time, for even NB also
 // a+NB/2 when a < NB/2; and itself one-sidedly (no reaction kept).  Every unordered pair of
 // blocks is met exactly once; every body collects its force as: rows of its own I-block (role i)
 // + one row per meeting of its J-block (role j), all written to scratch and summed in a FIXED
@@ -35,8 +37,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int SYM_K2 = 4;                 // packed pairs of bodies i per lane
-constexpr uint32_t SYM_IB = 128u * SYM_K2; // bodies per I-block (512)
+constexpr uint32_t SYM_IB = SYM_BLOCK;     // bodies per I-block (1024)
+constexpr uint32_t JPI = SYM_JPI;          // J-blocks per I-block (16)
 
 __device__ __forceinline__ float lane_next(float v, int addr)
 {
@@ -104,22 +106,22 @@ __device__ __forceinline__ void one_step(SymBodies &b, float xj, float yj, float
 
 // grid = (S, NB)   block = 64 * WAVES
 // Workgroup (s, a): I-block a, part s of S of its meetings.  The meetings of an I-block are numbered
-// m = 0 .. M-1: m < 8 -> itself, J-block a*8 + m, one-sided; then 8 per partner block a + d.
+// m = 0 .. M-1: m < 16 -> itself, J-block a*16 + m, one-sided; then 16 per partner block a + d.
 // The workgroup's part [m0, m1) is dealt to its waves contiguously.  Every wave keeps the I-block's
 // accumulators in registers for all of its meetings; at the end the WAVES copies are combined in LDS
-// in ascending wave order into ONE row arow[a][s][512]; each symmetric meeting writes ONE row
+// in ascending wave order into ONE row arow[a][s][1024]; each symmetric meeting writes ONE row
 // brow[jblock][d-1][64] with the reactions of the J-block's bodies.
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 4) void force_sym_kernel(const SymArgs p)
+__global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs p)
 {
-    __shared__ float comb[WAVES][3][SYM_IB];               // 48 KiB at 8 waves: two workgroups per CU fit
+    __shared__ float comb[WAVES][3][SYM_IB];               // 48 KiB at 4 waves: the two workgroups a CU holds fit
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t s = blockIdx.x, a = blockIdx.y;
     const uint32_t nb = p.nb, half = p.half_d;             // half_d = NB/2 when NB is even, else 0
     const uint32_t D = (nb - 1u) / 2u;
-    const uint32_t M = 8u * (1u + D) + ((half && a < half) ? 8u : 0u);
+    const uint32_t M = JPI * (1u + D) + ((half && a < half) ? JPI : 0u);
     // part s of S, then wave w of WAVES, both by the same even split (the first `rem` take one more)
     const uint32_t pm0 = (uint32_t)(((uint64_t)M * s) / p.parts), pm1 = (uint32_t)(((uint64_t)M * (s + 1u)) / p.parts);
     const uint32_t cnt = pm1 - pm0;
@@ -139,11 +141,11 @@ __global__ __launch_bounds__(64 * WAVES, 4) void force_sym_kernel(const SymArgs 
     // J-block of meeting m (and whether it is symmetric); the NEXT meeting's bodies are fetched while
     // the current one is computed (a meeting is ~9 us of a wave's life, a global load ~1-2 us)
     auto meeting = [&](uint32_t m, uint32_t &jb, uint32_t &d) {
-        const uint32_t grp = m >> 3, t = m & 7u;           // grp 0: own block; grp g: partner a + g (the last may be the half ring)
+        const uint32_t grp = m / JPI, t = m % JPI;         // grp 0: own block; grp g: partner a + g (the last may be the half ring)
         d = grp <= D ? grp : half;
         uint32_t ap = a + d;
         ap = ap >= nb ? ap - nb : ap;
-        jb = ap * 8u + t;
+        jb = ap * JPI + t;
     };
     // diagnostic launches only (mapn_measure_clock): stamps around the wave's meetings; null otherwise
     unsigned long long st_c = 0, st_r = 0;

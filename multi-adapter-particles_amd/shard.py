@@ -69,7 +69,7 @@ class ShardPlan:
 
 def sym_meetings(nb: int):
     """Meetings of the symmetric kernel: yields (a, partner block, d, symmetric) for every I-block
-    a of `nb`, 8 J-blocks each (not expanded here).  d = 0: the block against itself, one-sided;
+    a of `nb`, 16 J-blocks of 64 bodies each (not expanded here).  d = 0: the block against itself, one-sided;
     1 <= d <= D = (nb-1)//2: partner a+d, symmetric; for even nb also d = nb/2 when a < nb/2."""
     D = (nb - 1) // 2
     half = nb // 2 if nb % 2 == 0 else 0

@@ -23,9 +23,9 @@ def errs(a, b, scale):
     return d.max(), np.median(d)
 
 
-@pytest.mark.parametrize("n", [512, 1024, 1536, 2048, 2560, 4096, 8192])
+@pytest.mark.parametrize("n", [1024, 2048, 3072, 4096, 5120, 8192, 16384])
 def test_symmetric_one_step_against_the_oracle(oracle, n):
-    """Odd and even numbers of 512-body blocks (the half-ring partner exists only for even counts),
+    """Odd and even numbers of 1024-body blocks (the half-ring partner exists only for even counts),
     one block only (nothing symmetric to do), teacher-forced."""
     mass = 70000.0 / n
     pos, vel = oracle.initial_state(n, seed=2)
@@ -82,7 +82,7 @@ def test_symmetric_free_run_matches_golden_and_the_one_sided_kernel(oracle, gold
 
 
 def test_symmetric_context_falls_back_where_the_kernel_does_not_apply(oracle):
-    """num_active < N, or N not a multiple of 512: the step runs the scalar-cache kernel (same results
+    """num_active < N, or N not a multiple of 1024: the step runs the scalar-cache kernel (same results
     contract); with all bodies active again the symmetric kernel is back."""
     n = 4096
     pos, vel = oracle.initial_state(n, seed=4)

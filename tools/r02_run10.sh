@@ -24,7 +24,7 @@ cp profiles/r02_sym_pmc_summary.* profiles/r02_onesided_pmc_summary.* $O/
 for n in 262144 1048576; do
   for k in sym sgpr; do MAPN_SYM_MAX_MB=20000 python bench.py --kernel $k --bodies $n --steps $((n==262144?40:6)) --warmup 2 --no-cpu-baseline > $O/bench_${n}_$k.json 2>/dev/null; done
 done
-for p in 8,2 8,4 8,8 8,16; do MAPN_SYM_PLAN=$p python bench.py --kernel sym --bodies 262144 --steps 40 --warmup 2 --no-cpu-baseline > $O/bench_262144_sym_plan_${p//,/_}.json 2>/dev/null; done
+for p in 4,4 4,8 4,16 4,32; do MAPN_SYM_PLAN=$p python bench.py --kernel sym --bodies 262144 --steps 40 --warmup 2 --no-cpu-baseline > $O/bench_262144_sym_plan_${p//,/_}.json 2>/dev/null; done
 for f in $O/bench_*.json; do python - "$f" <<'PY'
 import json,sys,os
 try:
@@ -35,3 +35,5 @@ PY
 done
 for k in sym sgpr; do find $O/stats_$k -name "*kernel_stats.csv" | head -1 | xargs head -4; done
 tail -30 $O/pmc_summary_sym.txt
+python -m pytest tests/test_parity_1000.py -m gpu -q -s > $O/pytest_parity1000.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_parity1000.txt
+grep -E "passed|failed|vs ref @1000|@1000 vs acc64|# oracle" $O/pytest_parity1000.txt | cut -c1-300

@@ -303,12 +303,12 @@ int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     unsigned ew = 0, ep = 0;
     if (e && sscanf(e, "%u,%u", &ew, &ep) == 2 && (ew == 4 || ew == 8) && ep >= 1) { waves = ew; parts = ep; }
     if (!parts) {
-        // 2 waves per SIMD are resident (246 VGPRs); about four rounds of 4-wave workgroups balance the tail
-        // (65 536 bodies, parts 24 / 32 / 48 / 64 -> 0.663 / 0.647 / 0.669 / 0.675 ms; 8-wave workgroups 0.68-0.72)
-        const uint32_t slots = (uint32_t)c->cus * 4u * 2u;
+        // 2 waves per SIMD are resident (246 VGPRs).  32 four-wave workgroups per I-block measured best or
+        // within 0.5 % of best at every size (65 536 bodies: parts 24 / 32 / 48 / 64 -> 0.663 / 0.647 / 0.669 /
+        // 0.675 ms; 262 144: 8 / 32 / 64 / 128 -> 9.95 / 9.60 / 9.60 / 9.89 ms; 1 048 576: 2 / 8 / 32 / 64 ->
+        // 154.3 / 153.2 / 152.9 / 153.0 ms; 8-wave workgroups 0.68-0.72 ms at 65 536)
         const uint32_t meetings = mapn::SYM_JPI * (1u + (a.nb - 1u) / 2u) + (a.half_d ? mapn::SYM_JPI : 0u);
-        parts = (uint32_t)std::max<uint64_t>(1, (4ull * slots + (uint64_t)a.nb * waves / 2) / ((uint64_t)a.nb * waves));
-        parts = std::min(parts, std::max(1u, meetings / waves));
+        parts = std::min(32u, std::max(1u, meetings / waves));
     }
     a.parts = parts;
     const size_t ab = (size_t)a.nb * parts * mapn::SYM_BLOCK * sizeof(float4), bb = (size_t)(c->n / 64u) * a.brows * 64u * sizeof(float4);

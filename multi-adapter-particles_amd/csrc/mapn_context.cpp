@@ -271,8 +271,8 @@ mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_tota
     return p;
 }
 
-// The symmetric kernel (mapn_sym.hip) covers the whole-N, unsharded, all-bodies-active step with N a
-// multiple of 1024; anything else runs the one-sided kernels.  Its scratch grows with N^2 / 64 bytes
+// The symmetric kernel (mapn_sym.hip) covers the whole-N, unsharded, all-bodies-active step with N >= 1024
+// (padded to a multiple of 1024 inside the kernel); anything else runs the one-sided kernels.  Its scratch grows with N^2 / 64 bytes
 // (one 1 KiB row per meeting of a 64-body block with a 512-body block), capped by MAPN_SYM_MAX_MB.
 bool sym_eligible(const mapn_ctx *c, uint32_t active)
 {
@@ -283,18 +283,18 @@ bool sym_eligible(const mapn_ctx *c, uint32_t active)
     if (off && off[0] == '1' && c->cfg.kernel == MAPN_KERNEL_AUTO) return false;
     if (c->cfg.world_size != 1 || c->cfg.force_mode != MAPN_FORCE_ALL_PAIRS) return false;
     if (c->comm || c->external_gather || c->p2p_ready) return false;   // a context wired for an exchange runs the sharded step
-    if (active != c->n || (c->n % mapn::SYM_BLOCK) != 0u) return false;
-    const uint64_t nb = c->n / mapn::SYM_BLOCK, brows = std::max<uint64_t>(1, (nb - 1) / 2 + ((nb & 1u) ? 0 : 1));
+    if (active != c->n || c->n < mapn::SYM_BLOCK) return false;       // (a smaller job does not fill one block: one-sided)
+    const uint64_t nb = (c->n + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK, brows = std::max<uint64_t>(1, (nb - 1) / 2 + ((nb & 1u) ? 0 : 1));
     const char *e = getenv("MAPN_SYM_MAX_MB");
     const uint64_t cap = (e ? strtoull(e, nullptr, 10) : 4096ull) << 20;
-    return (uint64_t)c->n * brows * 16ull <= cap;
+    return nb * mapn::SYM_BLOCK * brows * 16ull <= cap;
 }
 
 int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
 {
     mapn::SymArgs a{};
     a.pos_old = base.pos_old; a.vel_old = base.vel_old; a.pos_new = base.pos_new; a.vel_new = base.vel_new;
-    a.n = c->n; a.nb = c->n / mapn::SYM_BLOCK;
+    a.n = c->n; a.nb = (c->n + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK;     // the last block may be partly stand-in bodies
     a.half_d = (a.nb & 1u) ? 0u : a.nb / 2u;
     a.brows = std::max(1u, (a.nb - 1u) / 2u + (a.half_d ? 1u : 0u));
     a.mass = base.mass; a.soft2 = base.soft2; a.dt = base.dt; a.damping = base.damping;
@@ -311,7 +311,7 @@ int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
         parts = std::min(32u, std::max(1u, meetings / waves));
     }
     a.parts = parts;
-    const size_t ab = (size_t)a.nb * parts * mapn::SYM_BLOCK * sizeof(float4), bb = (size_t)(c->n / 64u) * a.brows * 64u * sizeof(float4);
+    const size_t ab = (size_t)a.nb * parts * mapn::SYM_BLOCK * sizeof(float4), bb = (size_t)a.nb * mapn::SYM_BLOCK * a.brows * sizeof(float4);
     if (ab > c->sym_arow_bytes) {
         if (c->sym_arow) HIP_TRY(hipFree(c->sym_arow));
         c->sym_arow = nullptr; c->sym_arow_bytes = 0;
@@ -1499,7 +1499,7 @@ int mapn_measure_clock(mapn_ctx *c, int steps, mapn_clock_info *out)
     if (!c->stamp_buf || (c->last_plan.kind != mapn::KERNEL_SGPR && c->last_plan.kind != mapn::KERNEL_SYM))
         return fail(MAPN_ERR_STATE, "measure_clock: the stamped diagnostic exists for the scalar-cache and the symmetric force kernels only");
     const size_t waves = c->last_plan.kind == mapn::KERNEL_SYM
-        ? (size_t)(c->n / mapn::SYM_BLOCK) * c->sym_parts * c->sym_waves
+        ? (size_t)((c->n + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK) * c->sym_parts * c->sym_waves
         : (size_t)((c->last_i_count + 64 * c->last_plan.k - 1) / (64 * c->last_plan.k)) * c->last_plan.sb * c->last_plan.waves;
     std::vector<unsigned long long> h(2 * waves);
     HIP_TRY(hipMemcpy(h.data(), c->stamp_buf, waves * 16, hipMemcpyDeviceToHost));
@@ -1553,7 +1553,7 @@ int mapn_get_kernel_stats(mapn_ctx *c, int reset, mapn_kernel_stats *out)
     out->force_launches_per_step = c->last_launches ? c->last_launches : 1u;
     if (p.kind == mapn::KERNEL_SYM) {
         out->force_launches_per_step = 1;                  // + sym_reduce_integrate_kernel (fused = 0)                      // grid (parts, I-blocks); one wave = 8 bodies per lane
-        out->grid_x = p.sb; out->grid_y = i_count / mapn::SYM_BLOCK; out->j_splits = p.sb * p.waves; out->fused = 0; out->epilogue = 3;
+        out->grid_x = p.sb; out->grid_y = (i_count + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK; out->j_splits = p.sb * p.waves; out->fused = 0; out->epilogue = 3;
     }
     if (reset) { c->force_launches = 0; c->force_seconds_sum = 0.0; }
     return MAPN_OK;

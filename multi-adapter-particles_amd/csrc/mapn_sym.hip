@@ -20,7 +20,8 @@
 // another 3-5 % although only two waves per SIMD remain.  LDS float atomics for the reaction
 // (ds_add_f32, ~195 cycles per wave-instruction): 1.1e12.
 //
-// Coverage of the N^2 ordered pairs (N a multiple of 1024): I-block a meets, symmetrically, the
+// Coverage of the N^2 ordered pairs (N padded to a multiple of 1024 with stand-in bodies that exert no
+// force): I-block a meets, symmetrically, the
 // I-blocks a+1 .. a+D (mod NB, D = (NB-1)/2, NB = N/1024) 64 bodies at a time, for even NB also
 // a+NB/2 when a < NB/2; and itself one-sidedly (no reaction kept).  Every unordered pair of
 // blocks is met exactly once; every body collects its force as: rows of its own I-block (role i)
@@ -128,10 +129,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     const uint32_t m0 = pm0 + (uint32_t)(((uint64_t)cnt * w) / WAVES), m1 = pm0 + (uint32_t)(((uint64_t)cnt * (w + 1u)) / WAVES);
 
     const float4 *__restrict__ pos = p.pos_old;
+    // N need not be a multiple of the block: bodies past the end are stand-ins so far away that
+    // (|r|^2 + soft^2)^(-3/2) underflows to zero -- they exert and feel exactly nothing, and what the
+    // kernel accumulates for them is never read (sym_reduce_integrate_kernel stops at n)
+    const float4 far = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);
+    auto body = [&](uint32_t i) { return i < p.n ? pos[i] : far; };
     SymBodies b;
 #pragma unroll
     for (int k = 0; k < SYM_K2; k++) {
-        const float4 b0 = pos[a * SYM_IB + (2 * k) * 64u + lane], b1 = pos[a * SYM_IB + (2 * k + 1) * 64u + lane];
+        const float4 b0 = body(a * SYM_IB + (2 * k) * 64u + lane), b1 = body(a * SYM_IB + (2 * k + 1) * 64u + lane);
         b.xi[k] = v2f{b0.x, b1.x}; b.yi[k] = v2f{b0.y, b1.y}; b.zi[k] = v2f{b0.z, b1.z};
         b.ax[k] = v2f{0.f, 0.f}; b.ay[k] = v2f{0.f, 0.f}; b.az[k] = v2f{0.f, 0.f};
     }
@@ -152,11 +158,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     if (p.stamps) asm volatile("s_memrealtime %0\n s_memtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(st_r), "=s"(st_c));
     uint32_t jb = 0, d = 0;
     float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m0 < m1) { meeting(m0, jb, d); pn = pos[jb * 64u + lane]; }
+    if (m0 < m1) { meeting(m0, jb, d); pn = body(jb * 64u + lane); }
     for (uint32_t m = m0; m < m1; m++) {
         const uint32_t jb_cur = jb, d_cur = d;
         float xj = pn.x, yj = pn.y, zj = pn.z;
-        if (m + 1u < m1) { meeting(m + 1u, jb, d); pn = pos[jb * 64u + lane]; }
+        if (m + 1u < m1) { meeting(m + 1u, jb, d); pn = body(jb * 64u + lane); }
         // (Alternatives to moving the position, measured on one box each: a wave-private LDS copy of the J-block
         //  read with one ds_read_b128 per step, also one step ahead: 2-3 % slower; re-reading body (lane + k) % 64
         //  from global memory every step, fetched one step ahead: 9 % slower.)

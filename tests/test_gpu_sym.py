@@ -23,18 +23,23 @@ def errs(a, b, scale):
     return d.max(), np.median(d)
 
 
-@pytest.mark.parametrize("n", [1024, 2048, 3072, 4096, 5120, 8192, 16384])
+@pytest.mark.parametrize("n", [1024, 1025, 2048, 3000, 3072, 4096, 5000, 5120, 8192, 16384, 65536 + 100])
 def test_symmetric_one_step_against_the_oracle(oracle, n):
     """Odd and even numbers of 1024-body blocks (the half-ring partner exists only for even counts),
-    one block only (nothing symmetric to do), teacher-forced."""
+    one block only (nothing symmetric to do), ragged N (the last block is padded with stand-in bodies that
+    exert no force), teacher-forced."""
     mass = 70000.0 / n
     pos, vel = oracle.initial_state(n, seed=2)
+    if n % 2:
+        pos[n - 1, :3] = [10.0, -20.0, 30.0]; vel[n - 1] = [1.0, 2.0, 3.0]     # the generator leaves the odd body at the origin
     sim = OracleSim(oracle, pos, vel, params=Params(mass=mass)); sim.simulate()
-    with mapn.Compute(n, mass=mass, seed=2, kernel=mapn.KERNEL_SYMMETRIC) as c:
+    with mapn.Compute(n, mass=mass, seed=2, kernel=mapn.KERNEL_SYMMETRIC, flags=mapn.FLAG_NO_INIT) as c:
+        c.upload_state(pos, vel)
         draw(c, 1)
         p, v = c.download_state()
         st = c.kernel_stats()
         assert st.kernel_name.decode() == "force_sym_kernel" and st.epilogue == 3
+        assert np.isfinite(p).all() and np.isfinite(v).all()
     rp, rv = sim.latest
     assert errs(p[:, :3], rp[:, :3], SPREAD)[0] < 1e-6
     assert errs(v, rv, SPEED)[0] < 2e-5
@@ -82,7 +87,7 @@ def test_symmetric_free_run_matches_golden_and_the_one_sided_kernel(oracle, gold
 
 
 def test_symmetric_context_falls_back_where_the_kernel_does_not_apply(oracle):
-    """num_active < N, or N not a multiple of 1024: the step runs the scalar-cache kernel (same results
+    """num_active < N, or N smaller than one 1024-body block: the step runs the scalar-cache kernel (same results
     contract); with all bodies active again the symmetric kernel is back."""
     n = 4096
     pos, vel = oracle.initial_state(n, seed=4)
@@ -95,6 +100,6 @@ def test_symmetric_context_falls_back_where_the_kernel_does_not_apply(oracle):
             for b in (0, 1):
                 pb, vb = c.download_buffer(b)
                 assert errs(pb[:, :3], sim.pos[b][:, :3], SPREAD)[0] < 3e-6
-    with mapn.Compute(3000, mass=1.0, kernel=mapn.KERNEL_SYMMETRIC) as c:
+    with mapn.Compute(1000, mass=1.0, kernel=mapn.KERNEL_SYMMETRIC) as c:       # less than one block: one-sided
         draw(c, 1)
         assert c.kernel_stats().kernel_name.decode() == "force_sgpr_kernel"

@@ -55,8 +55,8 @@ typedef enum mapn_kernel {
     MAPN_KERNEL_SCALAR = 2,     /* j-bodies through the scalar cache into SGPRs */
     MAPN_KERNEL_SYMMETRIC = 3   /* Newton's third law: every unordered pair evaluated once, feeding both bodies
                                    (csrc/mapn_sym.hip).  Applies to the unsharded step with all bodies active and
-                                   N >= 1024 (scratch N^2/64 bytes, capped by MAPN_SYM_MAX_MB, default
-                                   4096); any other step of such a context runs the scalar-cache kernel. */
+                                   N >= 1024 (scratch N^2/128 bytes, capped by MAPN_SYM_MAX_MB, default
+                                   16384); any other step of such a context runs the scalar-cache kernel. */
     /* No MFMA variant (BASELINE configs[4] A/B, closed in round 2): on gfx950 the f32 MFMA shapes do NOT
        run beside the packed fp32 VALU stream of the same SIMD -- their times add (16 v_pk_fma_f32 + one
        v_mfma_f32_16x16x4_f32: 105 cycles against 74 + 32) -- so every recast of the pair term is slower

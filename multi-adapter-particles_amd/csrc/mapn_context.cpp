@@ -272,8 +272,8 @@ mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_tota
 }
 
 // The symmetric kernel (mapn_sym.hip) covers the whole-N, unsharded, all-bodies-active step with N >= 1024
-// (padded to a multiple of 1024 inside the kernel); anything else runs the one-sided kernels.  Its scratch grows with N^2 / 64 bytes
-// (one 1 KiB row per meeting of a 64-body block with a 512-body block), capped by MAPN_SYM_MAX_MB.
+// (padded to a multiple of 1024 inside the kernel); anything else runs the one-sided kernels.  Its scratch grows with N^2 / 128
+// bytes (one 1 KiB row per meeting of a 64-body block with a 1024-body block), capped by MAPN_SYM_MAX_MB.
 bool sym_eligible(const mapn_ctx *c, uint32_t active)
 {
     // AUTO picks it wherever it applies (measured 1.33x the scalar-cache kernel at 65 536 bodies, 1.45x at
@@ -286,7 +286,7 @@ bool sym_eligible(const mapn_ctx *c, uint32_t active)
     if (active != c->n || c->n < mapn::SYM_BLOCK) return false;       // (a smaller job does not fill one block: one-sided)
     const uint64_t nb = (c->n + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK, brows = std::max<uint64_t>(1, (nb - 1) / 2 + ((nb & 1u) ? 0 : 1));
     const char *e = getenv("MAPN_SYM_MAX_MB");
-    const uint64_t cap = (e ? strtoull(e, nullptr, 10) : 4096ull) << 20;
+    const uint64_t cap = (e ? strtoull(e, nullptr, 10) : 16384ull) << 20;   // 1 048 576 bodies need 8.6 GB of the 288 GB
     return nb * mapn::SYM_BLOCK * brows * 16ull <= cap;
 }
 

@@ -64,9 +64,9 @@ struct SymArgs {
     const float  *vel_old;
     float4       *pos_new;
     float        *vel_new;
-    float4       *arow;       // [nb][parts][512]  force on the bodies of an I-block, one row per workgroup
+    float4       *arow;       // [nb][parts][SYM_BLOCK]  force on the bodies of an I-block, one row per workgroup
     float4       *brow;       // [n / 64][brows][64] reaction on the bodies of a J-block, one row per meeting
-    uint32_t      n, nb;      // bodies, I-blocks of 512
+    uint32_t      n, nb;      // bodies, I-blocks of SYM_BLOCK (the last may be padded)
     uint32_t      parts;      // workgroups per I-block (gridDim.x)
     uint32_t      brows;      // rows allocated per J-block: (nb - 1) / 2 (+ 1 when nb is even)
     uint32_t      half_d;     // nb / 2 when nb is even (the half-ring partner), else 0

@@ -276,8 +276,8 @@ mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_tota
 // bytes (one 1 KiB row per meeting of a 64-body block with a 1024-body block), capped by MAPN_SYM_MAX_MB.
 bool sym_eligible(const mapn_ctx *c, uint32_t active)
 {
-    // AUTO picks it wherever it applies (measured 1.33x the scalar-cache kernel at 65 536 bodies, 1.45x at
-    // 262 144 and 1 048 576: profiles/r02_sym_*.txt); MAPN_KERNEL_SCALAR / _LDS and a forced plan keep the one-sided kernels
+    // AUTO picks it wherever it applies (measured 1.40x the scalar-cache kernel at 65 536 bodies, 1.44x at
+    // 262 144 and 1 048 576: profiles/r02_sym_vs_onesided.txt); MAPN_KERNEL_SCALAR / _LDS and a forced plan keep the one-sided kernels
     if ((c->cfg.kernel != MAPN_KERNEL_SYMMETRIC && c->cfg.kernel != MAPN_KERNEL_AUTO) || c->plan_forced) return false;
     const char *off = getenv("MAPN_NO_SYM");
     if (off && off[0] == '1' && c->cfg.kernel == MAPN_KERNEL_AUTO) return false;

@@ -77,9 +77,15 @@ def cpu_baseline(n, seed, target_seconds):
     if (k * n / t) * target_seconds >= 2.0 * n * n:    # a whole step fits the budget comfortably
         sim = OracleSim(o, pos, vel, params=prm)
         sim.simulate(steps=1)                          # warm up threads / caches
-        t0 = time.perf_counter(); sim.simulate(steps=2); t2 = (time.perf_counter() - t0) / 2
-        steps = max(1, int(target_seconds / t2))
-        t0 = time.perf_counter(); sim.simulate(steps=steps); t = time.perf_counter() - t0
+        # time-bounded, not count-bounded: a two-step calibration underestimated the steady step time 3x
+        # on the 256-thread box (965 steps, 39.8 s for a 12 s target)
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            sim.simulate(steps=4)
+            steps += 4
+            t = time.perf_counter() - t0
+            if t >= target_seconds:
+                break
         pairs = float(steps) * n * n
         what = f"{steps} whole steps of {n} bodies"
     else:

@@ -725,7 +725,11 @@ int create_common(const mapn_config *cfg, mapn_ctx **out)
     *out = c;
 
     HIP_TRY(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    // the exchange stream outranks the compute stream: its few workgroups (RCCL, the pull kernels) must get a slot as soon
+    // as one frees up, also while a force launch keeps the device full
+    int prio_low = 0, prio_high = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    HIP_TRY(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, prio_high));
     for (int k = 0; k < kTimerRing; k++) {
         HIP_TRY(hipEventCreateWithFlags(&c->fence_events[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreate(&c->timers[k].start));

@@ -22,6 +22,9 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     c = mapn.Compute(n, device=0, mass=70000.0 / n, rank=rank, world_size=world)
     first, count = c.shard_range()
+    if os.environ.get("MAPN_WORKER_PLAN"):          # "kernel,k,waves,sb,fused": keep every rank's launch small enough to be co-resident
+        kn, k, w, sb, fu = os.environ["MAPN_WORKER_PLAN"].split(",")
+        c.set_force_plan({"lds": mapn.KERNEL_LDS, "sgpr": mapn.KERNEL_SCALAR}[kn], int(k), int(w), int(sb), int(fu))
     if mode == "p2p_timeout":
         # rank 0 steps once, the other ranks never do: rank 0's wait for a peer's slice must give up
         # after the configured bound and SURFACE it (MAPN_ERR_COMM naming the peer), not pass silently

@@ -186,8 +186,8 @@ int mapn_consumer_signal(mapn_ctx *ctx, uint64_t value);
  * recorded on its own stream) fires; simulate then waits for it on the GPU, not on the host */
 int mapn_consumer_signal_event(mapn_ctx *ctx, uint64_t value, void *hip_event);
 /* bounds of the device-side waits in milliseconds (0 = leave unchanged): the peer-to-peer
- * exchange's wait for a peer's slice (default 200) and the queued consumer-fence wait (default
- * 10 000).  A wait that gives up is reported by the next mapn_simulate / mapn_wait_idle /
+ * exchange's wait for a peer's slice (default 2000: it also covers a peer whose HOST is late
+ * enqueueing the step; bench.py sets 200) and the queued consumer-fence wait (default 10 000).  A wait that gives up is reported by the next mapn_simulate / mapn_wait_idle /
  * mapn_download_* as MAPN_ERR_COMM (naming the peer) / MAPN_ERR_STATE. */
 int mapn_set_timeouts(mapn_ctx *ctx, uint32_t p2p_ms, uint32_t consumer_ms);
 
@@ -300,7 +300,7 @@ int mapn_set_gather_algorithm(mapn_ctx *ctx, int algorithm);
  * the launcher all-gathers the blobs (rank order) and every rank imports them.  Afterwards each
  * step ends with one small kernel that publishes a per-peer flag, waits for the peers' flags and
  * pulls their slices over xGMI (csrc/mapn_kernels.hip, p2p_gather_kernel).  Device-side waits are
- * bounded (mapn_set_timeouts, default 200 ms): a wait that timed out makes the next mapn_simulate /
+ * bounded (mapn_set_timeouts, default 2 s): a wait that timed out makes the next mapn_simulate /
  * mapn_wait_idle / mapn_download_* return MAPN_ERR_COMM naming the peer; mapn_p2p_status() != 0
  * reports the same without failing (peer q = status - 1).
  */

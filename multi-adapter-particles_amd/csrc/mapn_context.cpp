@@ -299,9 +299,9 @@ int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     a.brows = std::max(1u, (a.nb - 1u) / 2u + (a.half_d ? 1u : 0u));
     a.mass = base.mass; a.soft2 = base.soft2; a.dt = base.dt; a.damping = base.damping;
     uint32_t waves = 4, parts = 0;
-    const char *e = getenv("MAPN_SYM_PLAN");               // "waves,parts" tuning override
-    unsigned ew = 0, ep = 0;
-    if (e && sscanf(e, "%u,%u", &ew, &ep) == 2 && (ew == 4 || ew == 8) && ep >= 1) { waves = ew; parts = ep; }
+    const char *e = getenv("MAPN_SYM_PLAN");               // "waves,parts[,whole_only]" tuning override (parts 0 = default)
+    unsigned ew = 0, ep = 0, eo = 0;
+    if (e && sscanf(e, "%u,%u,%u", &ew, &ep, &eo) >= 2 && (ew == 4 || ew == 8)) { waves = ew; parts = ep; a.whole_only = eo ? 1u : 0u; }
     if (!parts) {
         // 2 waves per SIMD are resident (246 VGPRs).  32 four-wave workgroups per I-block measured best or
         // within 0.5 % of best at every size (65 536 bodies: parts 24 / 32 / 48 / 64 -> 0.663 / 0.647 / 0.669 /

@@ -70,6 +70,7 @@ struct SymArgs {
     uint32_t      parts;      // workgroups per I-block (gridDim.x)
     uint32_t      brows;      // rows allocated per J-block: (nb - 1) / 2 (+ 1 when nb is even)
     uint32_t      half_d;     // nb / 2 when nb is even (the half-ring partner), else 0
+    uint32_t      whole_only; // A/B only (MAPN_SYM_PLAN third field): deal whole meetings to waves, none shared
     float         mass, soft2, dt, damping;
     unsigned long long *stamps;   // diagnostic launches only (mapn_measure_clock), else null
 };

@@ -11,13 +11,15 @@
 //     two waves per SIMD) -- an I-block of 1024 bodies per wave;
 //   * a J-block is 64 bodies, ONE per lane, travelling with its reaction accumulator; after each step
 //     (8 packed evaluations = 32 interactions per lane) the travelling body and its reaction move one
-//     lane on (6 ds_bpermute_b32: through the LDS crossbar), so after 64 steps every lane has met
+//     lane on (9 ds_bpermute_b32: through the LDS crossbar), so after 64 steps every lane has met
 //     every body of the J-block and each body is back home with its complete reaction.
 // Measured (tools/ubench.hip, profiles/r02_ubench.txt): a cross-lane move costs ~12 SIMD cycles per
 // register whatever the mechanism (ds_bpermute_b32, ds_swizzle_b32, v_mov_b32_dpp), so the loop gets
 // faster the more bodies i a lane owns per move: 4 bodies 5.3e12 interactions/s, 8 bodies 7.4e12 in
 // the microbenchmark (one-sided pair term: 4.9e12); in the kernel 8 -> 16 bodies per lane gained
-// another 3-5 % although only two waves per SIMD remain.  LDS float atomics for the reaction
+// another 3-5 % although only two waves per SIMD remain (re-measured with the final loop: 12 bodies at
+// three waves per SIMD -8 %, 8 bodies at four waves -5 %, and the chip holds a lower clock under both:
+// profiles/r02_sym_loop_variants.txt).  LDS float atomics for the reaction
 // (ds_add_f32, ~195 cycles per wave-instruction): 1.1e12.
 //
 // Coverage of the N^2 ordered pairs (N padded to a multiple of 1024 with stand-in bodies that exert no
@@ -51,9 +53,11 @@ struct SymBodies {
     v2f ax[SYM_K2], ay[SYM_K2], az[SYM_K2];
 };
 
-// one step against the travelling body (xj, yj, zj): SYMMETRIC -- b collects the reaction on j
-// The reaction travels as the LOW half of a register pair whose high half stays zero, so the first
-// evaluation's fma can take it as its addend and ONE add per component folds the two halves again.
+// one step against the travelling body (xj, yj, zj): SYMMETRIC -- b collects the reaction on j.
+// The reaction travels UNFOLDED, as the register pair the packed fma chain accumulates in (the even and
+// the odd bodies i of the lane): the moves cost no VALU cycles, a fold per step would (3 v_pk_add + the
+// re-zeroing copies; measured 0.4-1.3 % slower, profiles/r02_sym_loop_variants.txt).  The meeting's end
+// folds the pair once.
 __device__ __forceinline__ void sym_step(SymBodies &b, float xj, float yj, float zj, v2f soft2,
                                          v2f &bx, v2f &by, v2f &bz)
 {
@@ -77,9 +81,7 @@ __device__ __forceinline__ void sym_step(SymBodies &b, float xj, float yj, float
         ry = __builtin_elementwise_fma(-dy, inv3, ry);
         rz = __builtin_elementwise_fma(-dz, inv3, rz);
     }
-    bx.x = rx.x + rx.y;
-    by.x = ry.x + ry.y;
-    bz.x = rz.x + rz.y;
+    bx = rx; by = ry; bz = rz;
 }
 
 // one step, ONE-SIDED (the I-block against itself: every ordered pair is met from both sides anyway)
@@ -108,7 +110,7 @@ __device__ __forceinline__ void one_step(SymBodies &b, float xj, float yj, float
 // grid = (S, NB)   block = 64 * WAVES
 // Workgroup (s, a): I-block a, part s of S of its meetings.  The meetings of an I-block are numbered
 // m = 0 .. M-1: m < 16 -> itself, J-block a*16 + m, one-sided; then 16 per partner block a + d.
-// The workgroup's part [m0, m1) is dealt to its waves contiguously.  Every wave keeps the I-block's
+// The workgroup's part is dealt to its waves: whole meetings first, the remainder shared step-wise.  Every wave keeps the I-block's
 // accumulators in registers for all of its meetings; at the end the WAVES copies are combined in LDS
 // in ascending wave order into ONE row arow[a][s][1024]; each symmetric meeting writes ONE row
 // brow[jblock][d-1][64] with the reactions of the J-block's bodies.
@@ -123,10 +125,20 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     const uint32_t nb = p.nb, half = p.half_d;             // half_d = NB/2 when NB is even, else 0
     const uint32_t D = (nb - 1u) / 2u;
     const uint32_t M = JPI * (1u + D) + ((half && a < half) ? JPI : 0u);
-    // part s of S, then wave w of WAVES, both by the same even split (the first `rem` take one more)
+    // part s of S (even split: the first `rem` parts take one more), then the part's `cnt` meetings to its
+    // waves: q = cnt / WAVES whole meetings each, and the remaining r < WAVES meetings are SHARED -- every
+    // wave runs 64 / WAVES of such a meeting's 64 steps (wave w starts with the J-block rotated by w * SEG
+    // lanes), the waves' partial reactions are added in LDS in ascending wave order.  All waves of the
+    // workgroup finish together (before: a wave with one meeting more kept the other three waiting -- at
+    // 65 536 bodies a quarter of the workgroups ran 5 meeting-times for 4.25 of work).
+    constexpr uint32_t SEG = 64u / WAVES;
     const uint32_t pm0 = (uint32_t)(((uint64_t)M * s) / p.parts), pm1 = (uint32_t)(((uint64_t)M * (s + 1u)) / p.parts);
     const uint32_t cnt = pm1 - pm0;
-    const uint32_t m0 = pm0 + (uint32_t)(((uint64_t)cnt * w) / WAVES), m1 = pm0 + (uint32_t)(((uint64_t)cnt * (w + 1u)) / WAVES);
+    // (p.whole_only: the A/B form -- whole meetings only, the first cnt % WAVES waves take one more)
+    const uint32_t wm0 = pm0 + (uint32_t)(((uint64_t)cnt * w) / WAVES), wm1 = pm0 + (uint32_t)(((uint64_t)cnt * (w + 1u)) / WAVES);
+    const uint32_t q = p.whole_only ? wm1 - wm0 : cnt / WAVES, r = p.whole_only ? 0u : cnt % WAVES, items = q + r;
+    const uint32_t first = p.whole_only ? wm0 : pm0 + w * q, first_shared = pm0 + WAVES * q;
+    __shared__ float part[WAVES - 1][WAVES][3][64];
 
     const float4 *__restrict__ pos = p.pos_old;
     // N need not be a multiple of the block: bodies past the end are stand-ins so far away that
@@ -156,35 +168,48 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     // diagnostic launches only (mapn_measure_clock): stamps around the wave's meetings; null otherwise
     unsigned long long st_c = 0, st_r = 0;
     if (p.stamps) asm volatile("s_memrealtime %0\n s_memtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(st_r), "=s"(st_c));
-    uint32_t jb = 0, d = 0;
+    auto item = [&](uint32_t it, uint32_t &jb, uint32_t &d, uint32_t &rot) {
+        meeting(it < q ? first + it : first_shared + (it - q), jb, d);
+        rot = it < q ? 0u : w * SEG;
+    };
+    uint32_t jb = 0, d = 0, rot = 0;
     float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m0 < m1) { meeting(m0, jb, d); pn = body(jb * 64u + lane); }
-    for (uint32_t m = m0; m < m1; m++) {
-        const uint32_t jb_cur = jb, d_cur = d;
+    if (items) { item(0u, jb, d, rot); pn = body(jb * 64u + ((lane + rot) & 63u)); }
+    for (uint32_t it = 0; it < items; it++) {
+        const uint32_t jb_cur = jb, d_cur = d, rot_cur = rot;
+        const int steps = it < q ? 64 : (int)SEG;
         float xj = pn.x, yj = pn.y, zj = pn.z;
-        if (m + 1u < m1) { meeting(m + 1u, jb, d); pn = body(jb * 64u + lane); }
+        if (it + 1u < items) { item(it + 1u, jb, d, rot); pn = body(jb * 64u + ((lane + rot) & 63u)); }
         // (Alternatives to moving the position, measured on one box each: a wave-private LDS copy of the J-block
         //  read with one ds_read_b128 per step, also one step ahead: 2-3 % slower; re-reading body (lane + k) % 64
         //  from global memory every step, fetched one step ahead: 9 % slower.)
         if (d_cur == 0u) {
 #pragma nounroll
-            for (int k = 0; k < 64; k++) {
+            for (int k = 0; k < steps; k++) {
                 const float nx = lane_next(xj, next), ny = lane_next(yj, next), nz = lane_next(zj, next);
                 one_step(b, xj, yj, zj, soft2);
                 xj = nx; yj = ny; zj = nz;
             }
         } else {
             v2f bx = v2f{0.f, 0.f}, by = v2f{0.f, 0.f}, bz = v2f{0.f, 0.f};
-#pragma nounroll
-            for (int k = 0; k < 64; k++) {
+#pragma nounroll                                           // (unrolled by two: no loop-carried copies, but the moves issue late: 2 % slower)
+            for (int k = 0; k < steps; k++) {
                 // the travelling position does not change during the step: its move overlaps the step
                 const float nx = lane_next(xj, next), ny = lane_next(yj, next), nz = lane_next(zj, next);
                 sym_step(b, xj, yj, zj, soft2, bx, by, bz);
                 xj = nx; yj = ny; zj = nz;
                 bx.x = lane_next(bx.x, next); by.x = lane_next(by.x, next); bz.x = lane_next(bz.x, next);
+                bx.y = lane_next(bx.y, next); by.y = lane_next(by.y, next); bz.y = lane_next(bz.y, next);
             }
-            // 64 moves: every body is back in its home lane with its complete reaction from this I-block
-            p.brow[((size_t)jb_cur * p.brows + (d_cur - 1u)) * 64u + lane] = make_float4(bx.x, by.x, bz.x, 0.f);
+            const float fx = bx.x + bx.y, fy = by.x + by.y, fz = bz.x + bz.y;
+            if (it < q) {
+                // 64 moves: every body is back in its home lane with its complete reaction from this I-block
+                p.brow[((size_t)jb_cur * p.brows + (d_cur - 1u)) * 64u + lane] = make_float4(fx, fy, fz, 0.f);
+            } else {
+                // SEG moves: this lane holds body (lane + rot + SEG) % 64 with this wave's share of its reaction
+                const uint32_t home = (lane + rot_cur + SEG) & 63u;
+                part[it - q][w][0][home] = fx; part[it - q][w][1][home] = fy; part[it - q][w][2][home] = fz;
+            }
         }
     }
 
@@ -213,6 +238,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
 #pragma unroll
         for (int ww = 0; ww < WAVES; ww++) { ax += comb[ww][0][e]; ay += comb[ww][1][e]; az += comb[ww][2][e]; }
         row[e] = make_float4(ax, ay, az, 0.f);
+    }
+    // the shared meetings' reactions: wave t adds the WAVES shares of shared meeting t in ascending wave order
+    if (w < r) {
+        uint32_t jbs, ds;
+        meeting(first_shared + w, jbs, ds);
+        if (ds != 0u) {
+            float fx = 0.f, fy = 0.f, fz = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < WAVES; ww++) { fx += part[w][ww][0][lane]; fy += part[w][ww][1][lane]; fz += part[w][ww][2][lane]; }
+            p.brow[((size_t)jbs * p.brows + (ds - 1u)) * 64u + lane] = make_float4(fx, fy, fz, 0.f);
+        }
     }
 }
 

@@ -88,6 +88,21 @@ def sym_reaction_rows(nb: int, block: int) -> list[int]:
     return list(range(D + (1 if half and block >= half else 0)))
 
 
+def sym_wave_items(meetings: int, parts: int, waves: int):
+    """How force_sym_kernel deals the M meetings of an I-block: yields (part, wave, meeting, first lane
+    rotation, steps).  A part's meetings go to its waves whole (q = cnt // waves each); the remaining
+    cnt % waves meetings are shared, every wave running 64 // waves of the 64 steps from a rotated start."""
+    seg = 64 // waves
+    for s in range(parts):
+        pm0, pm1 = meetings * s // parts, meetings * (s + 1) // parts
+        q, r = divmod(pm1 - pm0, waves)
+        for w in range(waves):
+            for it in range(q):
+                yield s, w, pm0 + w * q + it, 0, 64
+            for t in range(r):
+                yield s, w, pm0 + waves * q + t, w * seg, seg
+
+
 def chunk_tiles(tiles: int, splits: int, chunk: int) -> tuple[int, int]:
     """64-body tiles [t0, t1) of chunk `chunk` of `splits` (mapn_kernels.hip chunk_tiles)."""
     base, rem = divmod(tiles, splits)

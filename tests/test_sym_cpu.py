@@ -5,6 +5,8 @@ blocks exactly once, its reduce kernel must read exactly the rows that were writ
 mode's row rotation must start on the rank's own slice without changing which chunk a row names."""
 import itertools
 
+import numpy as np
+
 import pytest
 
 from mapn import shard
@@ -59,3 +61,21 @@ def test_chunk_tiles_partition_the_range():
         edges = [shard.chunk_tiles(tiles, splits, c) for c in range(splits)]
         assert edges[0][0] == 0 and edges[-1][1] == tiles
         assert all(edges[c][1] == edges[c + 1][0] for c in range(splits - 1))
+
+
+@pytest.mark.parametrize("meetings,parts,waves", [(528, 32, 4), (512, 32, 4), (16, 4, 4), (48, 12, 4), (2064, 32, 4), (528, 16, 8), (40, 7, 4), (3, 2, 4)])
+def test_wave_deal_covers_every_step_of_every_meeting_once_and_is_balanced(meetings, parts, waves):
+    """force_sym_kernel's deal of an I-block's meetings to waves: whole meetings first, the remainder of a
+    part shared step-wise.  Every (meeting, travelling-body offset) is run exactly once, and the waves of
+    a workgroup all run the same number of steps (nobody waits at the closing barrier)."""
+    seen = np.zeros((meetings, 64), np.int32)
+    steps = {}
+    for s, w, m, rot, n in shard.sym_wave_items(meetings, parts, waves):
+        seen[m, rot:rot + n] += 1
+        steps[(s, w)] = steps.get((s, w), 0) + n
+    assert (seen == 1).all()
+    for s in range(parts):
+        per_wave = {steps.get((s, w), 0) for w in range(waves)}
+        assert len(per_wave) == 1
+    per_part = sorted({steps.get((s, 0), 0) for s in range(parts)})
+    assert per_part[-1] - per_part[0] <= 64 // waves      # parts differ by at most one meeting = 64 / waves steps per wave

@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--kernel", choices=["auto", "lds", "sgpr", "sym"], default="auto",
                     help="force kernel: scalar-cache (auto), LDS-tiled, or the symmetric (Newton's third law) kernel")
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl")
-    ap.add_argument("--gather", choices=["auto", "allgather", "sendrecv", "p2p", "flow"], default="auto",
+    ap.add_argument("--gather", choices=["auto", "allgather", "sendrecv", "p2p", "flow", "sym"], default="auto",
                     help="how the in-library exchange is issued: RCCL ncclAllGather, one group of RCCL send/recv pairs, or the "
                          "direct peer-to-peer pull kernel (hipIpc + device flags); auto times every way that sets up and "
                          "verifies on this node during untimed steps and keeps the fastest")
@@ -182,7 +182,7 @@ def main():
     gather_fn = None
     if dist is not None:
         transport = a.transport
-        if transport == "rccl" and a.gather not in ("p2p", "flow"):
+        if transport == "rccl" and a.gather not in ("p2p", "flow", "sym"):
             try:
                 c.comm_init_torch()
             except Exception as e:     # RCCL-in-library unavailable: use torch's RCCL instead, loudly
@@ -237,7 +237,7 @@ def main():
         if a.overlap:                                   # --overlap: only the overlap structures
             candidates = [x for x in candidates if x[2]]
         p2p_ok = False
-        if a.gather in ("auto", "p2p", "flow") and world > 1:
+        if a.gather in ("auto", "p2p", "flow", "sym") and world > 1:
             try:
                 c.p2p_setup_torch()
                 c.set_timeouts(p2p_ms=200)
@@ -248,17 +248,36 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # all ranks or none
             p2p_ok = bool(ok.item())
             # LAST: these have to prove themselves on this node
-            if p2p_ok and a.gather in ("auto", "p2p"):
-                candidates.append(("p2p", 2, False))
+            if p2p_ok and a.gather in ("auto", "p2p", "sym"):
+                candidates.append(("p2p", 2, False))               # (also the yardstick "p2p+symmetric" is verified against)
             if p2p_ok and a.gather in ("auto", "flow"):
                 candidates.append(("p2p+inkernel", 3, False))  # the same exchange overlapped inside the force launch
+            if p2p_ok and a.gather in ("auto", "sym") and mode == mapn.FORCE_ALL_PAIRS and (n // world) % 1024 == 0 and n % world == 0:
+                # the SYMMETRIC step sharded over the ranks: every unordered pair of the job once, reactions
+                # stored into the owners' receive regions, positions pulled as in "p2p"
+                candidates.append(("p2p+symmetric", 4, False))
 
         def select(name, algo, overlap):
             c.set_gather_algorithm(algo)
             c.set_shard_overlap(overlap)
 
+        def symmetric_deviation():
+            import numpy as np
+            got = []
+            for algo in (2, 4):
+                c.WaitForGpu()
+                c.set_gather_algorithm(algo)
+                pos0, vel0 = mapn.generate_initial_state(n, seed=a.seed)
+                c.upload_state(pos0, vel0)
+                sync()
+                for _ in range(4):
+                    step()
+                c.WaitForGpu()
+                got.append(c.download_state()[0][:, :3].astype(np.float64))
+            return float(np.linalg.norm(got[0] - got[1], axis=1).max() / 400.0)
+
         def reinit():
-            c.set_gather_algorithm(0)
+            c.set_gather_algorithm(0 if a.gather not in ("p2p", "flow", "sym") else 2)
             c.set_shard_overlap(False)
             pos0, vel0 = mapn.generate_initial_state(n, seed=a.seed)
             c.upload_state(pos0, vel0)
@@ -273,7 +292,7 @@ def main():
                 nonlocal c
                 c.close()
                 c = mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed, rank=rank, world_size=world, flags=flags)
-                if a.gather not in ("p2p", "flow"):
+                if a.gather not in ("p2p", "flow", "sym"):
                     c.comm_init_torch()
                 if with_p2p:
                     c.p2p_setup_torch()
@@ -304,6 +323,14 @@ def main():
                     dist.all_reduce(bad, op=dist.ReduceOp.MAX)
                     if bad.item() and not failed:
                         failed = "replicas differ across ranks"
+                if not bad.item() and algo == 4:
+                    # identical replicas do not show that the reactions ARRIVED: compare four steps from the
+                    # initial state with the one-sided sharded step ("p2p", verified above)
+                    dev = symmetric_deviation()
+                    bad = torch.tensor([0 if dev < 1e-5 else 1], device=red_dev)
+                    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                    if bad.item():
+                        failed = f"symmetric sharded step deviates from the one-sided one by {dev:.2e} of the spread after 4 steps"
                 if bad.item():
                     if rank == 0:
                         print(f"[bench] exchange '{name}' failed on this node ({failed or 'on another rank'}) -> not used; state re-initialised",
@@ -319,6 +346,8 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 trial[name] = float(t.item()) / 30
             gather_algo = min(trial, key=trial.get) if trial else "allgather"
+            if a.gather == "sym" and "p2p+symmetric" in trial:
+                gather_algo = "p2p+symmetric"               # asked for by name: it only had to pass its check
             if rank == 0:
                 print("[bench] exchange trial: " + ", ".join(f"{k} {v*1e6:.1f} us/step" for k, v in trial.items()) + f" -> {gather_algo}",
                       file=sys.stderr, flush=True)
@@ -326,6 +355,9 @@ def main():
             gather_algo = candidates[0][0] if candidates else "allgather"
             if gather_algo.startswith("p2p") and not p2p_ok:
                 sys.exit("bench: --gather p2p requested but the peer-to-peer setup failed")
+
+        if a.gather == "sym" and gather_algo != "p2p+symmetric":
+            sys.exit("bench: --gather sym: the sharded symmetric step does not apply (N / ranks must be a multiple of 1024) or failed its check")
         chosen = {x[0]: x for x in candidates}.get(gather_algo, (gather_algo, 0, False))
         c.set_gather_algorithm(chosen[1])
         c.set_shard_overlap(chosen[2])
@@ -430,7 +462,7 @@ def main():
                                    "flop_executed_per_pair": executed_per_pair,
                                    "frac_executed": ach / peak * executed_per_pair / FLOP_PER_PAIR,
                                    "instruction_mix_ceiling": ("symmetric kernel: 14 packed ops x 4 cycles + 2 v_rsq_f32 x 8 cycles per 256 ordered interactions per SIMD "
-                                                               "(+ 6 ds_bpermute_b32 and 3 adds per 16 per lane) = 111 % of the ALGORITHMIC peak at any clock: every "
+                                                               "(+ 9 ds_bpermute_b32 per 16 per lane, no VALU cycles) = 111 % of the ALGORITHMIC peak at any clock: every "
                                                                "unordered pair is evaluated once (Newton's third law), so `frac` counts 20 flop per ordered pair of "
                                                                "which 12 are executed (`frac_executed`)") if sym else
                                                               "11 packed ops x 4 cycles + 2 v_rsq_f32 x 8 cycles per 128 pairs per SIMD = 66.7 % of peak at any clock",

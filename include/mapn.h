@@ -292,7 +292,12 @@ int mapn_comm_init(mapn_ctx *ctx, const void *id128);
  * overlapped INSIDE the force launch ("flow" mode: the pull runs beside the launch on the comm
  * stream, the launch starts on its own slice and its remote chunks wait for each peer's arrival
  * flag, the last integrated tile publishes to the peers -- no separate exchange step, no
- * cross-stream event); all ranks must agree */
+ * cross-stream event), 4 = the SYMMETRIC step sharded over the ranks (every unordered pair evaluated
+ * once in the whole job: a rank runs the meetings of its own 1024-body blocks, stores the reactions it
+ * produced for another rank's bodies -- summed over its blocks first, one row per destination -- straight
+ * into that rank's receive region, and integrates its bodies from its own rows plus the rows received;
+ * positions then travel as in 2; needs N / world_size to be a multiple of 1024 and all bodies active,
+ * otherwise the step runs as 2); all ranks must agree */
 int mapn_set_gather_algorithm(mapn_ctx *ctx, int algorithm);
 /*
  * Direct peer-to-peer exchange (algorithm 2 of mapn_set_gather_algorithm), no collective library:

@@ -139,6 +139,9 @@ struct mapn_ctx {
     uint32_t *p2p_peer_flags[mapn::P2P_MAX_RANKS] = {};
     uint32_t p2p_step = 0;
     uint32_t **p2p_flag_table = nullptr;      // device copy of p2p_peer_flags[] (flow mode reads it in the kernel)
+    uint32_t *sym_shard_ticket = nullptr;     // gather algorithm 4: the send kernel's per-destination tickets
+    uint32_t sym_shard_step = 0;
+    uint32_t sym_send_mask = 0, sym_recv_mask = 0;
     uint32_t *flow_block = nullptr;           // ordinary device memory: [0..15] arrived[q], [16] tiles_done (flow mode)
 
     // graph replay
@@ -346,6 +349,98 @@ int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     return MAPN_OK;
 }
 
+// Gather algorithm 4: the symmetric step sharded over ranks.  Every rank's slice must be whole I-blocks;
+// the reaction scratch is one row per (J-block of the job, I-block of this rank): n * nbl * 16 bytes.
+bool sym_shard_eligible(const mapn_ctx *c, uint32_t active)
+{
+    if (!c->p2p_ready || c->gather_algo != 4 || c->cfg.world_size < 2) return false;
+    if ((c->cfg.kernel != MAPN_KERNEL_SYMMETRIC && c->cfg.kernel != MAPN_KERNEL_AUTO) || c->plan_forced) return false;
+    if (c->cfg.force_mode != MAPN_FORCE_ALL_PAIRS || active != c->n) return false;
+    if (c->count % mapn::SYM_BLOCK != 0 || c->count * (uint32_t)c->cfg.world_size != c->n) return false;
+    const char *e = getenv("MAPN_SYM_MAX_MB");
+    const uint64_t cap = (e ? strtoull(e, nullptr, 10) : 16384ull) << 20;
+    return (uint64_t)c->n * (c->count / mapn::SYM_BLOCK) * 16ull <= cap;
+}
+
+// which ranks this rank produces reactions for / receives reactions from: the meeting schedule of
+// force_sym_kernel (I-block a meets a+1 .. a+D, and a+nb/2 when nb is even and a < nb/2), block -> owner
+void sym_shard_masks(uint32_t nb, uint32_t world, uint32_t rank, uint32_t &send, uint32_t &recv)
+{
+    const uint32_t nbl = nb / world, D = (nb - 1u) / 2u, half = (nb & 1u) ? 0u : nb / 2u;
+    send = recv = 0;
+    for (uint32_t a = 0; a < nb; a++) {
+        for (uint32_t d = 1; d <= D + (half ? 1u : 0u); d++) {
+            if (d > D && !(d == half && a < half)) continue;
+            const uint32_t b = (a + d) % nb, ra = a / nbl, rb = b / nbl;
+            if (ra == rank) send |= 1u << rb;
+            if (rb == rank) recv |= 1u << ra;
+        }
+    }
+}
+
+int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
+{
+    const uint32_t world = (uint32_t)c->cfg.world_size, rank = (uint32_t)c->cfg.rank;
+    mapn::SymArgs a{};
+    a.pos_old = base.pos_old; a.vel_old = base.vel_old; a.pos_new = base.pos_new; a.vel_new = base.vel_new;
+    a.n = c->n; a.nb = c->n / mapn::SYM_BLOCK;
+    a.half_d = (a.nb & 1u) ? 0u : a.nb / 2u;
+    a.brows = 0;
+    a.mass = base.mass; a.soft2 = base.soft2; a.dt = base.dt; a.damping = base.damping;
+    a.shard_nbl = c->count / mapn::SYM_BLOCK;
+    a.a0 = rank * a.shard_nbl;
+    // about 512 four-wave workgroups fill the chip once (2 per CU); at least 32 per I-block as in the
+    // unsharded launch, never fewer than one whole meeting per wave
+    const uint32_t waves = 4, meetings = mapn::SYM_JPI * (1u + (a.nb - 1u) / 2u);
+    uint32_t parts = std::max(32u, (512u + a.shard_nbl - 1u) / a.shard_nbl);
+    const char *e = getenv("MAPN_SYM_SHARD_PARTS");
+    if (e && atoi(e) > 0) parts = (uint32_t)atoi(e);
+    parts = std::min(parts, std::max(1u, meetings / waves));
+    a.parts = parts;
+    const size_t ab = (size_t)a.shard_nbl * parts * mapn::SYM_BLOCK * sizeof(float4), bb = (size_t)c->n * a.shard_nbl * sizeof(float4);
+    if (ab > c->sym_arow_bytes) {
+        if (c->sym_arow) HIP_TRY(hipFree(c->sym_arow));
+        c->sym_arow = nullptr; c->sym_arow_bytes = 0;
+        HIP_TRY(hipMalloc(&c->sym_arow, ab));
+        c->sym_arow_bytes = ab;
+    }
+    if (bb > c->sym_brow_bytes) {
+        if (c->sym_brow) HIP_TRY(hipFree(c->sym_brow));
+        c->sym_brow = nullptr; c->sym_brow_bytes = 0;
+        HIP_TRY(hipMalloc(&c->sym_brow, bb));
+        c->sym_brow_bytes = bb;
+    }
+    a.arow = c->sym_arow; a.brow = c->sym_brow;
+    HIP_TRY(mapn::launch_force_sym(a, waves, c->compute));
+    if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
+
+    mapn::SymShardArgs h{};
+    h.pos_old = a.pos_old; h.vel_old = a.vel_old; h.pos_new = a.pos_new; h.vel_new = a.vel_new;
+    h.arow = a.arow; h.brow = a.brow;
+    for (uint32_t q = 0; q < world; q++) {
+        h.flags_peer[q] = c->p2p_peer_flags[q];
+        h.recv_peer[q] = reinterpret_cast<float4 *>(reinterpret_cast<char *>(c->p2p_peer_flags[q]) + mapn::SYM_RECV_OFFSET);
+    }
+    h.flags_mine = c->p2p_flags;
+    h.recv_mine = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(c->p2p_flags) + mapn::SYM_RECV_OFFSET);
+    h.ticket = c->sym_shard_ticket;
+    h.status = c->async_status;
+    h.rank = rank; h.world = world; h.count = c->count;
+    h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = parts;
+    h.send_mask = c->sym_send_mask; h.recv_mask = c->sym_recv_mask;
+    h.wgs_per_dest = std::max(1u, std::min(32u, c->count / 1024u));
+    h.step = ++c->sym_shard_step;
+    h.timeout_ticks = c->p2p_timeout_ticks;
+    h.mass = a.mass; h.dt = a.dt; h.damping = a.damping;
+    HIP_TRY(mapn::launch_sym_shard_send(h, c->compute));
+    HIP_TRY(mapn::launch_sym_shard_reduce(h, c->compute));
+    mapn::ForcePlan p{};
+    p.kind = mapn::KERNEL_SYM; p.k = 2 * mapn::SYM_K2; p.waves = waves; p.sb = parts; p.nseg = 1; p.epi = mapn::EPI_ROWS;
+    c->last_plan = p; c->last_i_count = c->count; c->last_launches = 3;
+    c->sym_parts = parts; c->sym_waves = waves;
+    return MAPN_OK;
+}
+
 // MAPN_OWN_PLAN / MAPN_REM_PLAN = "k,waves,sb": tuning override of the two sharded launches
 bool env_plan(const char *name, mapn::ForcePlan &p)
 {
@@ -453,7 +548,7 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
     a.i_first = lo;
     a.i_count = i_count;
     const bool flow = c->p2p_ready && c->gather_algo == 3;
-    const bool sharded_native = c->comm != nullptr || (c->p2p_ready && c->gather_algo == 2);
+    const bool sharded_native = c->comm != nullptr || (c->p2p_ready && (c->gather_algo == 2 || c->gather_algo == 4));
     const bool overlap = c->comm != nullptr && c->gather_algo < 2 && (c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP);
     if (flow) {
         // the pull half of THIS step's exchange runs beside the launch on the comm stream (it only
@@ -483,6 +578,8 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
         HIP_TRY(mapn::launch_flow_publish(c->p2p_flag_table, a.flow_rank, a.flow_world, a.flow_publish, c->compute));
     } else if (i_count > 0 && sym_eligible(c, active)) {
         if (int rc = enqueue_sym(c, a, timer)) return rc;
+    } else if (i_count > 0 && sym_shard_eligible(c, active)) {
+        if (int rc = enqueue_sym_shard(c, a, timer)) return rc;
     } else if (i_count > 0 && !overlap) {
         // one force launch over all j.  Sharded: the read buffer is complete once the all-gather
         // that filled it has finished (event recorded on the comm stream).
@@ -645,7 +742,7 @@ int enqueue_flow_pull(mapn_ctx *c)
 int enqueue_gather(mapn_ctx *c)
 {
     if (c->p2p_ready && c->gather_algo == 3) return enqueue_flow_pull(c);
-    if (c->p2p_ready && c->gather_algo == 2) return enqueue_p2p(c);
+    if (c->p2p_ready && (c->gather_algo == 2 || c->gather_algo == 4)) return enqueue_p2p(c);   // 4: positions travel as in 2
     if (!c->comm) return MAPN_OK;
     const uint32_t w = c->buffer_index;
     const bool overlap = (c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP) != 0;
@@ -848,6 +945,7 @@ int mapn_destroy(mapn_ctx *c)
     }
     if (c->p2p_flags) (void)hipFree(c->p2p_flags);
     if (c->p2p_flag_table) (void)hipFree(c->p2p_flag_table);
+    if (c->sym_shard_ticket) (void)hipFree(c->sym_shard_ticket);
     if (c->flow_block) (void)hipFree(c->flow_block);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->exported_done) (void)hipEventDestroy(c->exported_done);
@@ -1328,7 +1426,7 @@ int mapn_comm_init(mapn_ctx *c, const void *id128)
 
 int mapn_set_gather_algorithm(mapn_ctx *c, int algorithm)
 {
-    if (!c || algorithm < 0 || algorithm > 3) return fail(MAPN_ERR_INVALID_ARGUMENT, "set_gather_algorithm: bad argument");
+    if (!c || algorithm < 0 || algorithm > 4) return fail(MAPN_ERR_INVALID_ARGUMENT, "set_gather_algorithm: bad argument");
     if (algorithm >= 2 && !c->p2p_ready) return fail(MAPN_ERR_STATE, "set_gather_algorithm(%d): call mapn_p2p_import first", algorithm);
     if (algorithm < 2 && c->cfg.world_size > 1 && !c->comm && !c->external_gather)
         return fail(MAPN_ERR_STATE, "set_gather_algorithm(%d): no RCCL communicator (mapn_comm_init)", algorithm);
@@ -1368,8 +1466,11 @@ int mapn_p2p_export(mapn_ctx *c, void *out_blob)
     if (!c->p2p_flags) {
         // publication counters: uncached device memory, so that a peer's store over xGMI and this
         // GPU's polling loads meet in memory, never in a cache
-        HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void **>(&c->p2p_flags), 256, hipDeviceMallocUncached));
-        HIP_TRY(hipMemset(c->p2p_flags, 0, 256));
+        // Behind the counters (same allocation, same hipIpc handle): the receive region of the sharded symmetric
+        // step, one float4 row per sender rank and body of this rank -- peers store into it, this GPU reads it.
+        const size_t bytes = mapn::SYM_RECV_OFFSET + (size_t)c->cfg.world_size * c->count * sizeof(float4);
+        HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void **>(&c->p2p_flags), bytes, hipDeviceMallocUncached));
+        HIP_TRY(hipMemset(c->p2p_flags, 0, bytes));
         HIP_TRY(hipDeviceSynchronize());
     }
     P2PBlob b{};
@@ -1406,6 +1507,10 @@ int mapn_p2p_import(mapn_ctx *c, const void *blobs, int count)
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->flow_block), 256));
     HIP_TRY(hipMemset(c->flow_block, 0, 256));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->sym_shard_ticket), 256));
+    HIP_TRY(hipMemset(c->sym_shard_ticket, 0, 256));
+    if (c->count % mapn::SYM_BLOCK == 0 && c->count * (uint32_t)count == c->n)
+        sym_shard_masks(c->n / mapn::SYM_BLOCK, (uint32_t)count, (uint32_t)c->cfg.rank, c->sym_send_mask, c->sym_recv_mask);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->p2p_flag_table), sizeof(uint32_t *) * mapn::P2P_MAX_RANKS));
     HIP_TRY(hipMemcpy(c->p2p_flag_table, c->p2p_peer_flags, sizeof(uint32_t *) * mapn::P2P_MAX_RANKS, hipMemcpyHostToDevice));
     c->p2p_ready = true;
@@ -1556,7 +1661,7 @@ int mapn_get_kernel_stats(mapn_ctx *c, int reset, mapn_kernel_stats *out)
     out->epilogue = (uint32_t)p.epi;
     out->force_launches_per_step = c->last_launches ? c->last_launches : 1u;
     if (p.kind == mapn::KERNEL_SYM) {
-        out->force_launches_per_step = 1;                  // + sym_reduce_integrate_kernel (fused = 0)                      // grid (parts, I-blocks); one wave = 8 bodies per lane
+        out->force_launches_per_step = c->last_launches > 1 ? c->last_launches - 1u : 1u;   // the last one is the reduce + integrate launch (fused = 0); sharded: + the send kernel
         out->grid_x = p.sb; out->grid_y = (i_count + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK; out->j_splits = p.sb * p.waves; out->fused = 0; out->epilogue = 3;
     }
     if (reset) { c->force_launches = 0; c->force_seconds_sum = 0.0; }

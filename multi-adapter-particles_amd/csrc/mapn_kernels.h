@@ -71,11 +71,46 @@ struct SymArgs {
     uint32_t      brows;      // rows allocated per J-block: (nb - 1) / 2 (+ 1 when nb is even)
     uint32_t      half_d;     // nb / 2 when nb is even (the half-ring partner), else 0
     uint32_t      whole_only; // A/B only (MAPN_SYM_PLAN third field): deal whole meetings to waves, none shared
+    uint32_t      a0;         // sharded form: first I-block of this rank (gridDim.y = its nbl blocks); 0 otherwise
+    uint32_t      shard_nbl;  // sharded form: I-blocks of this rank -- brow is [n / 64][shard_nbl][64], one row per (J-block, local I-block); 0 = unsharded
     float         mass, soft2, dt, damping;
     unsigned long long *stamps;   // diagnostic launches only (mapn_measure_clock), else null
 };
 hipError_t launch_force_sym(const SymArgs &a, uint32_t waves, hipStream_t st);
 hipError_t launch_sym_reduce(const SymArgs &a, hipStream_t st);
+
+// The symmetric step SHARDED over ranks (gather algorithm 4): a rank runs the meetings of its own I-blocks
+// (force_sym_kernel with a0 / shard_nbl), adds the reactions it produced for every rank's bodies over its
+// I-blocks in ascending order and stores ONE row per destination rank straight into that rank's receive
+// region (sym_shard_send_kernel: remote stores through the hipIpc mapping, then the flag), and integrates
+// its own bodies from its a-rows plus the rows received (sym_shard_reduce_kernel: waits for the senders'
+// flags, bounded).
+enum { P2P_MAX_RANKS = 16 };          // ranks of a direct peer-to-peer job (one process per GPU, buffers mapped through hipIpc)
+enum { SYM_FLAG_BASE = 16,            // reaction-arrival counters follow the P2P_MAX_RANKS publication counters
+       SYM_RECV_OFFSET = 4096 };      // byte offset of the receive region [world][count] float4 inside the flags allocation
+struct SymShardArgs {
+    const float4 *pos_old;
+    const float  *vel_old;
+    float4       *pos_new;
+    float        *vel_new;
+    const float4 *arow;                       // [nbl][parts][SYM_BLOCK]
+    const float4 *brow;                       // [n / 64][nbl][64]
+    float4       *recv_peer[P2P_MAX_RANKS];   // rank q's receive region as mapped here: row [sender][body of q]
+    uint32_t     *flags_peer[P2P_MAX_RANKS];  // rank q's flag array as mapped here
+    const float4 *recv_mine;
+    uint32_t     *flags_mine;
+    uint32_t     *ticket;                     // [world] workgroups of the send kernel that have finished, per destination
+    uint32_t     *status;                     // host-visible word: non-zero = a wait timed out
+    uint32_t      rank, world, count;         // count = bodies per rank (a multiple of SYM_BLOCK)
+    uint32_t      nb, nbl, a0, half_d, parts;
+    uint32_t      send_mask, recv_mask;       // bit q: this rank produces reactions for / receives reactions from rank q
+    uint32_t      wgs_per_dest;
+    uint32_t      step;                       // monotonically increasing (>= 1)
+    uint64_t      timeout_ticks;
+    float         mass, dt, damping;
+};
+hipError_t launch_sym_shard_send(const SymShardArgs &a, hipStream_t st);
+hipError_t launch_sym_shard_reduce(const SymShardArgs &a, hipStream_t st);
 
 bool force_plan_supported(const ForcePlan &plan);
 hipError_t launch_force(const ForcePlan &plan, const StepArgs &a, hipStream_t st);
@@ -84,7 +119,6 @@ hipError_t launch_central_well(const StepArgs &a, hipStream_t st);
 
 // Direct peer-to-peer exchange of the new position slices (one process per GPU, peers' buffers
 // mapped through hipIpc).  See p2p_gather_kernel.
-enum { P2P_MAX_RANKS = 16 };
 struct P2PArgs {
     float4       *local;                    // this rank's written position buffer (full N)
     const float4 *peer[P2P_MAX_RANKS];      // every rank's written position buffer, as mapped here

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t s = blockIdx.x, a = blockIdx.y;
+    const uint32_t s = blockIdx.x, la = blockIdx.y, a = p.a0 + la;    // a: the I-block in the whole job; la: among this launch's
     const uint32_t nb = p.nb, half = p.half_d;             // half_d = NB/2 when NB is even, else 0
     const uint32_t D = (nb - 1u) / 2u;
     const uint32_t M = JPI * (1u + D) + ((half && a < half) ? JPI : 0u);
@@ -165,6 +165,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
         ap = ap >= nb ? ap - nb : ap;
         jb = ap * JPI + t;
     };
+    // where the reactions of J-block jb from this I-block go: one row per partner distance, or -- sharded --
+    // one row per I-block of this rank (sym_shard_send_kernel adds them up per destination rank)
+    auto brow_row = [&](uint32_t jb, uint32_t d) -> size_t {
+        return p.shard_nbl ? (size_t)jb * p.shard_nbl + la : (size_t)jb * p.brows + (d - 1u);
+    };
     // diagnostic launches only (mapn_measure_clock): stamps around the wave's meetings; null otherwise
     unsigned long long st_c = 0, st_r = 0;
     if (p.stamps) asm volatile("s_memrealtime %0\n s_memtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(st_r), "=s"(st_c));
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
             const float fx = bx.x + bx.y, fy = by.x + by.y, fz = bz.x + bz.y;
             if (it < q) {
                 // 64 moves: every body is back in its home lane with its complete reaction from this I-block
-                p.brow[((size_t)jb_cur * p.brows + (d_cur - 1u)) * 64u + lane] = make_float4(fx, fy, fz, 0.f);
+                p.brow[brow_row(jb_cur, d_cur) * 64u + lane] = make_float4(fx, fy, fz, 0.f);
             } else {
                 // SEG moves: this lane holds body (lane + rot + SEG) % 64 with this wave's share of its reaction
                 const uint32_t home = (lane + rot_cur + SEG) & 63u;
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
         asm volatile("" :: "v"(b.ax[0]), "v"(b.ay[0]), "v"(b.az[0]));
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
-            const size_t wave = ((size_t)a * p.parts + s) * WAVES + w;
+            const size_t wave = ((size_t)la * p.parts + s) * WAVES + w;
             p.stamps[2 * wave] = c1 - st_c;
             p.stamps[2 * wave + 1] = r1 - st_r;
         }
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
         comb[w][2][e0] = b.az[k].x; comb[w][2][e1] = b.az[k].y;
     }
     __syncthreads();
-    float4 *row = p.arow + ((size_t)a * p.parts + s) * SYM_IB;
+    float4 *row = p.arow + ((size_t)la * p.parts + s) * SYM_IB;
     for (uint32_t e = threadIdx.x; e < SYM_IB; e += 64u * WAVES) {
         float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
             float fx = 0.f, fy = 0.f, fz = 0.f;
 #pragma unroll
             for (int ww = 0; ww < WAVES; ww++) { fx += part[w][ww][0][lane]; fy += part[w][ww][1][lane]; fz += part[w][ww][2][lane]; }
-            p.brow[((size_t)jbs * p.brows + (ds - 1u)) * 64u + lane] = make_float4(fx, fy, fz, 0.f);
+            p.brow[brow_row(jbs, ds) * 64u + lane] = make_float4(fx, fy, fz, 0.f);
         }
     }
 }
@@ -298,12 +303,129 @@ __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs
     vo[0] = vx; vo[1] = vy; vo[2] = vz;
 }
 
+
+// ---- the symmetric step sharded over ranks ----------------------------------------------------------
+namespace {
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// does I-block a meet I-block b symmetrically (b's bodies travelling)?  The schedule of force_sym_kernel.
+__device__ __forceinline__ bool sym_meets(uint32_t a, uint32_t b, uint32_t nb, uint32_t half)
+{
+    const uint32_t d = b >= a ? b - a : b + nb - a, D = (nb - 1u) / 2u;
+    return (d >= 1u && d <= D) || (half && d == half && a < half);
+}
+}  // namespace
+
+// grid = (wgs_per_dest, world)   block = 256
+// Workgroup (x, q): the bodies of rank q this rank produced reactions for.  Per body: the rows of this
+// rank's I-blocks that met the body's block, added in ascending block order, stored as ONE float4 into
+// rank q's receive region (row [this rank]) with a system-scope write-through store -- over xGMI when q
+// is another GPU.  The last workgroup to finish for q (ticket) stores q's arrival flag behind a release.
+__global__ __launch_bounds__(256) void sym_shard_send_kernel(const SymShardArgs p)
+{
+    const uint32_t q = blockIdx.y;
+    if (!((p.send_mask >> q) & 1u)) return;
+    float4 *dst = p.recv_peer[q] + (size_t)p.rank * p.count;
+    for (uint32_t jl = blockIdx.x * 256u + threadIdx.x; jl < p.count; jl += gridDim.x * 256u) {
+        const uint32_t g = q * p.count + jl, b = g / SYM_BLOCK, jb = g >> 6;
+        const float4 *rows = p.brow + (size_t)jb * p.nbl * 64u + (g & 63u);
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+        for (uint32_t la = 0; la < p.nbl; la++) {
+            if (!sym_meets(p.a0 + la, b, p.nb, p.half_d)) continue;
+            const float4 v = rows[(size_t)la * 64u];
+            fx += v.x; fy += v.y; fz += v.z;
+        }
+        const f4v o = {fx, fy, fz, 0.f};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst + jl), "v"(o) : "memory");
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: this workgroup's stores have reached q's memory
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t prev = __hip_atomic_fetch_add(p.ticket + q, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if ((prev + 1u) % gridDim.x == 0u)
+            __hip_atomic_store(p.flags_peer[q] + SYM_FLAG_BASE + p.rank, p.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// grid = count / 256   block = 256
+// One thread per body of this rank: the a-rows of its I-block in ascending part order, then the rows
+// received from the ranks that met it, nearest sender first (this rank, rank - 1, rank - 2, ...: a fixed
+// order, so the replicas stay bit-identical), then mass, kick, damp, drift (hlsl:103-108).  The
+// workgroup first waits (bounded) until every expected sender's arrival flag shows this step.
+__global__ __launch_bounds__(256) void sym_shard_reduce_kernel(const SymShardArgs p)
+{
+    __shared__ uint32_t ok;
+    if (threadIdx.x == 0) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        uint32_t good = 1u;
+        for (uint32_t q = 0; q < p.world && good; q++) {
+            if (!((p.recv_mask >> q) & 1u)) continue;
+            while ((int32_t)(__hip_atomic_load(p.flags_mine + SYM_FLAG_BASE + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - p.step) < 0) {
+                __builtin_amdgcn_s_sleep(8);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
+                    good = 0u;
+                    __hip_atomic_store(p.status, 1u + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        ok = good;
+    }
+    __syncthreads();
+    if (!ok) return;
+    const uint32_t il = blockIdx.x * 256u + threadIdx.x;
+    if (il >= p.count) return;
+    const uint32_t la = il / SYM_BLOCK;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    const float4 *ar = p.arow + (size_t)la * p.parts * SYM_BLOCK + (il - la * SYM_BLOCK);
+    for (uint32_t s = 0; s < p.parts; s++) {
+        const float4 v = ar[(size_t)s * SYM_BLOCK];
+        ax += v.x; ay += v.y; az += v.z;
+    }
+    for (uint32_t k = 0; k < p.world; k++) {
+        const uint32_t q = p.rank >= k ? p.rank - k : p.rank + p.world - k;
+        if (!((p.recv_mask >> q) & 1u)) continue;
+        f4v v;                                             // uncached region, read past this GPU's caches
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p.recv_mine + (size_t)q * p.count + il) : "memory");
+        ax += v.x; ay += v.y; az += v.z;
+    }
+    ax *= p.mass; ay *= p.mass; az *= p.mass;
+    const uint32_t i = p.rank * p.count + il;
+    const float4 pos = p.pos_old[i];
+    const float *v = p.vel_old + 3 * (size_t)i;
+    float vx = v[0], vy = v[1], vz = v[2];
+    vx = __builtin_fmaf(ax, p.dt, vx) * p.damping;
+    vy = __builtin_fmaf(ay, p.dt, vy) * p.damping;
+    vz = __builtin_fmaf(az, p.dt, vz) * p.damping;
+    float4 o;
+    o.x = __builtin_fmaf(vx, p.dt, pos.x);
+    o.y = __builtin_fmaf(vy, p.dt, pos.y);
+    o.z = __builtin_fmaf(vz, p.dt, pos.z);
+    o.w = __builtin_sqrtf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)));
+    p.pos_new[i] = o;
+    float *vo = p.vel_new + 3 * (size_t)i;
+    vo[0] = vx; vo[1] = vy; vo[2] = vz;
+}
+
 hipError_t launch_force_sym(const SymArgs &a, uint32_t waves, hipStream_t st)
 {
-    const dim3 grid(a.parts, a.nb);
+    const dim3 grid(a.parts, a.shard_nbl ? a.shard_nbl : a.nb);
     if (waves == 4) hipLaunchKernelGGL((force_sym_kernel<4>), grid, dim3(256), 0, st, a);
     else if (waves == 8) hipLaunchKernelGGL((force_sym_kernel<8>), grid, dim3(512), 0, st, a);
     else return hipErrorInvalidConfiguration;
+    return hipGetLastError();
+}
+
+hipError_t launch_sym_shard_send(const SymShardArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(sym_shard_send_kernel, dim3(a.wgs_per_dest, a.world), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_sym_shard_reduce(const SymShardArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(sym_shard_reduce_kernel, dim3((a.count + 255u) / 256u), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -103,6 +103,22 @@ def sym_wave_items(meetings: int, parts: int, waves: int):
                 yield s, w, pm0 + waves * q + t, w * seg, seg
 
 
+def sym_shard_masks(nb: int, world: int, rank: int) -> tuple[int, int]:
+    """Gather algorithm 4 (mapn_context.cpp sym_shard_masks): bit q of `send` = this rank produces
+    reactions for bodies of rank q, bit q of `recv` = rank q produces reactions for this rank's bodies;
+    blocks are owned in contiguous runs of nb // world."""
+    nbl = nb // world
+    send = recv = 0
+    for a, b, d, symmetric in sym_meetings(nb):
+        if not symmetric:
+            continue
+        if a // nbl == rank:
+            send |= 1 << (b // nbl)
+        if b // nbl == rank:
+            recv |= 1 << (a // nbl)
+    return send, recv
+
+
 def chunk_tiles(tiles: int, splits: int, chunk: int) -> tuple[int, int]:
     """64-body tiles [t0, t1) of chunk `chunk` of `splits` (mapn_kernels.hip chunk_tiles)."""
     base, rem = divmod(tiles, splits)

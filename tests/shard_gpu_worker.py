@@ -49,17 +49,22 @@ def main():
         c.close()
         dist.destroy_process_group()
         return
-    if mode in ("p2p", "flow"):
+    if mode in ("p2p", "flow", "sym"):
         # the in-library direct exchange: hipIpc-mapped peer buffers + device flags, no caller help;
         # "flow" = the same exchange overlapped inside the force launch (gather algorithm 3)
         c.p2p_setup_torch()
-        c.set_gather_algorithm(3 if mode == "flow" else 2)
+        # "sym" = the symmetric step sharded over the ranks (gather algorithm 4): reactions stored into the
+        # owners' receive regions, positions pulled as in "p2p"
+        c.set_gather_algorithm({"p2p": 2, "flow": 3, "sym": 4}[mode])
         c.set_timeouts(p2p_ms=5000)      # several processes time-slice ONE GPU here: be generous
         num_active = int(sys.argv[8]) if len(sys.argv) > 8 else n
         for _ in range(steps):
             c.Simulate(num_active, c.GetFenceValue())
         c.WaitForGpu()
         assert c.p2p_status() == 0, f"p2p wait timed out: status {c.p2p_status()}"
+        if mode == "sym":
+            want = "force_sym_kernel" if (num_active == n and count % 1024 == 0) else "force_sgpr_kernel"
+            assert c.kernel_stats().kernel_name.decode() == want, c.kernel_stats().kernel_name
         pos, vel = c.download_state()
         other = c.download_buffer(c.buffer_index)[0]
         # every replica must hold the same positions, bit for bit

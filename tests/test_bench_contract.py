@@ -95,3 +95,20 @@ def test_bench_two_ranks_one_gpu_with_the_in_kernel_exchange():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["exchange"] == "p2p+inkernel"
     assert d["config"]["replicas_bit_identical_after_run"] is True and d["config"]["p2p_failure"] is None
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_one_gpu_with_the_sharded_symmetric_step():
+    """The N > 1 flow with gather algorithm 4: the symmetric step sharded over the ranks, verified inside
+    bench.py against the one-sided sharded step before it is used."""
+    port = 29990 + (os.getpid() % 90)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "30", "--warmup", "3", "--gather", "sym", "--dist-backend", "gloo",
+                        "--same-device", "--prewarm-ms", "20", "--bodies", "16384"], capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["exchange"] == "p2p+symmetric" and d["config"]["kernel"] == "force_sym_kernel"
+    assert d["config"]["replicas_bit_identical_after_run"] is True and d["config"]["p2p_failure"] is None
+    assert d["config"]["launches_per_step"] == 3 and set(d["config"]["exchange_trial_us_per_step"]) == {"p2p", "p2p+symmetric"}

@@ -79,3 +79,19 @@ def test_wave_deal_covers_every_step_of_every_meeting_once_and_is_balanced(meeti
         assert len(per_wave) == 1
     per_part = sorted({steps.get((s, 0), 0) for s in range(parts)})
     assert per_part[-1] - per_part[0] <= 64 // waves      # parts differ by at most one meeting = 64 / waves steps per wave
+
+
+@pytest.mark.parametrize("nb,world", [(8, 2), (8, 4), (8, 8), (9, 3), (6, 2), (16, 8), (64, 8), (64, 2), (1024, 8)])
+def test_sharded_symmetric_step_sender_and_receiver_sets_agree(nb, world):
+    """Gather algorithm 4: rank r stores a reaction row into rank q's receive region exactly when q
+    waits for one from r, and together the rows cover every symmetric meeting of the job."""
+    masks = [shard.sym_shard_masks(nb, world, r) for r in range(world)]
+    for r in range(world):
+        for q in range(world):
+            assert bool(masks[r][0] >> q & 1) == bool(masks[q][1] >> r & 1)
+    nbl = nb // world
+    need = {(a // nbl, b // nbl) for a, b, d, sym in shard.sym_meetings(nb) if sym}
+    have = {(r, q) for r in range(world) for q in range(world) if masks[r][0] >> q & 1}
+    assert need == have
+    if world == 8 and nb >= 16:
+        assert all(bin(m[0]).count("1") == 5 for m in masks)      # this rank and the four ahead of it on the ring

@@ -142,6 +142,7 @@ struct mapn_ctx {
     uint32_t *sym_shard_ticket = nullptr;     // gather algorithm 4: the send kernel's per-destination tickets
     uint32_t sym_shard_step = 0;
     uint32_t sym_send_mask = 0, sym_recv_mask = 0;
+    bool p2p_loopback = false;                // MAPN_P2P_LOOPBACK=1 (timing on a 1-GPU box only): every peer maps to this rank
     uint32_t *flow_block = nullptr;           // ordinary device memory: [0..15] arrived[q], [16] tiles_done (flow mode)
 
     // graph replay
@@ -428,7 +429,7 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     h.rank = rank; h.world = world; h.count = c->count;
     h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = parts;
     h.send_mask = c->sym_send_mask; h.recv_mask = c->sym_recv_mask;
-    h.wgs_per_dest = std::max(1u, std::min(32u, c->count / 1024u));
+    h.wgs_per_dest = std::max(1u, std::min(64u, (c->count + 255u) / 256u));   // one body per thread up to 16 384 bodies
     h.step = ++c->sym_shard_step;
     h.timeout_ticks = c->p2p_timeout_ticks;
     h.mass = a.mass; h.dt = a.dt; h.damping = a.damping;
@@ -742,6 +743,7 @@ int enqueue_flow_pull(mapn_ctx *c)
 int enqueue_gather(mapn_ctx *c)
 {
     if (c->p2p_ready && c->gather_algo == 3) return enqueue_flow_pull(c);
+    if (c->p2p_ready && c->p2p_loopback) return MAPN_OK;   // no peers to pull from
     if (c->p2p_ready && (c->gather_algo == 2 || c->gather_algo == 4)) return enqueue_p2p(c);   // 4: positions travel as in 2
     if (!c->comm) return MAPN_OK;
     const uint32_t w = c->buffer_index;
@@ -939,7 +941,7 @@ int mapn_destroy(mapn_ctx *c)
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm) mapn::comm_destroy(c->comm);
     for (int q = 0; q < mapn::P2P_MAX_RANKS; q++) {
-        if (q == c->cfg.rank) continue;
+        if (q == c->cfg.rank || c->p2p_loopback) continue;
         if (c->p2p_peer_heap[q]) (void)hipIpcCloseMemHandle(c->p2p_peer_heap[q]);
         if (c->p2p_peer_flags[q]) (void)hipIpcCloseMemHandle(c->p2p_peer_flags[q]);
     }
@@ -1491,7 +1493,14 @@ int mapn_p2p_import(mapn_ctx *c, const void *blobs, int count)
     if (!c->p2p_flags) return fail(MAPN_ERR_STATE, "p2p_import: call mapn_p2p_export first");
     if (c->p2p_ready) return MAPN_OK;
     HIP_TRY(hipSetDevice(c->device));
+    // MAPN_P2P_LOOPBACK=1 (timing experiments on a 1-GPU box only, like MAPN_COMM_LOOPBACK): rank 0 of a P-way
+    // job maps every peer to ITSELF, so a step runs its real kernels at the true shard size (force, send with
+    // all its destinations, reduce); the position pull is skipped and only this rank's own row is waited for --
+    // the other slices are never refreshed, so results are not a simulation.
+    const char *loop = getenv("MAPN_P2P_LOOPBACK");
+    c->p2p_loopback = loop && loop[0] == '1' && c->cfg.rank == 0;
     for (int q = 0; q < count; q++) {
+        if (c->p2p_loopback) { c->p2p_peer_heap[q] = c->pos_heap; c->p2p_peer_flags[q] = c->p2p_flags; continue; }
         P2PBlob b;
         memcpy(&b, static_cast<const char *>(blobs) + (size_t)q * MAPN_P2P_BLOB_BYTES, sizeof b);
         if (memcmp(b.magic, "MAPNP2P1", 8) != 0 || (int)b.rank != q || (int)b.world != count || b.n != c->n ||
@@ -1511,6 +1520,7 @@ int mapn_p2p_import(mapn_ctx *c, const void *blobs, int count)
     HIP_TRY(hipMemset(c->sym_shard_ticket, 0, 256));
     if (c->count % mapn::SYM_BLOCK == 0 && c->count * (uint32_t)count == c->n)
         sym_shard_masks(c->n / mapn::SYM_BLOCK, (uint32_t)count, (uint32_t)c->cfg.rank, c->sym_send_mask, c->sym_recv_mask);
+    if (c->p2p_loopback) c->sym_recv_mask = 1u << c->cfg.rank;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->p2p_flag_table), sizeof(uint32_t *) * mapn::P2P_MAX_RANKS));
     HIP_TRY(hipMemcpy(c->p2p_flag_table, c->p2p_peer_flags, sizeof(uint32_t *) * mapn::P2P_MAX_RANKS, hipMemcpyHostToDevice));
     c->p2p_ready = true;

@@ -330,31 +330,44 @@ __global__ __launch_bounds__(256) void sym_shard_send_kernel(const SymShardArgs 
         const uint32_t g = q * p.count + jl, b = g / SYM_BLOCK, jb = g >> 6;
         const float4 *rows = p.brow + (size_t)jb * p.nbl * 64u + (g & 63u);
         float fx = 0.f, fy = 0.f, fz = 0.f;
-        for (uint32_t la = 0; la < p.nbl; la++) {
-            if (!sym_meets(p.a0 + la, b, p.nb, p.half_d)) continue;
-            const float4 v = rows[(size_t)la * 64u];
-            fx += v.x; fy += v.y; fz += v.z;
+        for (uint32_t la = 0; la < p.nbl; la += 8u) {      // eight loads in flight, added in ascending block order
+            float4 v[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) {
+                const bool met = la + u < p.nbl && sym_meets(p.a0 + la + u, b, p.nb, p.half_d);
+                v[u] = met ? rows[(size_t)(la + u) * 64u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) { fx += v[u].x; fy += v[u].y; fz += v[u].z; }
         }
         const f4v o = {fx, fy, fz, 0.f};
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst + jl), "v"(o) : "memory");
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: this workgroup's stores have reached q's memory
+    // the stores are write-through at system scope: once acknowledged (vmcnt(0)) they are in q's memory -- no cache
+    // write-back is owed (a release fence here would write back the whole L2, full of this step's rows: measured
+    // 10+ us per step), so the ticket and the flag can be relaxed, ordered by the barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t prev = __hip_atomic_fetch_add(p.ticket + q, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t prev = __hip_atomic_fetch_add(p.ticket + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((prev + 1u) % gridDim.x == 0u)
-            __hip_atomic_store(p.flags_peer[q] + SYM_FLAG_BASE + p.rank, p.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(p.flags_peer[q] + SYM_FLAG_BASE + p.rank, p.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-// grid = count / 256   block = 256
-// One thread per body of this rank: the a-rows of its I-block in ascending part order, then the rows
-// received from the ranks that met it, nearest sender first (this rank, rank - 1, rank - 2, ...: a fixed
-// order, so the replicas stay bit-identical), then mass, kick, damp, drift (hlsl:103-108).  The
-// workgroup first waits (bounded) until every expected sender's arrival flag shows this step.
+// grid = count / (256 / G)   block = 256: G threads per body (a rank's slice is small -- 8192 bodies at 65 536 / 8 --
+// so one thread per body would leave the rows' loads latency-bound)
+// Thread (body, g) adds the a-rows of parts [g P/G, (g+1) P/G) in ascending order; thread (body, 0) then adds the G
+// sums in ascending g, the rows received from the ranks that met the body, nearest sender first (this rank,
+// rank - 1, rank - 2, ...), then mass, kick, damp, drift (hlsl:103-108) -- a fixed order throughout, so the
+// replicas stay bit-identical.  The workgroup first waits (bounded) until every expected sender's arrival
+// flag shows this step.
+template <int G>
 __global__ __launch_bounds__(256) void sym_shard_reduce_kernel(const SymShardArgs p)
 {
+    constexpr uint32_t B = 256u / G;                       // bodies per workgroup
     __shared__ uint32_t ok;
+    __shared__ float part[G][3][B];
     if (threadIdx.x == 0) {
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
         uint32_t good = 1u;
@@ -372,17 +385,33 @@ __global__ __launch_bounds__(256) void sym_shard_reduce_kernel(const SymShardArg
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         ok = good;
     }
-    __syncthreads();
-    if (!ok) return;
-    const uint32_t il = blockIdx.x * 256u + threadIdx.x;
-    if (il >= p.count) return;
-    const uint32_t la = il / SYM_BLOCK;
+    const uint32_t bl = threadIdx.x % B, g = threadIdx.x / B;
+    const uint32_t il = blockIdx.x * B + bl;
+    const bool live = il < p.count;
+    const uint32_t la = live ? il / SYM_BLOCK : 0u;
     float ax = 0.f, ay = 0.f, az = 0.f;
-    const float4 *ar = p.arow + (size_t)la * p.parts * SYM_BLOCK + (il - la * SYM_BLOCK);
-    for (uint32_t s = 0; s < p.parts; s++) {
-        const float4 v = ar[(size_t)s * SYM_BLOCK];
-        ax += v.x; ay += v.y; az += v.z;
+    if (live) {                                            // the a-rows are this rank's own work: no need to wait for anybody
+        const float4 *ar = p.arow + (size_t)la * p.parts * SYM_BLOCK + (il - la * SYM_BLOCK);
+        const uint32_t s0 = (uint32_t)(((uint64_t)p.parts * g) / G), s1 = (uint32_t)(((uint64_t)p.parts * (g + 1u)) / G);
+        uint32_t s = s0;
+        for (; s + 8u <= s1; s += 8u) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = ar[(size_t)(s + u) * SYM_BLOCK];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { ax += v[u].x; ay += v[u].y; az += v[u].z; }
+        }
+        for (; s < s1; s++) {
+            const float4 v = ar[(size_t)s * SYM_BLOCK];
+            ax += v.x; ay += v.y; az += v.z;
+        }
     }
+    part[g][0][bl] = ax; part[g][1][bl] = ay; part[g][2][bl] = az;
+    __syncthreads();
+    if (!ok || g != 0u || !live) return;
+    ax = ay = az = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < G; gg++) { ax += part[gg][0][bl]; ay += part[gg][1][bl]; az += part[gg][2][bl]; }
     for (uint32_t k = 0; k < p.world; k++) {
         const uint32_t q = p.rank >= k ? p.rank - k : p.rank + p.world - k;
         if (!((p.recv_mask >> q) & 1u)) continue;
@@ -425,7 +454,10 @@ hipError_t launch_sym_shard_send(const SymShardArgs &a, hipStream_t st)
 
 hipError_t launch_sym_shard_reduce(const SymShardArgs &a, hipStream_t st)
 {
-    hipLaunchKernelGGL(sym_shard_reduce_kernel, dim3((a.count + 255u) / 256u), dim3(256), 0, st, a);
+    // enough threads to keep the rows' loads in flight: 8 per body up to 16 384 bodies, 4 up to 65 536, else 1
+    if (a.count <= 16384u) hipLaunchKernelGGL((sym_shard_reduce_kernel<8>), dim3((a.count + 31u) / 32u), dim3(256), 0, st, a);
+    else if (a.count <= 65536u) hipLaunchKernelGGL((sym_shard_reduce_kernel<4>), dim3((a.count + 63u) / 64u), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((sym_shard_reduce_kernel<1>), dim3((a.count + 255u) / 256u), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

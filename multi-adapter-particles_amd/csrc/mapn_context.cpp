@@ -394,6 +394,8 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     // unsharded launch, never fewer than one whole meeting per wave
     const uint32_t waves = 4, meetings = mapn::SYM_JPI * (1u + (a.nb - 1u) / 2u);
     uint32_t parts = std::max(32u, (512u + a.shard_nbl - 1u) / a.shard_nbl);
+    // (65 536 / 8: 64 parts = 512 workgroups = one resident round, 8 or 9 meetings each, 98.7 us.  66 parts would
+    //  give every workgroup 8 meetings but 528 workgroups -- the 16 that do not fit cost a second round: 123 us.)
     const char *e = getenv("MAPN_SYM_SHARD_PARTS");
     if (e && atoi(e) > 0) parts = (uint32_t)atoi(e);
     parts = std::min(parts, std::max(1u, meetings / waves));

@@ -134,3 +134,23 @@ def test_symmetric_sharded_step_falls_back_bit_identically(tmp_path):
         b = _run_ranks(d4, world, n, 4, "sym", str(active))
         for k in ("pos", "vel", "other"):
             np.testing.assert_array_equal(a[k], b[k])
+
+
+def test_config3_sharded_symmetric_step_with_eight_processes(tmp_path, oracle):
+    """configs[3] (1 048 576 bodies sharded over 8 ranks) through gather algorithm 4, all eight ranks real
+    processes on ONE GPU: one step of the whole job (every unordered pair once: ~160 ms of the GPU), then
+    two 4096-body subsets -- one inside a rank's slice, one straddling a rank boundary -- against the oracle.
+    w = |a| is compared with the fp64-accumulated oracle (the reference order's running fp32 sum over 1 Mi
+    terms is itself ~2e-4 off, see test_config3_one_rank_share_of_the_8_gpu_1mi_body_job)."""
+    from oracle import Params, SumSpec, SUM_FP64_ACC
+    n, world = 1048576, 8
+    got = _run_ranks(tmp_path, world, n, 1, "sym", str(n))
+    pos0, vel0 = oracle.initial_state(n, seed=1)
+    mass = 70000.0 / n
+    for sub in (5 * (n // world) + 37 * 64, 3 * (n // world) - 2048):
+        rp, rv = oracle.step_slice(pos0, vel0, sub, 4096, params=Params(mass=mass))
+        rp_acc, _ = oracle.step_slice(pos0, vel0, sub, 4096, params=Params(mass=mass), sum_spec=SumSpec(SUM_FP64_ACC))
+        p, v = got["pos"][sub:sub + 4096], got["vel"][sub:sub + 4096]
+        assert np.linalg.norm(p[:, :3].astype(np.float64) - rp[:, :3], axis=1).max() / 400.0 < 1e-6
+        assert np.linalg.norm(v.astype(np.float64) - rv, axis=1).max() / 15.0 < 2e-5
+        assert np.abs(p[:, 3] - rp_acc[:, 3]).max() / rp_acc[:, 3].max() < 2e-5

@@ -414,6 +414,17 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
         c->sym_brow_bytes = bb;
     }
     a.arow = c->sym_arow; a.brow = c->sym_brow;
+    if (c->stamp_next) {
+        const size_t nw = (size_t)a.shard_nbl * parts * waves;
+        if (nw > c->stamp_waves) {
+            if (c->stamp_buf) HIP_TRY(hipFree(c->stamp_buf));
+            c->stamp_buf = nullptr; c->stamp_waves = 0;
+            HIP_TRY(hipMalloc(&c->stamp_buf, nw * 16));
+            c->stamp_waves = nw;
+        }
+        HIP_TRY(hipMemsetAsync(c->stamp_buf, 0, c->stamp_waves * 16, c->compute));
+        a.stamps = c->stamp_buf;
+    }
     HIP_TRY(mapn::launch_force_sym(a, waves, c->compute));
     if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
 
@@ -1620,7 +1631,7 @@ int mapn_measure_clock(mapn_ctx *c, int steps, mapn_clock_info *out)
     if (!c->stamp_buf || (c->last_plan.kind != mapn::KERNEL_SGPR && c->last_plan.kind != mapn::KERNEL_SYM))
         return fail(MAPN_ERR_STATE, "measure_clock: the stamped diagnostic exists for the scalar-cache and the symmetric force kernels only");
     const size_t waves = c->last_plan.kind == mapn::KERNEL_SYM
-        ? (size_t)((c->n + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK) * c->sym_parts * c->sym_waves
+        ? (size_t)((c->last_i_count + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK) * c->sym_parts * c->sym_waves   // (sharded: this rank's blocks)
         : (size_t)((c->last_i_count + 64 * c->last_plan.k - 1) / (64 * c->last_plan.k)) * c->last_plan.sb * c->last_plan.waves;
     std::vector<unsigned long long> h(2 * waves);
     HIP_TRY(hipMemcpy(h.data(), c->stamp_buf, waves * 16, hipMemcpyDeviceToHost));

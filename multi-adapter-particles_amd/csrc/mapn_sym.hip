@@ -13,14 +13,14 @@
 //     (8 packed evaluations = 32 interactions per lane) the travelling body and its reaction move one
 //     lane on (9 ds_bpermute_b32: through the LDS crossbar), so after 64 steps every lane has met
 //     every body of the J-block and each body is back home with its complete reaction.
-// Measured (tools/ubench.hip, profiles/r02_ubench.txt): a cross-lane move costs ~12 SIMD cycles per
-// register whatever the mechanism (ds_bpermute_b32, ds_swizzle_b32, v_mov_b32_dpp), so the loop gets
-// faster the more bodies i a lane owns per move: 4 bodies 5.3e12 interactions/s, 8 bodies 7.4e12 in
-// the microbenchmark (one-sided pair term: 4.9e12); in the kernel 8 -> 16 bodies per lane gained
-// another 3-5 % although only two waves per SIMD remain (re-measured with the final loop: 12 bodies at
-// three waves per SIMD -8 %, 8 bodies at four waves -5 %, and the chip holds a lower clock under both:
-// profiles/r02_sym_loop_variants.txt).  LDS float atomics for the reaction
-// (ds_add_f32, ~195 cycles per wave-instruction): 1.1e12.
+// Measured (tools/ubench.hip, profiles/r02_ubench.txt, profiles/r02_sym_loop_variants.txt): the moves go through
+// the LDS pipe beside the VALU (ds_bpermute_b32; a v_mov_b32_dpp would take VALU cycles), so what a step costs is
+// its 131 VALU instructions; the loop gets faster the more bodies i a lane owns per move: 4 bodies 5.3e12
+// interactions/s, 8 bodies 7.4e12 in the microbenchmark (one-sided pair term: 4.9e12); in the kernel 16 bodies
+// per lane at two waves per SIMD beat 12 at three (-8 %) and 8 at four (-5 %: fewer cycles, but the chip holds a
+// lower clock under the denser variants).  While two waves are resident the SIMD's VALU is busy all the time
+// (profiles/r02_sym_issue_counters.txt).  LDS float atomics for the reaction (ds_add_f32, ~195 cycles per
+// wave-instruction): 1.1e12.
 //
 // Coverage of the N^2 ordered pairs (N padded to a multiple of 1024 with stand-in bodies that exert no
 // force): I-block a meets, symmetrically, the
@@ -29,6 +29,11 @@
 // blocks is met exactly once; every body collects its force as: rows of its own I-block (role i)
 // + one row per meeting of its J-block (role j), all written to scratch and summed in a FIXED
 // order by sym_reduce_integrate_kernel -- no float atomics, bit-reproducible.
+//
+// Sharded over ranks (gather algorithm 4, bottom of this file): a rank launches the kernel for ITS I-blocks
+// only (a0, shard_nbl), the reaction rows are kept per (J-block, local I-block), sym_shard_send_kernel adds
+// them per destination rank and stores them into the owner's receive region, sym_shard_reduce_kernel
+// integrates the rank's bodies from its own rows plus the rows received.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -350,8 +355,10 @@ __global__ __launch_bounds__(256) void sym_shard_send_kernel(const SymShardArgs 
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t prev = __hip_atomic_fetch_add(p.ticket + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((prev + 1u) % gridDim.x == 0u)
+        if (prev + 1u == gridDim.x) {
+            __hip_atomic_store(p.ticket + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
             __hip_atomic_store(p.flags_peer[q] + SYM_FLAG_BASE + p.rank, p.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

@@ -22,6 +22,21 @@ def test_bench_fails_loudly_without_a_gpu():
     assert not any(line.startswith("{") for line in r.stdout.splitlines())
 
 
+def test_committed_pmc_summaries_belong_to_the_current_kernel_sources():
+    """bench.py attaches `roofline.traffic` only while the committed PMC summary was measured on the kernel
+    sources being run (their sha is stored in it): a kernel edit without a fresh `--pmc` pass must show up
+    here, on the CPU, not as a silent `traffic: null` at round end."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_sha", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    sha = bench.kernel_source_sha16()
+    for tag, kernel in (("r02_sym", "force_sym_kernel"), ("r02_onesided", "force_sgpr_kernel")):
+        d = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json")))
+        assert d["_kernel_source_sha16"] == sha, f"profiles/{tag}_pmc_summary.json is stale: re-run tools/r02_run18.sh"
+    traffic, src = bench.pmc_traffic("force_sym_kernel", 65536, 1)
+    assert traffic and 5e7 < traffic < 2e8 and src.endswith("r02_sym_pmc_summary.json")
+
+
 @pytest.mark.gpu
 def test_bench_json_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5", "--cpu-seconds", "1"],

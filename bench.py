@@ -407,11 +407,19 @@ def main():
         except mapn.MapnError as e:
             print(f"[bench] clock measurement unavailable: {e}", file=sys.stderr, flush=True)
     consistent = None
+    sym_dev_after = None
     if dist is not None and world > 1 and gather_algo != "n/a":
         consistent = replicas_consistent() and (gather_algo != "p2p" or c.p2p_status() == 0)
+        if consistent and gather_algo == "p2p+symmetric":
+            # once more, after the timed run: the sharded symmetric step against the one-sided one
+            dev_after = symmetric_deviation()
+            worst = torch.tensor([dev_after], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+            sym_dev_after = float(worst.item())
+            consistent = sym_dev_after < 1e-5 and c.p2p_status() == 0
         if not consistent and rank == 0:
-            print("[bench] WARNING: position replicas differ across ranks after the run -- the exchange misbehaved; "
-                  "this result is INVALID", file=sys.stderr, flush=True)
+            print("[bench] WARNING: position replicas differ across ranks after the run (or the sharded symmetric step "
+                  "failed its check) -- the exchange misbehaved; this result is INVALID", file=sys.stderr, flush=True)
     if rank == 0:
         pairs_per_step = float(n) * float(n) if a.mode == "all_pairs" else float(n)
         value = pairs_per_step * a.steps / elapsed
@@ -435,7 +443,7 @@ def main():
                        "grid": [st.grid_x, st.grid_y], "block": st.block_x, "fused_integrator": bool(st.fused),
                        "epilogue": {0: "partial rows + reduce_integrate launch", 1: "fused in the workgroup", 2: "last-arriver ticket (one launch per step)", 3: "symmetric kernel: force rows + sym_reduce_integrate launch"}.get(st.epilogue, "?"),
                        "launches_per_step": int(st.force_launches_per_step) + (0 if st.fused else 1), "timer_interval": timer_interval,
-                       "p2p_failure": p2p_failure},
+                       "p2p_failure": p2p_failure, "sharded_symmetric_deviation_after_run": sym_dev_after},
         }
         if a.mode == "all_pairs":
             peak = info.peak_fp32_flops / 1e12

@@ -442,15 +442,13 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     h.rank = rank; h.world = world; h.count = c->count;
     h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = parts;
     h.send_mask = c->sym_send_mask; h.recv_mask = c->sym_recv_mask;
-    h.wgs_per_dest = std::max(1u, std::min(64u, (c->count + 255u) / 256u));   // one body per thread up to 16 384 bodies
     h.step = ++c->sym_shard_step;
     h.timeout_ticks = c->p2p_timeout_ticks;
     h.mass = a.mass; h.dt = a.dt; h.damping = a.damping;
-    HIP_TRY(mapn::launch_sym_shard_send(h, c->compute));
-    HIP_TRY(mapn::launch_sym_shard_reduce(h, c->compute));
+    HIP_TRY(mapn::launch_sym_shard_exchange(h, c->compute));
     mapn::ForcePlan p{};
     p.kind = mapn::KERNEL_SYM; p.k = 2 * mapn::SYM_K2; p.waves = waves; p.sb = parts; p.nseg = 1; p.epi = mapn::EPI_ROWS;
-    c->last_plan = p; c->last_i_count = c->count; c->last_launches = 3;
+    c->last_plan = p; c->last_i_count = c->count; c->last_launches = 2;
     c->sym_parts = parts; c->sym_waves = waves;
     return MAPN_OK;
 }

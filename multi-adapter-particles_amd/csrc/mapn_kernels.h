@@ -82,9 +82,9 @@ hipError_t launch_sym_reduce(const SymArgs &a, hipStream_t st);
 // The symmetric step SHARDED over ranks (gather algorithm 4): a rank runs the meetings of its own I-blocks
 // (force_sym_kernel with a0 / shard_nbl), adds the reactions it produced for every rank's bodies over its
 // I-blocks in ascending order and stores ONE row per destination rank straight into that rank's receive
-// region (sym_shard_send_kernel: remote stores through the hipIpc mapping, then the flag), and integrates
-// its own bodies from its a-rows plus the rows received (sym_shard_reduce_kernel: waits for the senders'
-// flags, bounded).
+// region (remote stores through the hipIpc mapping, then the flag), waits (bounded) for the flags of the
+// ranks that owe it rows and integrates its own bodies from its a-rows plus the rows received
+// (sym_shard_exchange_kernel: one launch).
 enum { P2P_MAX_RANKS = 16 };          // ranks of a direct peer-to-peer job (one process per GPU, buffers mapped through hipIpc)
 enum { SYM_FLAG_BASE = 16,            // reaction-arrival counters follow the P2P_MAX_RANKS publication counters
        SYM_RECV_OFFSET = 4096 };      // byte offset of the receive region [world][count] float4 inside the flags allocation
@@ -99,18 +99,16 @@ struct SymShardArgs {
     uint32_t     *flags_peer[P2P_MAX_RANKS];  // rank q's flag array as mapped here
     const float4 *recv_mine;
     uint32_t     *flags_mine;
-    uint32_t     *ticket;                     // [world] workgroups of the send kernel that have finished, per destination
+    uint32_t     *ticket;                     // workgroups of the exchange kernel whose sends are acknowledged
     uint32_t     *status;                     // host-visible word: non-zero = a wait timed out
     uint32_t      rank, world, count;         // count = bodies per rank (a multiple of SYM_BLOCK)
     uint32_t      nb, nbl, a0, half_d, parts;
     uint32_t      send_mask, recv_mask;       // bit q: this rank produces reactions for / receives reactions from rank q
-    uint32_t      wgs_per_dest;
     uint32_t      step;                       // monotonically increasing (>= 1)
     uint64_t      timeout_ticks;
     float         mass, dt, damping;
 };
-hipError_t launch_sym_shard_send(const SymShardArgs &a, hipStream_t st);
-hipError_t launch_sym_shard_reduce(const SymShardArgs &a, hipStream_t st);
+hipError_t launch_sym_shard_exchange(const SymShardArgs &a, hipStream_t st);
 
 bool force_plan_supported(const ForcePlan &plan);
 hipError_t launch_force(const ForcePlan &plan, const StepArgs &a, hipStream_t st);

@@ -31,11 +31,13 @@
 // order by sym_reduce_integrate_kernel -- no float atomics, bit-reproducible.
 //
 // Sharded over ranks (gather algorithm 4, bottom of this file): a rank launches the kernel for ITS I-blocks
-// only (a0, shard_nbl), the reaction rows are kept per (J-block, local I-block), sym_shard_send_kernel adds
-// them per destination rank and stores them into the owner's receive region, sym_shard_reduce_kernel
-// integrates the rank's bodies from its own rows plus the rows received.
+// only (a0, shard_nbl), the reaction rows are kept per (J-block, local I-block); sym_shard_exchange_kernel adds
+// them per destination rank, stores them into the owner's receive region, waits for the rows owed to this rank
+// and integrates its bodies from its own rows plus the rows received.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <algorithm>
 
 #include "mapn_kernels.h"
 
@@ -321,19 +323,33 @@ __device__ __forceinline__ bool sym_meets(uint32_t a, uint32_t b, uint32_t nb, u
 }
 }  // namespace
 
-// grid = (wgs_per_dest, world)   block = 256
-// Workgroup (x, q): the bodies of rank q this rank produced reactions for.  Per body: the rows of this
-// rank's I-blocks that met the body's block, added in ascending block order, stored as ONE float4 into
-// rank q's receive region (row [this rank]) with a system-scope write-through store -- over xGMI when q
-// is another GPU.  The last workgroup to finish for q (ticket) stores q's arrival flag behind a release.
-__global__ __launch_bounds__(256) void sym_shard_send_kernel(const SymShardArgs p)
+// grid <= 1024 workgroups (all co-resident: they wait for each other through the ticket)   block = 256
+// One launch does both halves of the reaction exchange.
+//  (1) SEND: for every rank q this rank produced reactions for and every body of q: the rows of this rank's
+//      I-blocks that met the body's block, added in ascending block order, stored as ONE float4 into rank q's
+//      receive region (row [this rank]) with a system-scope write-through store -- over xGMI when q is another
+//      GPU.  Once acknowledged (vmcnt(0)) the stores are in q's memory: no cache write-back is owed (a release
+//      fence here would write back the whole L2, full of this step's rows: measured 10+ us per step).  The
+//      last workgroup through the ticket stores the arrival flags.
+//  (2) REDUCE: lanes 0 .. world-1 of the first wave wait (bounded) for the arrival flags of the ranks that owe
+//      this rank rows; then G threads per body (a rank's slice is small -- 8192 bodies at 65 536 / 8 -- so one
+//      thread per body would leave the rows' loads latency-bound): thread (body, g) adds the a-rows of parts
+//      [g P/G, (g+1) P/G) in ascending order, thread (body, 0) adds the G sums in ascending g, then the rows
+//      received, nearest sender first (this rank, rank - 1, rank - 2, ...), then mass, kick, damp, drift
+//      (hlsl:103-108) -- a fixed order throughout, so the replicas stay bit-identical.
+template <int G>
+__global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardArgs p)
 {
-    const uint32_t q = blockIdx.y;
-    if (!((p.send_mask >> q) & 1u)) return;
-    float4 *dst = p.recv_peer[q] + (size_t)p.rank * p.count;
-    for (uint32_t jl = blockIdx.x * 256u + threadIdx.x; jl < p.count; jl += gridDim.x * 256u) {
-        const uint32_t g = q * p.count + jl, b = g / SYM_BLOCK, jb = g >> 6;
-        const float4 *rows = p.brow + (size_t)jb * p.nbl * 64u + (g & 63u);
+    constexpr uint32_t B = 256u / G;                       // bodies per workgroup and pass
+    __shared__ uint32_t ok;
+    __shared__ float part[G][3][B];
+
+    const uint32_t total = p.world * p.count;
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+        const uint32_t q = t / p.count, jl = t - q * p.count;
+        if (!((p.send_mask >> q) & 1u)) continue;
+        const uint32_t b = t / SYM_BLOCK, jb = t >> 6;     // t is the body's index in the whole job
+        const float4 *rows = p.brow + (size_t)jb * p.nbl * 64u + (t & 63u);
         float fx = 0.f, fy = 0.f, fz = 0.f;
         for (uint32_t la = 0; la < p.nbl; la += 8u) {      // eight loads in flight, added in ascending block order
             float4 v[8];
@@ -346,42 +362,27 @@ __global__ __launch_bounds__(256) void sym_shard_send_kernel(const SymShardArgs 
             for (uint32_t u = 0; u < 8u; u++) { fx += v[u].x; fy += v[u].y; fz += v[u].z; }
         }
         const f4v o = {fx, fy, fz, 0.f};
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst + jl), "v"(o) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p.recv_peer[q] + (size_t)p.rank * p.count + jl), "v"(o) : "memory");
     }
-    // the stores are write-through at system scope: once acknowledged (vmcnt(0)) they are in q's memory -- no cache
-    // write-back is owed (a release fence here would write back the whole L2, full of this step's rows: measured
-    // 10+ us per step), so the ticket and the flag can be relaxed, ordered by the barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t prev = __hip_atomic_fetch_add(p.ticket + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev + 1u == gridDim.x) {
-            __hip_atomic_store(p.ticket + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
-            __hip_atomic_store(p.flags_peer[q] + SYM_FLAG_BASE + p.rank, p.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x < 64u) {
+        if (threadIdx.x == 0) {
+            const uint32_t prev = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev + 1u == gridDim.x) {
+                __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+                for (uint32_t q = 0; q < p.world; q++)
+                    if ((p.send_mask >> q) & 1u)
+                        __hip_atomic_store(p.flags_peer[q] + SYM_FLAG_BASE + p.rank, p.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
-    }
-}
-
-// grid = count / (256 / G)   block = 256: G threads per body (a rank's slice is small -- 8192 bodies at 65 536 / 8 --
-// so one thread per body would leave the rows' loads latency-bound)
-// Thread (body, g) adds the a-rows of parts [g P/G, (g+1) P/G) in ascending order; thread (body, 0) then adds the G
-// sums in ascending g, the rows received from the ranks that met the body, nearest sender first (this rank,
-// rank - 1, rank - 2, ...), then mass, kick, damp, drift (hlsl:103-108) -- a fixed order throughout, so the
-// replicas stay bit-identical.  The workgroup first waits (bounded) until every expected sender's arrival
-// flag shows this step.
-template <int G>
-__global__ __launch_bounds__(256) void sym_shard_reduce_kernel(const SymShardArgs p)
-{
-    constexpr uint32_t B = 256u / G;                       // bodies per workgroup
-    __shared__ uint32_t ok;
-    __shared__ float part[G][3][B];
-    if (threadIdx.x == 0) {
-        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        const uint32_t q = threadIdx.x;
+        const bool need = q < p.world && ((p.recv_mask >> q) & 1u);
         uint32_t good = 1u;
-        for (uint32_t q = 0; q < p.world && good; q++) {
-            if (!((p.recv_mask >> q) & 1u)) continue;
+        if (need) {
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
             while ((int32_t)(__hip_atomic_load(p.flags_mine + SYM_FLAG_BASE + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - p.step) < 0) {
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(4);
                 if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
                     good = 0u;
                     __hip_atomic_store(p.status, 1u + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -389,59 +390,75 @@ __global__ __launch_bounds__(256) void sym_shard_reduce_kernel(const SymShardArg
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-        ok = good;
+        const uint32_t all_good = __builtin_amdgcn_ballot_w64(good == 0u) == 0ull ? 1u : 0u;
+        if (threadIdx.x == 0) ok = all_good;
     }
-    const uint32_t bl = threadIdx.x % B, g = threadIdx.x / B;
-    const uint32_t il = blockIdx.x * B + bl;
-    const bool live = il < p.count;
-    const uint32_t la = live ? il / SYM_BLOCK : 0u;
-    float ax = 0.f, ay = 0.f, az = 0.f;
-    if (live) {                                            // the a-rows are this rank's own work: no need to wait for anybody
-        const float4 *ar = p.arow + (size_t)la * p.parts * SYM_BLOCK + (il - la * SYM_BLOCK);
-        const uint32_t s0 = (uint32_t)(((uint64_t)p.parts * g) / G), s1 = (uint32_t)(((uint64_t)p.parts * (g + 1u)) / G);
-        uint32_t s = s0;
-        for (; s + 8u <= s1; s += 8u) {
-            float4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = ar[(size_t)(s + u) * SYM_BLOCK];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { ax += v[u].x; ay += v[u].y; az += v[u].z; }
-        }
-        for (; s < s1; s++) {
-            const float4 v = ar[(size_t)s * SYM_BLOCK];
-            ax += v.x; ay += v.y; az += v.z;
-        }
-    }
-    part[g][0][bl] = ax; part[g][1][bl] = ay; part[g][2][bl] = az;
     __syncthreads();
-    if (!ok || g != 0u || !live) return;
-    ax = ay = az = 0.f;
+    if (!ok) return;
+
+    const uint32_t bl = threadIdx.x % B, g = threadIdx.x / B;
+    for (uint32_t base = blockIdx.x * B; base < p.count; base += gridDim.x * B) {
+        const uint32_t il = base + bl;
+        const bool live = il < p.count;
+        const uint32_t la = live ? il / SYM_BLOCK : 0u;
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        if (live) {
+            const float4 *ar = p.arow + (size_t)la * p.parts * SYM_BLOCK + (il - la * SYM_BLOCK);
+            const uint32_t s0 = (uint32_t)(((uint64_t)p.parts * g) / G), s1 = (uint32_t)(((uint64_t)p.parts * (g + 1u)) / G);
+            uint32_t s = s0;
+            for (; s + 8u <= s1; s += 8u) {
+                float4 v[8];
 #pragma unroll
-    for (int gg = 0; gg < G; gg++) { ax += part[gg][0][bl]; ay += part[gg][1][bl]; az += part[gg][2][bl]; }
-    for (uint32_t k = 0; k < p.world; k++) {
-        const uint32_t q = p.rank >= k ? p.rank - k : p.rank + p.world - k;
-        if (!((p.recv_mask >> q) & 1u)) continue;
-        f4v v;                                             // uncached region, read past this GPU's caches
-        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p.recv_mine + (size_t)q * p.count + il) : "memory");
-        ax += v.x; ay += v.y; az += v.z;
+                for (int u = 0; u < 8; u++) v[u] = ar[(size_t)(s + u) * SYM_BLOCK];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { ax += v[u].x; ay += v[u].y; az += v[u].z; }
+            }
+            for (; s < s1; s++) {
+                const float4 v = ar[(size_t)s * SYM_BLOCK];
+                ax += v.x; ay += v.y; az += v.z;
+            }
+        }
+        __syncthreads();                                   // (the previous pass has read `part`)
+        part[g][0][bl] = ax; part[g][1][bl] = ay; part[g][2][bl] = az;
+        __syncthreads();
+        if (g != 0u || !live) continue;
+        ax = ay = az = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < G; gg++) { ax += part[gg][0][bl]; ay += part[gg][1][bl]; az += part[gg][2][bl]; }
+        // the rows received: uncached region, read past this GPU's caches with system-scope loads (global_load_dwordx2
+        // sc0 sc1, issued by the compiler so that it places the waits), all in flight, added nearest sender first
+        unsigned long long lo[P2P_MAX_RANKS], hi[P2P_MAX_RANKS];
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)P2P_MAX_RANKS; k++) {
+            const uint32_t q = p.rank >= k ? p.rank - k : p.rank + p.world - k;
+            const bool need = k < p.world && ((p.recv_mask >> q) & 1u);
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p.recv_mine + (size_t)(need ? q : p.rank) * p.count + il);
+            lo[k] = need ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+            hi[k] = need ? __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)P2P_MAX_RANKS; k++) {
+            ax += __builtin_bit_cast(float, (uint32_t)lo[k]);
+            ay += __builtin_bit_cast(float, (uint32_t)(lo[k] >> 32));
+            az += __builtin_bit_cast(float, (uint32_t)hi[k]);
+        }
+        ax *= p.mass; ay *= p.mass; az *= p.mass;
+        const uint32_t i = p.rank * p.count + il;
+        const float4 pos = p.pos_old[i];
+        const float *v = p.vel_old + 3 * (size_t)i;
+        float vx = v[0], vy = v[1], vz = v[2];
+        vx = __builtin_fmaf(ax, p.dt, vx) * p.damping;
+        vy = __builtin_fmaf(ay, p.dt, vy) * p.damping;
+        vz = __builtin_fmaf(az, p.dt, vz) * p.damping;
+        float4 o;
+        o.x = __builtin_fmaf(vx, p.dt, pos.x);
+        o.y = __builtin_fmaf(vy, p.dt, pos.y);
+        o.z = __builtin_fmaf(vz, p.dt, pos.z);
+        o.w = __builtin_sqrtf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)));
+        p.pos_new[i] = o;
+        float *vo = p.vel_new + 3 * (size_t)i;
+        vo[0] = vx; vo[1] = vy; vo[2] = vz;
     }
-    ax *= p.mass; ay *= p.mass; az *= p.mass;
-    const uint32_t i = p.rank * p.count + il;
-    const float4 pos = p.pos_old[i];
-    const float *v = p.vel_old + 3 * (size_t)i;
-    float vx = v[0], vy = v[1], vz = v[2];
-    vx = __builtin_fmaf(ax, p.dt, vx) * p.damping;
-    vy = __builtin_fmaf(ay, p.dt, vy) * p.damping;
-    vz = __builtin_fmaf(az, p.dt, vz) * p.damping;
-    float4 o;
-    o.x = __builtin_fmaf(vx, p.dt, pos.x);
-    o.y = __builtin_fmaf(vy, p.dt, pos.y);
-    o.z = __builtin_fmaf(vz, p.dt, pos.z);
-    o.w = __builtin_sqrtf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)));
-    p.pos_new[i] = o;
-    float *vo = p.vel_new + 3 * (size_t)i;
-    vo[0] = vx; vo[1] = vy; vo[2] = vz;
 }
 
 hipError_t launch_force_sym(const SymArgs &a, uint32_t waves, hipStream_t st)
@@ -453,18 +470,13 @@ hipError_t launch_force_sym(const SymArgs &a, uint32_t waves, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_sym_shard_send(const SymShardArgs &a, hipStream_t st)
+hipError_t launch_sym_shard_exchange(const SymShardArgs &a, hipStream_t st)
 {
-    hipLaunchKernelGGL(sym_shard_send_kernel, dim3(a.wgs_per_dest, a.world), dim3(256), 0, st, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_sym_shard_reduce(const SymShardArgs &a, hipStream_t st)
-{
-    // enough threads to keep the rows' loads in flight: 8 per body up to 16 384 bodies, 4 up to 65 536, else 1
-    if (a.count <= 16384u) hipLaunchKernelGGL((sym_shard_reduce_kernel<8>), dim3((a.count + 31u) / 32u), dim3(256), 0, st, a);
-    else if (a.count <= 65536u) hipLaunchKernelGGL((sym_shard_reduce_kernel<4>), dim3((a.count + 63u) / 64u), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((sym_shard_reduce_kernel<1>), dim3((a.count + 255u) / 256u), dim3(256), 0, st, a);
+    // enough threads to keep the rows' loads in flight: 8 per body up to 16 384 bodies, 4 up to 65 536, else 1;
+    // never more workgroups than are resident together (they wait for each other through the ticket)
+    if (a.count <= 16384u) hipLaunchKernelGGL((sym_shard_exchange_kernel<8>), dim3(std::min(1024u, (a.count + 31u) / 32u)), dim3(256), 0, st, a);
+    else if (a.count <= 65536u) hipLaunchKernelGGL((sym_shard_exchange_kernel<4>), dim3(std::min(1024u, (a.count + 63u) / 64u)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((sym_shard_exchange_kernel<1>), dim3(std::min(1024u, (a.count + 255u) / 256u)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -67,7 +67,8 @@ struct SymArgs {
     float4       *arow;       // [nb][parts][SYM_BLOCK]  force on the bodies of an I-block, one row per workgroup
     float4       *brow;       // [n / 64][brows][64] reaction on the bodies of a J-block, one row per meeting
     uint32_t      n, nb;      // bodies, I-blocks of SYM_BLOCK (the last may be padded)
-    uint32_t      parts;      // workgroups per I-block (gridDim.x)
+    uint32_t      parts;      // workgroups per I-block (gridDim.y)
+    uint32_t      taper1, taper2;   // part sizes: the first taper1 parts weigh 4, the next taper2 weigh 2, the rest 1 (taper1 = parts: equal parts)
     uint32_t      brows;      // rows allocated per J-block: (nb - 1) / 2 (+ 1 when nb is even)
     uint32_t      half_d;     // nb / 2 when nb is even (the half-ring partner), else 0
     uint32_t      whole_only; // A/B only (MAPN_SYM_PLAN third field): deal whole meetings to waves, none shared

@@ -114,7 +114,7 @@ __device__ __forceinline__ void one_step(SymBodies &b, float xj, float yj, float
 
 }  // namespace
 
-// grid = (S, NB)   block = 64 * WAVES
+// grid = (NB, S)   block = 64 * WAVES
 // Workgroup (s, a): I-block a, part s of S of its meetings.  The meetings of an I-block are numbered
 // m = 0 .. M-1: m < 16 -> itself, J-block a*16 + m, one-sided; then 16 per partner block a + d.
 // The workgroup's part is dealt to its waves: whole meetings first, the remainder shared step-wise.  Every wave keeps the I-block's
@@ -128,7 +128,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t s = blockIdx.x, la = blockIdx.y, a = p.a0 + la;    // a: the I-block in the whole job; la: among this launch's
+    // grid = (I-blocks, parts): dispatch order is part-major -- all blocks' part 0, then part 1, ... -- so that the
+    // LATE workgroups are the small ones when the parts taper (below)
+    const uint32_t s = blockIdx.y, la = blockIdx.x, a = p.a0 + la;    // a: the I-block in the whole job; la: among this launch's
     const uint32_t nb = p.nb, half = p.half_d;             // half_d = NB/2 when NB is even, else 0
     const uint32_t D = (nb - 1u) / 2u;
     const uint32_t M = JPI * (1u + D) + ((half && a < half) ? JPI : 0u);
@@ -139,7 +141,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     // workgroup finish together (before: a wave with one meeting more kept the other three waiting -- at
     // 65 536 bodies a quarter of the workgroups ran 5 meeting-times for 4.25 of work).
     constexpr uint32_t SEG = 64u / WAVES;
-    const uint32_t pm0 = (uint32_t)(((uint64_t)M * s) / p.parts), pm1 = (uint32_t)(((uint64_t)M * (s + 1u)) / p.parts);
+    // Part sizes TAPER: the first taper1 parts weigh 4 units, the next taper2 parts 2, the rest 1 (taper1 = parts:
+    // all equal).  The CUs do not all run at one speed and a launch is only a few rounds of workgroups, so with
+    // equal parts the slots that finish first idle for up to a whole workgroup time at the end (65 536 bodies, 32
+    // equal parts: 11 % of the wave slots empty over the launch); small workgroups LAST keep that tail short.
+    auto units = [&](uint32_t x) {
+        return x <= p.taper1 ? 4u * x : x <= p.taper1 + p.taper2 ? 4u * p.taper1 + 2u * (x - p.taper1) : 4u * p.taper1 + 2u * p.taper2 + (x - p.taper1 - p.taper2);
+    };
+    const uint32_t U = units(p.parts);
+    const uint32_t pm0 = (uint32_t)(((uint64_t)M * units(s)) / U), pm1 = (uint32_t)(((uint64_t)M * units(s + 1u)) / U);
     const uint32_t cnt = pm1 - pm0;
     // (p.whole_only: the A/B form -- whole meetings only, the first cnt % WAVES waves take one more)
     const uint32_t wm0 = pm0 + (uint32_t)(((uint64_t)cnt * w) / WAVES), wm1 = pm0 + (uint32_t)(((uint64_t)cnt * (w + 1u)) / WAVES);
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
 
 hipError_t launch_force_sym(const SymArgs &a, uint32_t waves, hipStream_t st)
 {
-    const dim3 grid(a.parts, a.shard_nbl ? a.shard_nbl : a.nb);
+    const dim3 grid(a.shard_nbl ? a.shard_nbl : a.nb, a.parts);
     if (waves == 4) hipLaunchKernelGGL((force_sym_kernel<4>), grid, dim3(256), 0, st, a);
     else if (waves == 8) hipLaunchKernelGGL((force_sym_kernel<8>), grid, dim3(512), 0, st, a);
     else return hipErrorInvalidConfiguration;

@@ -88,13 +88,25 @@ def sym_reaction_rows(nb: int, block: int) -> list[int]:
     return list(range(D + (1 if half and block >= half else 0)))
 
 
-def sym_wave_items(meetings: int, parts: int, waves: int):
+def sym_part_bounds(meetings: int, parts: int, taper1: int | None = None, taper2: int = 0) -> list[int]:
+    """First meeting of every part (and the end): the first `taper1` parts weigh 4 units, the next `taper2`
+    weigh 2, the rest 1 (force_sym_kernel's `units`); taper1 = parts (the default) = equal parts."""
+    t1 = parts if taper1 is None else taper1
+
+    def units(x):
+        return 4 * x if x <= t1 else 4 * t1 + 2 * (x - t1) if x <= t1 + taper2 else 4 * t1 + 2 * taper2 + (x - t1 - taper2)
+    total = units(parts)
+    return [meetings * units(s) // total for s in range(parts + 1)]
+
+
+def sym_wave_items(meetings: int, parts: int, waves: int, taper1: int | None = None, taper2: int = 0):
     """How force_sym_kernel deals the M meetings of an I-block: yields (part, wave, meeting, first lane
     rotation, steps).  A part's meetings go to its waves whole (q = cnt // waves each); the remaining
     cnt % waves meetings are shared, every wave running 64 // waves of the 64 steps from a rotated start."""
     seg = 64 // waves
+    bounds = sym_part_bounds(meetings, parts, taper1, taper2)
     for s in range(parts):
-        pm0, pm1 = meetings * s // parts, meetings * (s + 1) // parts
+        pm0, pm1 = bounds[s], bounds[s + 1]
         q, r = divmod(pm1 - pm0, waves)
         for w in range(waves):
             for it in range(q):

@@ -63,22 +63,32 @@ def test_chunk_tiles_partition_the_range():
         assert all(edges[c][1] == edges[c + 1][0] for c in range(splits - 1))
 
 
-@pytest.mark.parametrize("meetings,parts,waves", [(528, 32, 4), (512, 32, 4), (16, 4, 4), (48, 12, 4), (2064, 32, 4), (528, 16, 8), (40, 7, 4), (3, 2, 4)])
-def test_wave_deal_covers_every_step_of_every_meeting_once_and_is_balanced(meetings, parts, waves):
+@pytest.mark.parametrize("meetings,parts,waves,taper", [(528, 32, 4, None), (512, 32, 4, None), (16, 4, 4, None), (48, 12, 4, None), (2064, 32, 4, None),
+                                                        (528, 16, 8, None), (40, 7, 4, None), (3, 2, 4, None), (528, 48, 4, (24, 8)), (512, 48, 4, (24, 8)),
+                                                        (272, 48, 4, (24, 8)), (144, 48, 4, (24, 8)), (1040, 40, 4, (28, 4))])
+def test_wave_deal_covers_every_step_of_every_meeting_once_and_is_balanced(meetings, parts, waves, taper):
     """force_sym_kernel's deal of an I-block's meetings to waves: whole meetings first, the remainder of a
     part shared step-wise.  Every (meeting, travelling-body offset) is run exactly once, and the waves of
-    a workgroup all run the same number of steps (nobody waits at the closing barrier)."""
+    a workgroup all run the same number of steps (nobody waits at the closing barrier).  With tapered parts
+    (4 : 2 : 1 units) the late parts are a quarter of the early ones."""
+    t1, t2 = taper if taper else (None, 0)
     seen = np.zeros((meetings, 64), np.int32)
     steps = {}
-    for s, w, m, rot, n in shard.sym_wave_items(meetings, parts, waves):
+    for s, w, m, rot, n in shard.sym_wave_items(meetings, parts, waves, t1, t2):
         seen[m, rot:rot + n] += 1
         steps[(s, w)] = steps.get((s, w), 0) + n
     assert (seen == 1).all()
     for s in range(parts):
         per_wave = {steps.get((s, w), 0) for w in range(waves)}
         assert len(per_wave) == 1
-    per_part = sorted({steps.get((s, 0), 0) for s in range(parts)})
-    assert per_part[-1] - per_part[0] <= 64 // waves      # parts differ by at most one meeting = 64 / waves steps per wave
+    bounds = shard.sym_part_bounds(meetings, parts, t1, t2)
+    assert bounds[0] == 0 and bounds[-1] == meetings and all(b1 >= b0 for b0, b1 in zip(bounds, bounds[1:]))
+    sizes = [b1 - b0 for b0, b1 in zip(bounds, bounds[1:])]
+    if taper is None:
+        assert max(sizes) - min(sizes) <= 1                # equal parts differ by at most one meeting
+    else:
+        big, small = sizes[:t1], sizes[t1 + t2:]
+        assert max(big) - min(big) <= 1 and max(small) - min(small) <= 1 and abs(4 * np.mean(small) - np.mean(big)) <= 2
 
 
 @pytest.mark.parametrize("nb,world", [(8, 2), (8, 4), (8, 8), (9, 3), (6, 2), (16, 8), (64, 8), (64, 2), (1024, 8)])

@@ -411,6 +411,11 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     if (e && atoi(e) > 0) parts = (uint32_t)atoi(e);
     parts = std::min(parts, std::max(1u, meetings / waves));
     a.parts = parts; a.taper1 = parts; a.taper2 = 0;
+    {
+        const char *t = getenv("MAPN_SYM_SHARD_TAPER");     // "parts,taper1,taper2" tuning override
+        unsigned tp = 0, t1 = 0, t2 = 0;
+        if (t && sscanf(t, "%u,%u,%u", &tp, &t1, &t2) == 3 && tp >= 1 && t1 + t2 <= tp) { a.parts = parts = tp; a.taper1 = t1; a.taper2 = t2; }
+    }
     const size_t ab = (size_t)a.shard_nbl * parts * mapn::SYM_BLOCK * sizeof(float4), bb = (size_t)c->n * a.shard_nbl * sizeof(float4);
     if (ab > c->sym_arow_bytes) {
         if (c->sym_arow) HIP_TRY(hipFree(c->sym_arow));

@@ -38,6 +38,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "mapn_kernels.h"
 
@@ -474,7 +475,9 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
 hipError_t launch_force_sym(const SymArgs &a, uint32_t waves, hipStream_t st)
 {
     const dim3 grid(a.shard_nbl ? a.shard_nbl : a.nb, a.parts);
-    if (waves == 4) hipLaunchKernelGGL((force_sym_kernel<4>), grid, dim3(256), 0, st, a);
+    // (experiments only: MAPN_SYM_PAD_LDS=bytes of unused dynamic LDS, e.g. 60000 leaves room for ONE workgroup per CU)
+    static const unsigned pad = [] { const char *e = getenv("MAPN_SYM_PAD_LDS"); return e ? (unsigned)strtoul(e, nullptr, 10) : 0u; }();
+    if (waves == 4) hipLaunchKernelGGL((force_sym_kernel<4>), grid, dim3(256), pad, st, a);
     else if (waves == 8) hipLaunchKernelGGL((force_sym_kernel<8>), grid, dim3(512), 0, st, a);
     else return hipErrorInvalidConfiguration;
     return hipGetLastError();

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of the symmetric kernel's inner-loop variants on one box (MAPN_SYM_PLAN=waves,parts,variant):
+# (the variant template parameter / -DMAPN_SYM_K2 builds existed only in the experiment commits; see profiles/r02_sym_loop_variants.txt)
 # 0 = reaction folded every step (6 moves + 3 adds + copies), 1 = reaction travels unfolded (9 moves),
 # 2 = 1 unrolled by two (no loop-carried copies), 3 = 2 with the position moves pinned at the step head.
 R=$PWD; O=$R/gpurun_out/r02k; mkdir -p $O

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of bodies-per-lane in the symmetric kernel on one box: K2 = 8 (16 bodies, 2 waves/SIMD, shipped),
+# (the variant template parameter / -DMAPN_SYM_K2 builds existed only in the experiment commits; see profiles/r02_sym_loop_variants.txt)
 # 6 (12 bodies, 3 waves/SIMD), 4 (8 bodies, 4 waves/SIMD); experiment libraries built with -DMAPN_SYM_K2.
 R=$PWD; O=$R/gpurun_out/r02l; mkdir -p $O
 L=multi-adapter-particles_amd

@@ -1,5 +1,6 @@
 #!/bin/bash
 # experiment: time-sliced issue priority between the two waves of a SIMD (MAPN_SYM_FAIR=log2 of the slice in cycles)
+# (the MAPN_SYM_FAIR hook existed only in the experiment build; it was removed after this measurement)
 python -m pytest tests/test_gpu_sym.py -m "gpu and not slow" -q 2>&1 | tail -1
 MAPN_SYM_FAIR=13 python -m pytest tests/test_gpu_sym.py -m "gpu and not slow" -q 2>&1 | tail -1
 for rep in 1 2; do for f in 0 11 13 15 17; do

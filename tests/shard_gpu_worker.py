@@ -56,8 +56,11 @@ def main():
         # "sym" = the symmetric step sharded over the ranks (gather algorithm 4): reactions stored into the
         # owners' receive regions, positions pulled as in "p2p"
         c.set_gather_algorithm({"p2p": 2, "flow": 3, "sym": 4}[mode])
-        c.set_timeouts(p2p_ms=5000)      # several processes time-slice ONE GPU here: be generous
+        # several processes time-slice ONE GPU here: be generous (the big jobs allocate GBs of scratch inside their
+        # first step, one process after the other)
+        c.set_timeouts(p2p_ms=5000 if n <= 65536 else 60000)
         num_active = int(sys.argv[8]) if len(sys.argv) > 8 else n
+        dist.barrier()                   # start stepping together: process start-up skews by seconds on a cold box
         for _ in range(steps):
             c.Simulate(num_active, c.GetFenceValue())
         c.WaitForGpu()

@@ -306,6 +306,7 @@ def main():
                 failed = None
                 try:
                     select(name, algo, overlap)
+                    dist.barrier()                          # the device-side waits are bounded (200 ms): start together
                     for _ in range(5):
                         step()
                     sync()

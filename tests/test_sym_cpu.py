@@ -105,3 +105,40 @@ def test_sharded_symmetric_step_sender_and_receiver_sets_agree(nb, world):
     assert need == have
     if world == 8 and nb >= 16:
         assert all(bin(m[0]).count("1") == 5 for m in masks)      # this rank and the four ahead of it on the ring
+
+
+@pytest.mark.parametrize("nb,world", [(4, 2), (6, 2), (6, 3), (8, 4), (8, 8), (9, 3), (16, 8)])
+def test_sharded_symmetric_decomposition_reproduces_the_all_pairs_forces(nb, world):
+    """Gather algorithm 4 on paper (float64, tiny blocks): every rank evaluates the meetings of its own blocks
+    once, keeps the forces on its bodies and ships the reactions, summed per destination rank, to the owners.
+    Own rows + received rows must equal the direct all-pairs sum for every body, and rows may only travel
+    where the sender / receiver masks say so."""
+    B = 6                                                  # bodies per block (the device uses 1024)
+    rng = np.random.default_rng(nb * 100 + world)
+    n = nb * B
+    x = rng.normal(size=(n, 3)) * 100.0
+    soft2 = 25.0
+
+    def pair(i, j):                                        # force on i from j (hlsl:44-57 without the mass)
+        r = x[j] - x[i]
+        return r * (r @ r + soft2) ** -1.5
+
+    direct = np.array([sum(pair(i, j) for j in range(n)) for i in range(n)])
+    nbl = nb // world
+    own = np.zeros((n, 3))                                 # a-rows: forces a rank computed for its own bodies
+    recv = np.zeros((world, world, n, 3))                  # recv[receiver][sender][body]
+    for a, b, d, symmetric in shard.sym_meetings(nb):
+        r = a // nbl
+        for i in range(a * B, (a + 1) * B):
+            for j in range(b * B, (b + 1) * B):
+                f = pair(i, j)
+                own[i] += f
+                if symmetric:
+                    recv[b // nbl][r][j] -= f              # the reaction, to the owner of block b
+    total = own + recv.sum(axis=1).sum(axis=0)
+    np.testing.assert_allclose(total, direct, rtol=1e-9, atol=1e-12)
+    for q in range(world):
+        send, rcv = shard.sym_shard_masks(nb, world, q)
+        for r in range(world):
+            used = bool(np.abs(recv[q][r]).max() > 0)
+            assert used == bool(rcv >> r & 1), (q, r)

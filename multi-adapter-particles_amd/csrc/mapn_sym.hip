@@ -284,7 +284,15 @@ __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs
     const uint32_t a = i / SYM_IB, jb = i >> 6;
     float ax = 0.f, ay = 0.f, az = 0.f;
     const float4 *ar = p.arow + (size_t)a * p.parts * SYM_IB + (i - a * SYM_IB);
-    for (uint32_t s = 0; s < p.parts; s++) {
+    uint32_t s = 0;
+    for (; s + 8u <= p.parts; s += 8u) {                   // 8 loads in flight (one wave per SIMD: nothing else hides the latency), summed in ascending order
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = ar[(size_t)(s + u) * SYM_IB];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { ax += v[u].x; ay += v[u].y; az += v[u].z; }
+    }
+    for (; s < p.parts; s++) {
         const float4 v = ar[(size_t)s * SYM_IB];
         ax += v.x; ay += v.y; az += v.z;
     }

@@ -55,8 +55,12 @@ typedef enum mapn_kernel {
     MAPN_KERNEL_SCALAR = 2,     /* j-bodies through the scalar cache into SGPRs */
     MAPN_KERNEL_SYMMETRIC = 3   /* Newton's third law: every unordered pair evaluated once, feeding both bodies
                                    (csrc/mapn_sym.hip).  Applies to the unsharded step with all bodies active and
-                                   N >= 1024 (scratch N^2/128 bytes, capped by MAPN_SYM_MAX_MB, default
-                                   16384); any other step of such a context runs the scalar-cache kernel. */
+                                   N >= 1024; any other step of such a context runs the scalar-cache kernel.  Its
+                                   scratch is O(N): a step is made in as many launches (windows of partner distance) as
+                                   keep the reaction rows within MAPN_SYM_MAX_MB (default 1024), and is allocated by
+                                   mapn_create -- which fails if the memory is not to be had.  Under
+                                   MAPN_KERNEL_AUTO the same failure only selects the one-sided kernel
+                                   (mapn_get_sym_plan tells why). */
     /* No MFMA variant (BASELINE configs[4] A/B, closed in round 2): on gfx950 the f32 MFMA shapes do NOT
        run beside the packed fp32 VALU stream of the same SIMD -- their times add (16 v_pk_fma_f32 + one
        v_mfma_f32_16x16x4_f32: 105 cycles against 74 + 32) -- so every recast of the pair term is slower
@@ -363,6 +367,38 @@ int mapn_get_kernel_stats(mapn_ctx *ctx, int reset, mapn_kernel_stats *out);
  * multiplies the total. */
 int mapn_set_force_plan(mapn_ctx *ctx, int kernel, uint32_t bodies_per_lane, uint32_t waves,
                         uint32_t sb, int fused);
+/*
+ * The SYMMETRIC kernel's launch plan (csrc/mapn_sym_plan.h).  A step is made in `windows` force launches (partner
+ * distance groups [g0, g1) each; one launch while the reaction rows fit MAPN_SYM_MAX_MB, default 1024), each
+ * followed by a reduce launch that carries the running sum; inside a launch `parts` workgroups of `waves` waves
+ * share the meetings of every 1024-body block, cut to the STEP so that every wave carries the same cost.
+ * windows[4 k ..] = {g0, g1, meetings of a class-0 block, of a class-1 block}; tables = per window
+ * bounds[2][parts * waves + 1] (first linear step of every wave) then split[2][max_meetings] (the part whose
+ * head row holds the last steps of a meeting cut between two workgroups, 0xffffffff otherwise); class 0 = the blocks
+ * that also run the half-ring group (even block count, a < nb / 2).  What an order-matched checker must reproduce
+ * (the CPU checker restates exactly this): per wave one fused-multiply-add chain per body over its steps in
+ * order; the workgroup's waves added in ascending order into ONE row per (block, part); the reaction of a meeting as
+ * two chains (even / odd bodies of the lane) folded once per piece, pieces of a cut meeting added first steps + last
+ * steps; per body: rows of its block in ascending part order, then per group in ascending order the meeting's row and
+ * its head row, windows in ascending order; the mass multiplies the total.
+ * mapn_sym_plan_describe computes the plan of a shape WITHOUT a device (CPU tests, the oracle);
+ * mapn_get_sym_plan returns the plan a context runs (a0 / nbl: first block and block count of this rank when sharded);
+ * mapn_set_sym_plan is the tuning hook (waves 4 or 8; taper1 = taper2 = 0: equal parts; groups_per_window 0: as many
+ * as fit; waves = parts = 0: back to the default shape) -- it re-allocates the scratch, never call it per step.
+ */
+typedef struct mapn_sym_plan_info {
+    uint32_t nb, groups, windows;
+    uint32_t parts, taper1, taper2, waves;
+    uint32_t brows, max_meetings, table_stride;
+    uint32_t a0, nbl;
+    uint64_t scratch_bytes;      /* device memory the symmetric step holds (rows, running sum, tables) */
+    char     error[256];         /* why a shape was refused / why the kernel does not run */
+} mapn_sym_plan_info;
+int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2,
+                           uint32_t waves, mapn_sym_plan_info *info, uint32_t *windows, uint32_t *tables, uint64_t tables_capacity);
+int mapn_get_sym_plan(mapn_ctx *ctx, mapn_sym_plan_info *info, uint32_t *windows, uint32_t *tables, uint64_t tables_capacity);
+int mapn_set_sym_plan(mapn_ctx *ctx, uint32_t waves, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t groups_per_window);
+
 /* Sharded mode: switch the own/remote overlap structure (MAPN_FLAG_SHARD_OVERLAP) at run time, so a
  * launcher can time both structures on the node it runs on; all ranks must agree. */
 int mapn_set_shard_overlap(mapn_ctx *ctx, int enabled);
@@ -370,8 +406,10 @@ int mapn_set_shard_overlap(mapn_ctx *ctx, int enabled);
 /* The shader clock the chip HOLDS under this kernel (it lowers its clock under load): runs `steps`
  * ordinary steps whose force launch additionally stamps s_memtime / s_memrealtime around every
  * wave's pair loop into a scratch buffer nothing else reads (no stamp executes in a normal launch),
- * and reports the median over waves of d(s_memtime) / d(s_memrealtime) x 100 MHz.  The steps advance
- * the simulation like mapn_simulate.  Scalar-cache force kernel, all-pairs mode only. */
+ * and reports the median over waves of d(s_memtime) / d(s_memrealtime) x 100 MHz.
+ * SIDE EFFECTS: these are real steps -- positions, velocities, fence value and buffer index advance exactly as by
+ * `steps` calls of mapn_simulate(ctx, N, 0) (no consumer wait); in a sharded job every rank must call it.  Scalar-cache
+ * and symmetric force kernels, all-pairs mode only: anything else is refused BEFORE a step is taken. */
 typedef struct mapn_clock_info {
     double   shader_clock_ghz;       /* median over the stamped waves of the last diagnostic launch */
     double   shader_clock_ghz_p10, shader_clock_ghz_p90;

@@ -11,12 +11,12 @@ from ._lib import (  # noqa: F401
     FLAG_NO_INIT, FLAG_SHARD_OVERLAP, FLAG_STRICT_CONSUMER, FLAG_USE_GRAPH, INIT_LCG, INIT_MT, INIT_SSE, Config, DeviceInfo, KernelStats, MapnError, SharedHandles,
     build_library, library_path, load_library,
 )
-from .compute import Compute, IpcView, generate_initial_state  # noqa: F401
+from .compute import Compute, IpcView, SymPlan, describe_sym_plan, generate_initial_state  # noqa: F401
 from .shard import ShardPlan, shard_range, remote_segments  # noqa: F401
 
 __all__ = [
     "Compute", "IpcView", "Config", "MapnError", "ShardPlan", "shard_range", "remote_segments",
-    "generate_initial_state", "build_library", "load_library", "library_path",
+    "generate_initial_state", "SymPlan", "describe_sym_plan", "build_library", "load_library", "library_path",
     "FORCE_ALL_PAIRS", "FORCE_CENTRAL_WELL", "KERNEL_AUTO", "KERNEL_LDS", "KERNEL_SCALAR", "KERNEL_SYMMETRIC",
     "FLAG_NO_INIT", "FLAG_USE_GRAPH", "FLAG_SHARD_OVERLAP", "FLAG_STRICT_CONSUMER", "INIT_LCG", "INIT_SSE", "INIT_MT",
 ]

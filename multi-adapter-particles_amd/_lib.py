@@ -70,6 +70,15 @@ class KernelStats(C.Structure):
     ]
 
 
+class SymPlanInfo(C.Structure):
+    _fields_ = [
+        ("nb", C.c_uint32), ("groups", C.c_uint32), ("windows", C.c_uint32),
+        ("parts", C.c_uint32), ("taper1", C.c_uint32), ("taper2", C.c_uint32), ("waves", C.c_uint32),
+        ("brows", C.c_uint32), ("max_meetings", C.c_uint32), ("table_stride", C.c_uint32),
+        ("a0", C.c_uint32), ("nbl", C.c_uint32), ("scratch_bytes", C.c_uint64), ("error", C.c_char * 256),
+    ]
+
+
 # every symbol include/mapn.h declares: (name, restype, argtypes)
 _fp = C.POINTER(C.c_float)
 _ctx = C.c_void_p
@@ -127,6 +136,10 @@ SIGNATURES = {
     "mapn_get_kernel_stats": (C.c_int, [_ctx, C.c_int, C.POINTER(KernelStats)]),
     "mapn_set_force_plan": (C.c_int, [_ctx, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     "mapn_set_shard_overlap": (C.c_int, [_ctx, C.c_int]),
+    "mapn_sym_plan_describe": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.POINTER(SymPlanInfo), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint64]),
+    "mapn_get_sym_plan": (C.c_int, [_ctx, C.POINTER(SymPlanInfo), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint64]),
+    "mapn_set_sym_plan": (C.c_int, [_ctx, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "mapn_measure_clock": (C.c_int, [_ctx, C.c_int, C.POINTER(ClockInfo)]),
     "mapn_set_timers": (C.c_int, [_ctx, C.c_int]),
     "mapn_compute_stream": (C.c_void_p, [_ctx]),

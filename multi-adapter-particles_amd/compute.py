@@ -244,6 +244,20 @@ class Compute:
         """fused: False/0 two launches (rows + reduce_integrate), True/1 one launch, 2 ticket form always."""
         check(self._lib.mapn_set_force_plan(self._ctx, kernel, bodies_per_lane, waves, sb, int(fused)))
 
+    def set_sym_plan(self, waves: int = 0, parts: int = 0, taper1: int = 0, taper2: int = 0, groups_per_window: int = 0):
+        """Shape of the symmetric kernel's launches (waves = parts = 0: the default); re-allocates its scratch."""
+        check(self._lib.mapn_set_sym_plan(self._ctx, waves, parts, taper1, taper2, groups_per_window))
+
+    def sym_plan(self) -> "SymPlan":
+        """The plan the symmetric kernel runs in this context (raises MapnError if it does not run)."""
+        info = _lib.SymPlanInfo()
+        check(self._lib.mapn_get_sym_plan(self._ctx, C.byref(info), None, None, 0))
+        win = np.zeros((info.windows, 4), np.uint32)
+        tab = np.zeros(info.windows * info.table_stride, np.uint32)
+        u32p = C.POINTER(C.c_uint32)
+        check(self._lib.mapn_get_sym_plan(self._ctx, C.byref(info), win.ctypes.data_as(u32p), tab.ctypes.data_as(u32p), tab.size))
+        return SymPlan(info, win, tab)
+
     def set_shard_overlap(self, enabled: bool):
         check(self._lib.mapn_set_shard_overlap(self._ctx, int(bool(enabled))))
 
@@ -304,6 +318,44 @@ class IpcView:
 
     def consumer_signal(self, value: int, consumer_stream: int = 0):
         check(self._lib.mapn_ipc_consumer_signal(self._view, int(value), C.c_void_p(consumer_stream)))
+
+
+class SymPlan:
+    """The symmetric kernel's launch plan as data (include/mapn.h, mapn_sym_plan_info): `windows[k]` =
+    (g0, g1, meetings of a class-0 block, of a class-1 block); `bounds(k, cls)[v]` = first linear step of wave v;
+    `split(k, cls)[m]` = part holding the head row of meeting m, or SPLIT_NONE."""
+    SPLIT_NONE = 0xffffffff
+
+    def __init__(self, info, windows, tables):
+        self.info, self.windows, self.tables = info, windows, tables
+        for k in ("nb", "groups", "parts", "taper1", "taper2", "waves", "brows", "max_meetings", "table_stride", "a0", "nbl", "scratch_bytes"):
+            setattr(self, k, int(getattr(info, k)))
+        self.nwaves = self.parts * self.waves
+
+    def bounds(self, window: int, cls: int):
+        o = window * self.table_stride + cls * (self.nwaves + 1)
+        return self.tables[o:o + self.nwaves + 1]
+
+    def split(self, window: int, cls: int):
+        o = window * self.table_stride + 2 * (self.nwaves + 1) + cls * self.max_meetings
+        return self.tables[o:o + self.max_meetings]
+
+
+def describe_sym_plan(nb: int, groups_per_window: int = 0, parts: int = 32, taper1: int | None = None, taper2: int = 0, waves: int = 4) -> SymPlan:
+    """The plan of a shape, computed on the host without a device (csrc/mapn_sym_plan.cpp)."""
+    lib = load_library()
+    info = _lib.SymPlanInfo()
+    t1 = parts if taper1 is None else taper1
+    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, C.byref(info), None, None, 0)
+    if rc:
+        raise MapnError(rc, info.error.decode(errors="replace"))
+    win = np.zeros((info.windows, 4), np.uint32)
+    tab = np.zeros(info.windows * info.table_stride, np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, C.byref(info), win.ctypes.data_as(u32p), tab.ctypes.data_as(u32p), tab.size)
+    if rc:
+        raise MapnError(rc, info.error.decode(errors="replace"))
+    return SymPlan(info, win, tab)
 
 
 def device_info(device: int = 0) -> _lib.DeviceInfo:

@@ -18,6 +18,7 @@
 #include "mapn.h"
 #include "mapn_comm.h"
 #include "mapn_kernels.h"
+#include "mapn_sym_plan.h"
 
 namespace {
 
@@ -74,12 +75,24 @@ struct mapn_ctx {
     float4 *partial = nullptr;
     size_t partial_bytes = 0;
     uint32_t *ticket = nullptr;               // EPI_TICKET arrival counters, one per i-tile, zero between launches
-    float4 *sym_arow = nullptr, *sym_brow = nullptr;   // scratch rows of the symmetric kernel (mapn_sym.hip)
-    size_t sym_arow_bytes = 0, sym_brow_bytes = 0;
+    // the symmetric kernel (mapn_sym.hip): plan and scratch are made when the context is created / wired for exchange
+    // algorithm 4 (prepare_sym) -- never inside mapn_simulate
+    mapn::SymPlanHost sym_plan;               // which steps every wave runs, in how many launches (windows) a step is made
+    bool sym_ready = false;                   // plan built, scratch allocated, tables uploaded
+    bool sym_sharded = false;                 // ... for the sharded form (this rank's blocks) rather than the whole job
+    bool sym_user_plan = false;               // mapn_set_sym_plan: keep the shape on re-preparation
+    uint32_t sym_user[5] = {0, 0, 0, 0, 0};   // waves, parts, taper1, taper2, groups per window
+    std::string sym_note;                     // why AUTO runs the one-sided kernel instead (allocation failed, ...)
+    float4 *sym_arow = nullptr, *sym_brow = nullptr, *sym_brow1 = nullptr, *sym_acc = nullptr;
+    uint32_t *sym_tab = nullptr;              // device copy of sym_plan.tables
+    size_t sym_scratch_bytes = 0;
     uint32_t sym_parts = 0, sym_waves = 0;
+    uint32_t sym_exchange_cap = 0;            // workgroups of sym_shard_exchange_kernel the device holds at once
     unsigned long long *stamp_buf = nullptr;  // mapn_measure_clock: per-wave clock stamps of a diagnostic launch
     size_t stamp_waves = 0;
     bool stamp_next = false;
+    unsigned long long *timeline_buf = nullptr;   // MAPN_STAMP_DUMP: per-wave wall-clock stamps of a diagnostic symmetric launch
+    size_t timeline_waves = 0, timeline_last = 0;
 
     uint32_t buffer_index = 0;                // Compute.cpp:80 m_bufferIndex(0)
     uint64_t fence_value = 0;                 // Compute.cpp:82 m_fenceValue(0)
@@ -139,8 +152,9 @@ struct mapn_ctx {
     uint32_t *p2p_peer_flags[mapn::P2P_MAX_RANKS] = {};
     uint32_t p2p_step = 0;
     uint32_t **p2p_flag_table = nullptr;      // device copy of p2p_peer_flags[] (flow mode reads it in the kernel)
-    uint32_t *sym_shard_ticket = nullptr;     // gather algorithm 4: the send kernel's per-destination tickets
+    uint32_t *sym_shard_ticket = nullptr;     // gather algorithm 4: the exchange kernel's two tickets
     uint32_t sym_shard_step = 0;
+    bool step_pulled = false;                 // this step's exchange launch already moved the positions (algorithm 4, pull folded in)
     uint32_t sym_send_mask = 0, sym_recv_mask = 0;
     bool p2p_loopback = false;                // MAPN_P2P_LOOPBACK=1 (timing on a 1-GPU box only): every peer maps to this rank
     uint32_t *flow_block = nullptr;           // ordinary device memory: [0..15] arrived[q], [16] tiles_done (flow mode)
@@ -275,103 +289,19 @@ mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_tota
     return p;
 }
 
-// The symmetric kernel (mapn_sym.hip) covers the whole-N, unsharded, all-bodies-active step with N >= 1024
-// (padded to a multiple of 1024 inside the kernel); anything else runs the one-sided kernels.  Its scratch grows with N^2 / 128
-// bytes (one 1 KiB row per meeting of a 64-body block with a 1024-body block), capped by MAPN_SYM_MAX_MB.
-bool sym_eligible(const mapn_ctx *c, uint32_t active)
-{
-    // AUTO picks it wherever it applies (measured 1.40x the scalar-cache kernel at 65 536 bodies, 1.44x at
-    // 262 144 and 1 048 576: profiles/r02_sym_vs_onesided.txt); MAPN_KERNEL_SCALAR / _LDS and a forced plan keep the one-sided kernels
-    if ((c->cfg.kernel != MAPN_KERNEL_SYMMETRIC && c->cfg.kernel != MAPN_KERNEL_AUTO) || c->plan_forced) return false;
-    const char *off = getenv("MAPN_NO_SYM");
-    if (off && off[0] == '1' && c->cfg.kernel == MAPN_KERNEL_AUTO) return false;
-    if (c->cfg.world_size != 1 || c->cfg.force_mode != MAPN_FORCE_ALL_PAIRS) return false;
-    if (c->comm || c->external_gather || c->p2p_ready) return false;   // a context wired for an exchange runs the sharded step
-    if (active != c->n || c->n < mapn::SYM_BLOCK) return false;       // (a smaller job does not fill one block: one-sided)
-    const uint64_t nb = (c->n + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK, brows = std::max<uint64_t>(1, (nb - 1) / 2 + ((nb & 1u) ? 0 : 1));
-    const char *e = getenv("MAPN_SYM_MAX_MB");
-    const uint64_t cap = (e ? strtoull(e, nullptr, 10) : 16384ull) << 20;   // 1 048 576 bodies need 8.6 GB of the 288 GB
-    return nb * mapn::SYM_BLOCK * brows * 16ull <= cap;
-}
+// ---- the symmetric kernel (mapn_sym.hip): plan, scratch, launches ---------------------------------------------
 
-int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
+void release_sym(mapn_ctx *c)
 {
-    mapn::SymArgs a{};
-    a.pos_old = base.pos_old; a.vel_old = base.vel_old; a.pos_new = base.pos_new; a.vel_new = base.vel_new;
-    a.n = c->n; a.nb = (c->n + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK;     // the last block may be partly stand-in bodies
-    a.half_d = (a.nb & 1u) ? 0u : a.nb / 2u;
-    a.brows = std::max(1u, (a.nb - 1u) / 2u + (a.half_d ? 1u : 0u));
-    a.mass = base.mass; a.soft2 = base.soft2; a.dt = base.dt; a.damping = base.damping;
-    uint32_t waves = 4, parts = 0;
-    const char *e = getenv("MAPN_SYM_PLAN");               // "waves,parts[,whole_only]" tuning override (parts 0 = default)
-    unsigned ew = 0, ep = 0, eo = 0;
-    if (e && sscanf(e, "%u,%u,%u", &ew, &ep, &eo) >= 2 && (ew == 4 || ew == 8)) { waves = ew; parts = ep; a.whole_only = eo ? 1u : 0u; }
-    if (!parts) {
-        // 2 waves per SIMD are resident (246 VGPRs).  32 four-wave workgroups per I-block measured best or
-        // within 0.5 % of best at every size (65 536 bodies: parts 24 / 32 / 48 / 64 -> 0.663 / 0.647 / 0.669 /
-        // 0.675 ms; 262 144: 8 / 32 / 64 / 128 -> 9.95 / 9.60 / 9.60 / 9.89 ms; 1 048 576: 2 / 8 / 32 / 64 ->
-        // 154.3 / 153.2 / 152.9 / 153.0 ms; 8-wave workgroups 0.68-0.72 ms at 65 536)
-        const uint32_t meetings = mapn::SYM_JPI * (1u + (a.nb - 1u) / 2u) + (a.half_d ? mapn::SYM_JPI : 0u);
-        parts = std::min(32u, std::max(1u, meetings / waves));
-    }
-    a.parts = parts; a.taper1 = parts; a.taper2 = 0;       // equal parts
-    {
-        // few rounds of workgroups (65 536 .. 131 072 bodies): taper the parts -- 28 of 4 units, 4 of 2, 8 of 1 (128 units,
-        // 40 parts) -- so that the workgroups dispatched last are a quarter of the first ones' size.  Same box, 65 536
-        // bodies: equal 32 parts 0.6342 ms, 40/28/4 0.6244, 48/24/8 0.6266, 36/28/8 0.6357, 64/16/16 0.6323 (the reduce
-        // launch grows with the part count: +2 us at 40); 100 000 bodies +3.5 %; 32 768 bodies lose 2 % (not tapered)
-        const char *t = getenv("MAPN_SYM_TAPER");           // "parts,taper1,taper2" tuning override; "0" = equal parts
-        unsigned tp = 0, t1 = 0, t2 = 0;
-        if (t && sscanf(t, "%u,%u,%u", &tp, &t1, &t2) == 3 && tp >= 1 && t1 + t2 <= tp) { a.parts = tp; a.taper1 = t1; a.taper2 = t2; }
-        else if (!(t && t[0] == '0') && !e && a.nb >= 64u && a.nb <= 128u) { a.parts = 40; a.taper1 = 28; a.taper2 = 4; }
-        parts = a.parts;
-    }
-    const size_t ab = (size_t)a.nb * parts * mapn::SYM_BLOCK * sizeof(float4), bb = (size_t)a.nb * mapn::SYM_BLOCK * a.brows * sizeof(float4);
-    if (ab > c->sym_arow_bytes) {
-        if (c->sym_arow) HIP_TRY(hipFree(c->sym_arow));
-        c->sym_arow = nullptr; c->sym_arow_bytes = 0;
-        HIP_TRY(hipMalloc(&c->sym_arow, ab));
-        c->sym_arow_bytes = ab;
-    }
-    if (bb > c->sym_brow_bytes) {
-        if (c->sym_brow) HIP_TRY(hipFree(c->sym_brow));
-        c->sym_brow = nullptr; c->sym_brow_bytes = 0;
-        HIP_TRY(hipMalloc(&c->sym_brow, bb));
-        c->sym_brow_bytes = bb;
-    }
-    a.arow = c->sym_arow; a.brow = c->sym_brow;
-    if (c->stamp_next) {
-        const size_t nw = (size_t)a.nb * parts * waves;
-        if (nw > c->stamp_waves) {
-            if (c->stamp_buf) HIP_TRY(hipFree(c->stamp_buf));
-            c->stamp_buf = nullptr; c->stamp_waves = 0;
-            HIP_TRY(hipMalloc(&c->stamp_buf, nw * 16));
-            c->stamp_waves = nw;
-        }
-        HIP_TRY(hipMemsetAsync(c->stamp_buf, 0, c->stamp_waves * 16, c->compute));
-        a.stamps = c->stamp_buf;
-    }
-    HIP_TRY(mapn::launch_force_sym(a, waves, c->compute));
-    if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
-    HIP_TRY(mapn::launch_sym_reduce(a, c->compute));
-    mapn::ForcePlan p{};
-    p.kind = mapn::KERNEL_SYM; p.k = 2 * mapn::SYM_K2; p.waves = waves; p.sb = parts; p.nseg = 1; p.epi = mapn::EPI_ROWS;
-    c->last_plan = p; c->last_i_count = c->n; c->last_launches = 2;
-    c->sym_parts = parts; c->sym_waves = waves;
-    return MAPN_OK;
-}
-
-// Gather algorithm 4: the symmetric step sharded over ranks.  Every rank's slice must be whole I-blocks;
-// the reaction scratch is one row per (J-block of the job, I-block of this rank): n * nbl * 16 bytes.
-bool sym_shard_eligible(const mapn_ctx *c, uint32_t active)
-{
-    if (!c->p2p_ready || c->gather_algo != 4 || c->cfg.world_size < 2) return false;
-    if ((c->cfg.kernel != MAPN_KERNEL_SYMMETRIC && c->cfg.kernel != MAPN_KERNEL_AUTO) || c->plan_forced) return false;
-    if (c->cfg.force_mode != MAPN_FORCE_ALL_PAIRS || active != c->n) return false;
-    if (c->count % mapn::SYM_BLOCK != 0 || c->count * (uint32_t)c->cfg.world_size != c->n) return false;
-    const char *e = getenv("MAPN_SYM_MAX_MB");
-    const uint64_t cap = (e ? strtoull(e, nullptr, 10) : 16384ull) << 20;
-    return (uint64_t)c->n * (c->count / mapn::SYM_BLOCK) * 16ull <= cap;
+    if (c->sym_arow) (void)hipFree(c->sym_arow);
+    if (c->sym_brow) (void)hipFree(c->sym_brow);
+    if (c->sym_brow1) (void)hipFree(c->sym_brow1);
+    if (c->sym_acc) (void)hipFree(c->sym_acc);
+    if (c->sym_tab) (void)hipFree(c->sym_tab);
+    c->sym_arow = c->sym_brow = c->sym_brow1 = c->sym_acc = nullptr;
+    c->sym_tab = nullptr;
+    c->sym_scratch_bytes = 0;
+    c->sym_ready = false;
 }
 
 // which ranks this rank produces reactions for / receives reactions from: the meeting schedule of
@@ -390,82 +320,246 @@ void sym_shard_masks(uint32_t nb, uint32_t world, uint32_t rank, uint32_t &send,
     }
 }
 
+// Does the symmetric kernel apply to this context at all (independent of a step's num_active)?  Unsharded: the
+// whole-N all-pairs step with N >= 1024 (the last block is padded inside the kernel).  Sharded (gather algorithm
+// 4): every rank's slice is whole 1024-body blocks.
+bool sym_applies(const mapn_ctx *c, bool sharded)
+{
+    if (c->cfg.kernel != MAPN_KERNEL_SYMMETRIC && c->cfg.kernel != MAPN_KERNEL_AUTO) return false;
+    if (c->cfg.force_mode != MAPN_FORCE_ALL_PAIRS) return false;
+    const char *off = getenv("MAPN_NO_SYM");
+    if (off && off[0] == '1' && c->cfg.kernel == MAPN_KERNEL_AUTO) return false;
+    if (sharded) return c->cfg.world_size >= 2 && c->count % mapn::SYM_BLOCK == 0 && c->count * (uint32_t)c->cfg.world_size == c->n;
+    return c->cfg.world_size == 1 && c->n >= mapn::SYM_BLOCK;   // (a smaller job does not fill one block: one-sided)
+}
+
+// Build the launch plan and allocate ALL of the symmetric step's scratch: a-rows [blocks][parts][1024], b-rows
+// (unsharded: [N/64][groups of the widest window][64], bounded by MAPN_SYM_MAX_MB -- a step is made in as many windows
+// of partner distance as that takes, so the scratch is O(N); sharded: [N/64][blocks of this rank][64]), head rows,
+// the running sum between windows, the plan tables.  Returns MAPN_OK with sym_ready false (and the reason in sym_note)
+// when the kernel does not apply or -- MAPN_KERNEL_AUTO only -- the memory is not to be had: the one-sided kernel
+// then runs every step.  An explicit MAPN_KERNEL_SYMMETRIC / mapn_set_sym_plan that cannot be honoured is an error.
+int prepare_sym(mapn_ctx *c, bool sharded)
+{
+    release_sym(c);
+    c->sym_note.clear();
+    if (!sym_applies(c, sharded)) return MAPN_OK;
+    const bool must = c->cfg.kernel == MAPN_KERNEL_SYMMETRIC || c->sym_user_plan;
+    const uint32_t nb = (c->n + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK, nbl = sharded ? c->count / mapn::SYM_BLOCK : nb;
+    const uint32_t gsym = (nb - 1u) / 2u + ((nb & 1u) ? 0u : 1u);
+    const char *e = getenv("MAPN_SYM_MAX_MB");
+    const bool simulate_failure = getenv("MAPN_SYM_FAIL_ALLOC") != nullptr;     // tests: behave as if hipMalloc had failed
+    // unsharded: 1 GiB of b-rows by default (1 048 576 bodies: 9 windows, 4 194 304 bodies: 129); sharded: one window, up to 16 GiB
+    const uint64_t cap = (e ? strtoull(e, nullptr, 10) : (sharded ? 16384ull : 1024ull)) << 20;
+    uint32_t gpw = 0;                                                           // symmetric groups per window (0: all in one)
+    if (sharded) {
+        if ((uint64_t)c->n * nbl * 16ull > cap) {
+            c->sym_note = "symmetric kernel (sharded): reaction rows exceed MAPN_SYM_MAX_MB";
+            return must ? fail(MAPN_ERR_INVALID_ARGUMENT, "%s", c->sym_note.c_str()) : MAPN_OK;
+        }
+    } else {
+        const uint64_t per_group = (uint64_t)nb * mapn::SYM_BLOCK * 16ull;
+        const uint64_t fit = std::max<uint64_t>(1, cap / per_group);
+        if (fit < gsym) gpw = (uint32_t)fit;
+    }
+    // shape: 4-wave workgroups (2 waves per SIMD are resident: 248 VGPRs).  Unsharded: about 8192 workgroups per launch
+    // but at most 32 per I-block (65 536 bodies: parts 24 / 32 / 48 / 64 -> 0.663 / 0.647 / 0.669 / 0.675 ms; 262 144: 8 / 32 /
+    // 64 / 128 -> 9.95 / 9.60 / 9.60 / 9.89 ms; 1 048 576: 2 / 8 / 32 / 64 equal within 1 %); few rounds of workgroups
+    // (65 536 .. 131 072 bodies, one window): parts that TAPER 4 : 2 : 1 so that the workgroups dispatched last are a
+    // quarter of the first ones' size (+1.1 % at 65 536, +3.6 % at 100 000).  Sharded: one resident round -- about 512
+    // workgroups, at least 32 per block.
+    uint32_t waves = 4, parts = sharded ? std::max(32u, (512u + nbl - 1u) / nbl) : std::min(32u, std::max(1u, (8192u + nb - 1u) / nb));
+    struct Shape { uint32_t parts, t1, t2; };
+    std::vector<Shape> tries;
+    {
+        unsigned ew = 0, ep = 0, tp = 0, t1 = 0, t2 = 0, eg = 0;
+        const char *pl = getenv(sharded ? "MAPN_SYM_SHARD_PLAN" : "MAPN_SYM_PLAN");     // "waves,parts" tuning override
+        if (pl && sscanf(pl, "%u,%u", &ew, &ep) == 2 && (ew == 4 || ew == 8) && ep >= 1) { waves = ew; parts = ep; }
+        const char *tw = getenv("MAPN_SYM_WINDOW");                                    // groups per window (unsharded)
+        if (tw && !sharded && sscanf(tw, "%u", &eg) == 1 && eg >= 1) gpw = eg >= gsym ? 0u : eg;
+        const char *t = getenv(sharded ? "MAPN_SYM_SHARD_TAPER" : "MAPN_SYM_TAPER");     // "parts,taper1,taper2"; "0" = equal parts
+        if (c->sym_user_plan) {
+            waves = c->sym_user[0]; parts = c->sym_user[1];
+            tries.push_back({parts, c->sym_user[2] + c->sym_user[3] ? c->sym_user[2] : parts, c->sym_user[3]});
+            if (!sharded && c->sym_user[4]) gpw = c->sym_user[4] >= gsym ? 0u : c->sym_user[4];
+        } else if (t && sscanf(t, "%u,%u,%u", &tp, &t1, &t2) == 3 && tp >= 1 && t1 + t2 <= tp) {
+            tries.push_back({tp, t1, t2});
+        } else if (!(t && t[0] == '0') && !pl && !sharded && gpw == 0 && nb >= 64u && nb <= 128u) {
+            tries.push_back({40, 28, 4}); tries.push_back({38, 28, 4}); tries.push_back({36, 28, 4});
+        }
+        if (!c->sym_user_plan)
+            for (uint32_t q = parts; q >= 1u; q = q > 1u ? q / 2u : 0u) tries.push_back({q, q, 0});   // equal parts, halved until every wave has 64 steps
+    }
+    std::string err;
+    bool built = false;
+    for (const Shape &sh : tries)
+        if ((built = mapn::build_sym_plan(nb, gpw, sh.parts, sh.t1, sh.t2, waves, c->sym_plan, err))) break;
+    if (!built) {
+        c->sym_note = err;
+        return must ? fail(MAPN_ERR_INVALID_ARGUMENT, "%s", err.c_str()) : MAPN_OK;
+    }
+    const mapn::SymPlanHost &pl = c->sym_plan;
+    const size_t ab = (size_t)nbl * pl.parts * mapn::SYM_BLOCK * sizeof(float4);
+    const size_t bb = sharded ? (size_t)c->n * nbl * sizeof(float4) : (size_t)nb * mapn::SYM_BLOCK * pl.brows * sizeof(float4);
+    const size_t hb = (size_t)nbl * pl.parts * 64 * sizeof(float4);
+    const size_t cb = pl.windows.size() > 1 ? (size_t)nb * mapn::SYM_BLOCK * sizeof(float4) : 0;
+    const size_t tb = pl.tables.size() * sizeof(uint32_t);
+    hipError_t he = simulate_failure ? hipErrorOutOfMemory : hipSuccess;
+    if (he == hipSuccess) he = hipMalloc(&c->sym_arow, ab);
+    if (he == hipSuccess) he = hipMalloc(&c->sym_brow, bb);
+    if (he == hipSuccess) he = hipMalloc(&c->sym_brow1, hb);
+    if (he == hipSuccess && cb) he = hipMalloc(&c->sym_acc, cb);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&c->sym_tab), tb);
+    if (he == hipSuccess) he = hipMemcpy(c->sym_tab, pl.tables.data(), tb, hipMemcpyHostToDevice);
+    if (he != hipSuccess) {
+        (void)hipGetLastError();
+        release_sym(c);
+        char msg[256];
+        snprintf(msg, sizeof msg, "symmetric kernel: %.1f MiB of scratch could not be allocated (%s); the one-sided kernel runs instead",
+                 (double)(ab + bb + hb + cb + tb) / 1048576.0, hipGetErrorString(he));
+        c->sym_note = msg;
+        if (must) return fail(MAPN_ERR_HIP, "%s", msg);
+        g_last_error = msg;                                // a warning: the call that got here still succeeds
+        return MAPN_OK;
+    }
+    c->sym_scratch_bytes = ab + bb + hb + cb + tb;
+    c->sym_parts = pl.parts; c->sym_waves = pl.waves;
+    c->sym_sharded = sharded;
+    c->sym_ready = true;
+    if (sharded) c->sym_exchange_cap = mapn::sym_shard_exchange_resident_workgroups(c->count, c->cus);
+    return MAPN_OK;
+}
+
+// this STEP: the unsharded symmetric kernel runs the whole-N step with all bodies active
+bool sym_eligible(const mapn_ctx *c, uint32_t active)
+{
+    if (!c->sym_ready || c->sym_sharded || c->plan_forced) return false;
+    if (c->comm || c->external_gather || c->p2p_ready) return false;   // a context wired for an exchange runs the sharded step
+    return active == c->n;
+}
+
+// MAPN_STAMP_DUMP=<file> (development tool): a stamped diagnostic launch of the symmetric kernel also records, per wave,
+// its entry / loop start / loop end / exit times (100 MHz) and where it ran; mapn_measure_clock writes them to the file.
+int timeline_prepare(mapn_ctx *c, size_t nw, mapn::SymArgs &a)
+{
+    if (!c->stamp_next || !getenv("MAPN_STAMP_DUMP")) return MAPN_OK;
+    if (nw > c->timeline_waves) {
+        if (c->timeline_buf) HIP_TRY(hipFree(c->timeline_buf));
+        c->timeline_buf = nullptr; c->timeline_waves = 0;
+        HIP_TRY(hipMalloc(&c->timeline_buf, nw * 48));
+        c->timeline_waves = nw;
+    }
+    HIP_TRY(hipMemsetAsync(c->timeline_buf, 0, nw * 48, c->compute));
+    a.timeline = c->timeline_buf;
+    c->timeline_last = nw;
+    return MAPN_OK;
+}
+
+// the stamp buffer of a diagnostic launch (mapn_measure_clock; never in an ordinary step)
+int stamps_prepare(mapn_ctx *c, size_t nw, mapn::SymArgs &a)
+{
+    if (!c->stamp_next) return MAPN_OK;
+    if (nw > c->stamp_waves) {
+        if (c->stamp_buf) HIP_TRY(hipFree(c->stamp_buf));
+        c->stamp_buf = nullptr; c->stamp_waves = 0;
+        HIP_TRY(hipMalloc(&c->stamp_buf, nw * 16));
+        c->stamp_waves = nw;
+    }
+    HIP_TRY(hipMemsetAsync(c->stamp_buf, 0, c->stamp_waves * 16, c->compute));
+    a.stamps = c->stamp_buf;
+    return timeline_prepare(c, nw, a);
+}
+
+mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t window)
+{
+    const mapn::SymPlanHost &pl = c->sym_plan;
+    mapn::SymArgs a{};
+    a.pos_old = base.pos_old; a.vel_old = base.vel_old; a.pos_new = base.pos_new; a.vel_new = base.vel_new;
+    a.arow = c->sym_arow; a.brow = c->sym_brow; a.brow1 = c->sym_brow1;
+    a.tab = c->sym_tab + window * pl.table_stride;
+    a.n = c->n; a.nb = pl.nb; a.parts = pl.parts; a.nwaves = pl.nwaves; a.max_meetings = pl.max_meetings;
+    a.g0 = pl.windows[window].g0; a.g1 = pl.windows[window].g1;
+    a.brows = pl.brows; a.half_d = pl.half;
+    a.mass = base.mass; a.soft2 = base.soft2; a.dt = base.dt; a.damping = base.damping;
+    static const uint32_t wt = [] { const char *e = getenv("MAPN_SYM_ROW_WT"); return e ? (uint32_t)atoi(e) : 0u; }();   // A/B: write-through rows
+    a.row_wt = wt;
+    return a;
+}
+
+// One step = one force launch + one reduce launch per window of partner distance; the reduce launches carry the
+// running sum from window to window (in a fixed order: bit-reproducible), the last one integrates.
+int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
+{
+    const mapn::SymPlanHost &pl = c->sym_plan;
+    const size_t nwin = pl.windows.size();
+    for (size_t k = 0; k < nwin; k++) {
+        mapn::SymArgs a = sym_args(c, base, k);
+        a.acc_in = k ? c->sym_acc : nullptr;
+        a.acc_out = k + 1 < nwin ? c->sym_acc : nullptr;
+        if (k == 0) { if (int rc = stamps_prepare(c, (size_t)a.nb * pl.nwaves, a)) return rc; }
+        HIP_TRY(mapn::launch_force_sym(a, pl.waves, c->compute));
+        if (timer && nwin == 1) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
+        HIP_TRY(mapn::launch_sym_reduce(a, c->compute));
+    }
+    mapn::ForcePlan p{};
+    p.kind = mapn::KERNEL_SYM; p.k = 2 * mapn::SYM_K2; p.waves = pl.waves; p.sb = pl.parts; p.nseg = 1; p.epi = mapn::EPI_ROWS;
+    c->last_plan = p; c->last_i_count = c->n; c->last_launches = 2 * (uint32_t)nwin;
+    return MAPN_OK;
+}
+
+// Gather algorithm 4: the symmetric step sharded over ranks.
+bool sym_shard_eligible(const mapn_ctx *c, uint32_t active)
+{
+    if (!c->sym_ready || !c->sym_sharded || c->plan_forced) return false;
+    if (!c->p2p_ready || c->gather_algo != 4) return false;
+    return active == c->n;
+}
+
+// do the new positions travel inside the exchange launch (default) or in p2p_gather_kernel behind it (MAPN_SYM_SHARD_PULL=0: A/B)
+bool sym_shard_pull_folded()
+{
+    static const bool folded = [] { const char *e = getenv("MAPN_SYM_SHARD_PULL"); return !(e && e[0] == '0'); }();
+    return folded;
+}
+
 int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
 {
     const uint32_t world = (uint32_t)c->cfg.world_size, rank = (uint32_t)c->cfg.rank;
-    mapn::SymArgs a{};
-    a.pos_old = base.pos_old; a.vel_old = base.vel_old; a.pos_new = base.pos_new; a.vel_new = base.vel_new;
-    a.n = c->n; a.nb = c->n / mapn::SYM_BLOCK;
-    a.half_d = (a.nb & 1u) ? 0u : a.nb / 2u;
-    a.brows = 0;
-    a.mass = base.mass; a.soft2 = base.soft2; a.dt = base.dt; a.damping = base.damping;
+    const mapn::SymPlanHost &pl = c->sym_plan;
+    mapn::SymArgs a = sym_args(c, base, 0);
     a.shard_nbl = c->count / mapn::SYM_BLOCK;
     a.a0 = rank * a.shard_nbl;
-    // about 512 four-wave workgroups fill the chip once (2 per CU); at least 32 per I-block as in the
-    // unsharded launch, never fewer than one whole meeting per wave
-    const uint32_t waves = 4, meetings = mapn::SYM_JPI * (1u + (a.nb - 1u) / 2u);
-    uint32_t parts = std::max(32u, (512u + a.shard_nbl - 1u) / a.shard_nbl);
-    // (65 536 / 8: 64 parts = 512 workgroups = one resident round, 8 or 9 meetings each, 98.7 us.  66 parts would
-    //  give every workgroup 8 meetings but 528 workgroups -- the 16 that do not fit cost a second round: 123 us.)
-    const char *e = getenv("MAPN_SYM_SHARD_PARTS");
-    if (e && atoi(e) > 0) parts = (uint32_t)atoi(e);
-    parts = std::min(parts, std::max(1u, meetings / waves));
-    a.parts = parts; a.taper1 = parts; a.taper2 = 0;
-    {
-        const char *t = getenv("MAPN_SYM_SHARD_TAPER");     // "parts,taper1,taper2" tuning override
-        unsigned tp = 0, t1 = 0, t2 = 0;
-        if (t && sscanf(t, "%u,%u,%u", &tp, &t1, &t2) == 3 && tp >= 1 && t1 + t2 <= tp) { a.parts = parts = tp; a.taper1 = t1; a.taper2 = t2; }
-    }
-    const size_t ab = (size_t)a.shard_nbl * parts * mapn::SYM_BLOCK * sizeof(float4), bb = (size_t)c->n * a.shard_nbl * sizeof(float4);
-    if (ab > c->sym_arow_bytes) {
-        if (c->sym_arow) HIP_TRY(hipFree(c->sym_arow));
-        c->sym_arow = nullptr; c->sym_arow_bytes = 0;
-        HIP_TRY(hipMalloc(&c->sym_arow, ab));
-        c->sym_arow_bytes = ab;
-    }
-    if (bb > c->sym_brow_bytes) {
-        if (c->sym_brow) HIP_TRY(hipFree(c->sym_brow));
-        c->sym_brow = nullptr; c->sym_brow_bytes = 0;
-        HIP_TRY(hipMalloc(&c->sym_brow, bb));
-        c->sym_brow_bytes = bb;
-    }
-    a.arow = c->sym_arow; a.brow = c->sym_brow;
-    if (c->stamp_next) {
-        const size_t nw = (size_t)a.shard_nbl * parts * waves;
-        if (nw > c->stamp_waves) {
-            if (c->stamp_buf) HIP_TRY(hipFree(c->stamp_buf));
-            c->stamp_buf = nullptr; c->stamp_waves = 0;
-            HIP_TRY(hipMalloc(&c->stamp_buf, nw * 16));
-            c->stamp_waves = nw;
-        }
-        HIP_TRY(hipMemsetAsync(c->stamp_buf, 0, c->stamp_waves * 16, c->compute));
-        a.stamps = c->stamp_buf;
-    }
-    HIP_TRY(mapn::launch_force_sym(a, waves, c->compute));
+    if (int rc = stamps_prepare(c, (size_t)a.shard_nbl * pl.nwaves, a)) return rc;
+    HIP_TRY(mapn::launch_force_sym(a, pl.waves, c->compute));
     if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
 
     mapn::SymShardArgs h{};
     h.pos_old = a.pos_old; h.vel_old = a.vel_old; h.pos_new = a.pos_new; h.vel_new = a.vel_new;
-    h.arow = a.arow; h.brow = a.brow;
+    h.arow = a.arow; h.brow = a.brow; h.brow1 = a.brow1; h.tab = a.tab;
+    const bool pull = sym_shard_pull_folded();
     for (uint32_t q = 0; q < world; q++) {
         h.flags_peer[q] = c->p2p_peer_flags[q];
         h.recv_peer[q] = reinterpret_cast<float4 *>(reinterpret_cast<char *>(c->p2p_peer_flags[q]) + mapn::SYM_RECV_OFFSET);
+        // both position buffers live in one heap allocation: the written buffer sits buffer_index * aligned_data_size in
+        h.pos_peer[q] = pull ? reinterpret_cast<const float4 *>(static_cast<char *>(c->p2p_peer_heap[q]) + (size_t)c->buffer_index * c->aligned_data_size) : nullptr;
     }
     h.flags_mine = c->p2p_flags;
     h.recv_mine = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(c->p2p_flags) + mapn::SYM_RECV_OFFSET);
     h.ticket = c->sym_shard_ticket;
     h.status = c->async_status;
     h.rank = rank; h.world = world; h.count = c->count;
-    h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = parts;
+    h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = pl.parts; h.nwaves = pl.nwaves; h.max_meetings = pl.max_meetings;
     h.send_mask = c->sym_send_mask; h.recv_mask = c->sym_recv_mask;
     h.step = ++c->sym_shard_step;
+    h.pos_step = pull ? ++c->p2p_step : 0u;
+    c->step_pulled = pull;
+    h.pull_self = c->p2p_loopback ? 1u : 0u;
     h.timeout_ticks = c->p2p_timeout_ticks;
     h.mass = a.mass; h.dt = a.dt; h.damping = a.damping;
-    HIP_TRY(mapn::launch_sym_shard_exchange(h, c->compute));
+    HIP_TRY(mapn::launch_sym_shard_exchange(h, c->sym_exchange_cap, c->compute));
     mapn::ForcePlan p{};
-    p.kind = mapn::KERNEL_SYM; p.k = 2 * mapn::SYM_K2; p.waves = waves; p.sb = parts; p.nseg = 1; p.epi = mapn::EPI_ROWS;
+    p.kind = mapn::KERNEL_SYM; p.k = 2 * mapn::SYM_K2; p.waves = pl.waves; p.sb = pl.parts; p.nseg = 1; p.epi = mapn::EPI_ROWS;
     c->last_plan = p; c->last_i_count = c->count; c->last_launches = 2;
-    c->sym_parts = parts; c->sym_waves = waves;
     return MAPN_OK;
 }
 
@@ -694,17 +788,14 @@ void drop_graphs(mapn_ctx *c)
 
 // MAPN_FLAG_USE_GRAPH: the step's launches (force [+ reduce/integrate]) are captured once per
 // ping-pong parity and replayed with one hipGraphLaunch.  Scratch memory is sized before the
-// capture (no allocation inside it).  A step that carries timer events runs eagerly.
+// capture (no allocation inside it; the symmetric kernel's was made when the context was created).  A step that carries timer events runs eagerly.
 int enqueue_step_graph(mapn_ctx *c, uint32_t active)
 {
     const uint32_t w = c->buffer_index;
     if (!c->graph_exec[w] || c->graph_active[w] != (int)active) {
         if (c->graph_exec[w]) { (void)hipGraphExecDestroy(c->graph_exec[w]); c->graph_exec[w] = nullptr; }
         const uint32_t lo = c->first, hi = std::min(c->first + c->count, active);
-        if (hi > lo && sym_eligible(c, active) && !c->sym_brow) {
-            return enqueue_step(c, active, nullptr);       // the symmetric step sizes its scratch on first use: that step runs eagerly
-        }
-        if (hi > lo && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS) {
+        if (hi > lo && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS && !sym_eligible(c, active)) {
             mapn::ForcePlan plan = choose_plan(c, hi - lo, c->n, 1, true);
             if (plan.epi != mapn::EPI_FUSED)
                 if (int rc = ensure_partial(c, plan.sb, ((hi - lo) + 63u) & ~63u)) return rc;
@@ -769,6 +860,7 @@ int enqueue_flow_pull(mapn_ctx *c)
 
 int enqueue_gather(mapn_ctx *c)
 {
+    if (c->step_pulled) { c->step_pulled = false; return MAPN_OK; }   // sym_shard_exchange_kernel has published and pulled
     if (c->p2p_ready && c->gather_algo == 3) return enqueue_flow_pull(c);
     if (c->p2p_ready && c->p2p_loopback) return MAPN_OK;   // no peers to pull from
     if (c->p2p_ready && (c->gather_algo == 2 || c->gather_algo == 4)) return enqueue_p2p(c);   // 4: positions travel as in 2
@@ -874,6 +966,9 @@ int create_common(const mapn_config *cfg, mapn_ctx **out)
     // Compute.cpp:434-436: fence created with value 0, m_fenceValue++ -> 1
     c->fence_value = 1;
     if (int rc = alloc_state(c)) return rc;
+    // the symmetric kernel's plan and scratch (unsharded contexts; a sharded one prepares when it is wired for exchange
+    // algorithm 4): made here so that mapn_simulate never allocates
+    if (int rc = prepare_sym(c, false)) return rc;
     // Compute.cpp:563: Initialize ends with WaitForGpu
     return mapn_wait_idle(c);
 }
@@ -990,8 +1085,8 @@ int mapn_destroy(mapn_ctx *c)
     if (c->partial) (void)hipFree(c->partial);
     if (c->ticket) (void)hipFree(c->ticket);
     if (c->stamp_buf) (void)hipFree(c->stamp_buf);
-    if (c->sym_arow) (void)hipFree(c->sym_arow);
-    if (c->sym_brow) (void)hipFree(c->sym_brow);
+    if (c->timeline_buf) (void)hipFree(c->timeline_buf);
+    release_sym(c);
     for (int k = 0; k < kTimerRing; k++) {
         if (c->fence_events[k]) (void)hipEventDestroy(c->fence_events[k]);
         if (c->timers[k].start) (void)hipEventDestroy(c->timers[k].start);
@@ -1469,6 +1564,10 @@ int mapn_set_gather_algorithm(mapn_ctx *c, int algorithm)
         arrived[16] = 0;                                   // tiles_done
         HIP_TRY(hipMemcpy(c->flow_block, arrived, sizeof arrived, hipMemcpyHostToDevice));
     }
+    // algorithm 4: plan and scratch of the sharded symmetric step are made HERE (never inside mapn_simulate); if they
+    // cannot be had under MAPN_KERNEL_AUTO the step runs as algorithm 2 (one-sided kernel + peer-to-peer pull)
+    if (algorithm == 4) { if (int rc = prepare_sym(c, true)) return rc; }
+    else if (c->sym_sharded) release_sym(c);
     c->gather_algo = algorithm;
     return MAPN_OK;
 }
@@ -1525,7 +1624,7 @@ int mapn_p2p_import(mapn_ctx *c, const void *blobs, int count)
     // all its destinations, reduce); the position pull is skipped and only this rank's own row is waited for --
     // the other slices are never refreshed, so results are not a simulation.
     const char *loop = getenv("MAPN_P2P_LOOPBACK");
-    c->p2p_loopback = loop && loop[0] == '1' && c->cfg.rank == 0;
+    c->p2p_loopback = loop && loop[0] == '1';
     for (int q = 0; q < count; q++) {
         if (c->p2p_loopback) { c->p2p_peer_heap[q] = c->pos_heap; c->p2p_peer_flags[q] = c->p2p_flags; continue; }
         P2PBlob b;
@@ -1621,6 +1720,56 @@ int mapn_set_force_plan(mapn_ctx *c, int kernel, uint32_t bodies_per_lane, uint3
     return MAPN_OK;
 }
 
+// ---- the symmetric kernel's launch plan (tuning hook + introspection) ---------------------------------------
+
+int mapn_set_sym_plan(mapn_ctx *c, uint32_t waves, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t groups_per_window)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    if (int rc = mapn_wait_idle(c)) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool sharded = c->cfg.world_size > 1;
+    if (sharded && !(c->p2p_ready && c->gather_algo == 4))
+        return fail(MAPN_ERR_STATE, "set_sym_plan: a sharded context runs the symmetric kernel under gather algorithm 4 only");
+    if (waves == 0 && parts == 0) c->sym_user_plan = false;            // back to the default shape
+    else {
+        if ((waves != 4 && waves != 8) || parts == 0 || taper1 + taper2 > parts)
+            return fail(MAPN_ERR_INVALID_ARGUMENT, "set_sym_plan: waves must be 4 or 8, parts >= 1, taper1 + taper2 <= parts");
+        c->sym_user_plan = true;
+        c->sym_user[0] = waves; c->sym_user[1] = parts; c->sym_user[2] = taper1; c->sym_user[3] = taper2; c->sym_user[4] = groups_per_window;
+    }
+    drop_graphs(c);
+    if (int rc = prepare_sym(c, sharded)) { c->sym_user_plan = false; std::string keep = g_last_error; (void)prepare_sym(c, sharded); g_last_error = keep; return rc; }
+    if (!c->sym_ready) return fail(MAPN_ERR_STATE, "set_sym_plan: the symmetric kernel does not run in this context (%s)", c->sym_note.c_str());
+    return MAPN_OK;
+}
+
+int mapn_get_sym_plan(mapn_ctx *c, mapn_sym_plan_info *info, uint32_t *windows, uint32_t *tables, uint64_t tables_capacity)
+{
+    if (!c || !info) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
+    memset(info, 0, sizeof *info);
+    if (!c->sym_ready) {
+        snprintf(info->error, sizeof info->error, "%s", c->sym_note.empty() ? "the symmetric kernel does not apply to this context" : c->sym_note.c_str());
+        return fail(MAPN_ERR_STATE, "get_sym_plan: %s", info->error);
+    }
+    const mapn::SymPlanHost &p = c->sym_plan;
+    info->nb = p.nb; info->groups = p.groups; info->windows = (uint32_t)p.windows.size();
+    info->parts = p.parts; info->taper1 = p.taper1; info->taper2 = p.taper2; info->waves = p.waves;
+    info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
+    info->a0 = c->sym_sharded ? (uint32_t)c->cfg.rank * (c->count / mapn::SYM_BLOCK) : 0u;
+    info->nbl = c->sym_sharded ? c->count / mapn::SYM_BLOCK : 0u;
+    info->scratch_bytes = c->sym_scratch_bytes;
+    if (windows)
+        for (size_t k = 0; k < p.windows.size(); k++) {
+            windows[4 * k + 0] = p.windows[k].g0; windows[4 * k + 1] = p.windows[k].g1;
+            windows[4 * k + 2] = p.windows[k].meetings[0]; windows[4 * k + 3] = p.windows[k].meetings[1];
+        }
+    if (tables) {
+        if (tables_capacity < p.tables.size()) return fail(MAPN_ERR_INVALID_ARGUMENT, "get_sym_plan: tables_capacity %llu < %zu", (unsigned long long)tables_capacity, p.tables.size());
+        std::copy(p.tables.begin(), p.tables.end(), tables);
+    }
+    return MAPN_OK;
+}
+
 int mapn_set_shard_overlap(mapn_ctx *c, int enabled)
 {
     if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
@@ -1635,6 +1784,13 @@ int mapn_measure_clock(mapn_ctx *c, int steps, mapn_clock_info *out)
     if (!c || !out || steps < 1) return fail(MAPN_ERR_INVALID_ARGUMENT, "measure_clock: bad argument");
     memset(out, 0, sizeof *out);
     if (c->cfg.force_mode != MAPN_FORCE_ALL_PAIRS) return fail(MAPN_ERR_STATE, "measure_clock: all-pairs mode only");
+    {
+        // refuse BEFORE any step is taken: only the scalar-cache and the symmetric force kernels carry the stamps
+        const bool sym = sym_eligible(c, c->n) || sym_shard_eligible(c, c->n);
+        const int kind = c->plan_forced ? c->forced_plan.kind : (c->cfg.kernel == MAPN_KERNEL_LDS ? mapn::KERNEL_LDS : mapn::KERNEL_SGPR);
+        if (!sym && kind != mapn::KERNEL_SGPR)
+            return fail(MAPN_ERR_STATE, "measure_clock: the stamped diagnostic exists for the scalar-cache and the symmetric force kernels only");
+    }
     HIP_TRY(hipSetDevice(c->device));
     c->stamp_next = true;
     int rc = MAPN_OK;
@@ -1649,6 +1805,18 @@ int mapn_measure_clock(mapn_ctx *c, int steps, mapn_clock_info *out)
         : (size_t)((c->last_i_count + 64 * c->last_plan.k - 1) / (64 * c->last_plan.k)) * c->last_plan.sb * c->last_plan.waves;
     std::vector<unsigned long long> h(2 * waves);
     HIP_TRY(hipMemcpy(h.data(), c->stamp_buf, waves * 16, hipMemcpyDeviceToHost));
+    if (const char *dump = getenv("MAPN_STAMP_DUMP")) {
+        if (c->timeline_buf && c->timeline_last && c->last_plan.kind == mapn::KERNEL_SYM) {
+            std::vector<unsigned long long> tl(6 * c->timeline_last);
+            HIP_TRY(hipMemcpy(tl.data(), c->timeline_buf, c->timeline_last * 48, hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(dump, "wb")) {
+                const unsigned long long hdr[4] = {c->timeline_last, c->sym_parts, c->sym_waves, (unsigned long long)c->cfg.rank};
+                fwrite(hdr, 8, 4, f);
+                fwrite(tl.data(), 8, tl.size(), f);
+                fclose(f);
+            }
+        }
+    }
     std::vector<double> ghz, cyc;
     for (size_t w = 0; w < waves; w++)
         if (h[2 * w + 1] > 1000) { ghz.push_back((double)h[2 * w] / (double)h[2 * w + 1] * 0.1); cyc.push_back((double)h[2 * w]); }
@@ -1698,7 +1866,7 @@ int mapn_get_kernel_stats(mapn_ctx *c, int reset, mapn_kernel_stats *out)
     out->epilogue = (uint32_t)p.epi;
     out->force_launches_per_step = c->last_launches ? c->last_launches : 1u;
     if (p.kind == mapn::KERNEL_SYM) {
-        out->force_launches_per_step = c->last_launches > 1 ? c->last_launches - 1u : 1u;   // the last one is the reduce + integrate launch (fused = 0); sharded: + the send kernel
+        out->force_launches_per_step = std::max(1u, c->last_launches / 2u);   // every force launch (one per window of partner distance) is followed by a reduce launch (fused = 0); sharded: by the exchange launch
         out->grid_x = (i_count + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK; out->grid_y = p.sb; out->j_splits = p.sb * p.waves; out->fused = 0; out->epilogue = 3;   // grid (I-blocks, parts)
     }
     if (reset) { c->force_launches = 0; c->force_seconds_sum = 0.0; }

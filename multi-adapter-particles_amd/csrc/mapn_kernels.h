@@ -55,7 +55,8 @@ struct ForcePlan {
     int      epi;      // EPI_*: EPI_FUSED requires sb == 1 and nseg == 1
 };
 
-// The symmetric (Newton's third law) all-pairs step, mapn_sym.hip: whole-N, unsharded, N % SYM_BLOCK == 0.
+// The symmetric (Newton's third law) all-pairs step, mapn_sym.hip.  The launch plan (which steps every wave runs, in how
+// many launches a step is made) is built on the host: mapn_sym_plan.h.
 enum { SYM_K2 = 8,                     // packed pairs of bodies i per lane
        SYM_BLOCK = 128 * SYM_K2,       // bodies per I-block (one wave)
        SYM_JPI = SYM_BLOCK / 64 };     // 64-body J-blocks per I-block
@@ -64,18 +65,25 @@ struct SymArgs {
     const float  *vel_old;
     float4       *pos_new;
     float        *vel_new;
-    float4       *arow;       // [nb][parts][SYM_BLOCK]  force on the bodies of an I-block, one row per workgroup
-    float4       *brow;       // [n / 64][brows][64] reaction on the bodies of a J-block, one row per meeting
+    float4       *arow;       // [blocks of the launch][parts][SYM_BLOCK]  force on the bodies of an I-block, one row per workgroup
+    float4       *brow;       // [n / 64][brows][64] reaction on the bodies of a J-block, one row per meeting (sharded: [n / 64][shard_nbl][64])
+    float4       *brow1;      // [blocks of the launch][parts][64] head rows: the last steps of a meeting that was cut between two workgroups
+    const float4 *acc_in;     // reduce launch: forces summed by the earlier windows of this step (null: none)
+    float4       *acc_out;    // reduce launch: where this window's running sum goes (null: last window -- integrate)
+    const uint32_t *tab;      // this window's tables: bounds[2][nwaves + 1], split[2][max_meetings] (SymPlanHost)
     uint32_t      n, nb;      // bodies, I-blocks of SYM_BLOCK (the last may be padded)
     uint32_t      parts;      // workgroups per I-block (gridDim.y)
-    uint32_t      taper1, taper2;   // part sizes: the first taper1 parts weigh 4, the next taper2 weigh 2, the rest 1 (taper1 = parts: equal parts)
-    uint32_t      brows;      // rows allocated per J-block: (nb - 1) / 2 (+ 1 when nb is even)
+    uint32_t      nwaves;     // parts * waves per workgroup
+    uint32_t      max_meetings;
+    uint32_t      g0, g1;     // meeting groups of this launch: 0 the block itself, 1 .. D partner a + g, D + 1 the half-ring partner
+    uint32_t      brows;      // rows allocated per J-block (symmetric groups of the widest window)
     uint32_t      half_d;     // nb / 2 when nb is even (the half-ring partner), else 0
-    uint32_t      whole_only; // A/B only (MAPN_SYM_PLAN third field): deal whole meetings to waves, none shared
-    uint32_t      a0;         // sharded form: first I-block of this rank (gridDim.y = its nbl blocks); 0 otherwise
-    uint32_t      shard_nbl;  // sharded form: I-blocks of this rank -- brow is [n / 64][shard_nbl][64], one row per (J-block, local I-block); 0 = unsharded
+    uint32_t      a0;         // sharded form: first I-block of this rank (gridDim.x = its shard_nbl blocks); 0 otherwise
+    uint32_t      shard_nbl;  // sharded form: I-blocks of this rank -- brow is one row per (J-block, local I-block); 0 = unsharded
+    uint32_t      row_wt;     // rows are stored write-through (sc1) as they are produced instead of waiting in L2 for the end-of-kernel write-back
     float         mass, soft2, dt, damping;
     unsigned long long *stamps;   // diagnostic launches only (mapn_measure_clock), else null
+    unsigned long long *timeline; // diagnostic launches only (MAPN_STAMP_DUMP): per wave {entry, loop start, loop end, exit (100 MHz), hw id, steps}
 };
 hipError_t launch_force_sym(const SymArgs &a, uint32_t waves, hipStream_t st);
 hipError_t launch_sym_reduce(const SymArgs &a, hipStream_t st);
@@ -84,8 +92,8 @@ hipError_t launch_sym_reduce(const SymArgs &a, hipStream_t st);
 // (force_sym_kernel with a0 / shard_nbl), adds the reactions it produced for every rank's bodies over its
 // I-blocks in ascending order and stores ONE row per destination rank straight into that rank's receive
 // region (remote stores through the hipIpc mapping, then the flag), waits (bounded) for the flags of the
-// ranks that owe it rows and integrates its own bodies from its a-rows plus the rows received
-// (sym_shard_exchange_kernel: one launch).
+// ranks that owe it rows, integrates its own bodies from its a-rows plus the rows received, publishes its
+// new slice and pulls the peers' slices (sym_shard_exchange_kernel: one launch).
 enum { P2P_MAX_RANKS = 16 };          // ranks of a direct peer-to-peer job (one process per GPU, buffers mapped through hipIpc)
 enum { SYM_FLAG_BASE = 16,            // reaction-arrival counters follow the P2P_MAX_RANKS publication counters
        SYM_RECV_OFFSET = 4096 };      // byte offset of the receive region [world][count] float4 inside the flags allocation
@@ -96,20 +104,26 @@ struct SymShardArgs {
     float        *vel_new;
     const float4 *arow;                       // [nbl][parts][SYM_BLOCK]
     const float4 *brow;                       // [n / 64][nbl][64]
+    const float4 *brow1;                      // [nbl][parts][64]
+    const uint32_t *tab;                      // the (single) window's tables
     float4       *recv_peer[P2P_MAX_RANKS];   // rank q's receive region as mapped here: row [sender][body of q]
     uint32_t     *flags_peer[P2P_MAX_RANKS];  // rank q's flag array as mapped here
+    const float4 *pos_peer[P2P_MAX_RANKS];    // rank q's WRITTEN position buffer as mapped here (null: positions travel in another launch)
     const float4 *recv_mine;
     uint32_t     *flags_mine;
-    uint32_t     *ticket;                     // workgroups of the exchange kernel whose sends are acknowledged
+    uint32_t     *ticket;                     // [0] workgroups whose sends are acknowledged, [1] workgroups whose new positions are in memory
     uint32_t     *status;                     // host-visible word: non-zero = a wait timed out
     uint32_t      rank, world, count;         // count = bodies per rank (a multiple of SYM_BLOCK)
-    uint32_t      nb, nbl, a0, half_d, parts;
+    uint32_t      nb, nbl, a0, half_d, parts, nwaves, max_meetings;
     uint32_t      send_mask, recv_mask;       // bit q: this rank produces reactions for / receives reactions from rank q
-    uint32_t      step;                       // monotonically increasing (>= 1)
+    uint32_t      step;                       // monotonically increasing (>= 1): number of the reaction exchange
+    uint32_t      pos_step;                   // publication number of the new positions (the p2p counter; 0: no pull in this launch)
+    uint32_t      pull_self;                  // loopback timing only: the "peers" are this rank, pull from every slot
     uint64_t      timeout_ticks;
     float         mass, dt, damping;
 };
-hipError_t launch_sym_shard_exchange(const SymShardArgs &a, hipStream_t st);
+hipError_t launch_sym_shard_exchange(const SymShardArgs &a, uint32_t max_workgroups, hipStream_t st);
+uint32_t sym_shard_exchange_resident_workgroups(uint32_t count, int cus);   // how many of its workgroups the device holds at once
 
 bool force_plan_supported(const ForcePlan &plan);
 hipError_t launch_force(const ForcePlan &plan, const StepArgs &a, hipStream_t st);

@@ -56,6 +56,20 @@ __device__ __forceinline__ float lane_next(float v, int addr)
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
 }
 
+// A row leaves the wave: rows are read by OTHER workgroups in the next launch, mostly on other XCDs (through memory), so
+// keeping them dirty in this XCD's L2 until the end-of-kernel write-back only lengthens the launch's tail; wt != 0 stores
+// them write-through (sc1) as they are produced.
+typedef float f4r __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_row(float4 *dst, float x, float y, float z, uint32_t wt)
+{
+    if (wt) {
+        const f4r o = {x, y, z, 0.f};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(o) : "memory");
+    } else {
+        *dst = make_float4(x, y, z, 0.f);
+    }
+}
+
 struct SymBodies {
     v2f xi[SYM_K2], yi[SYM_K2], zi[SYM_K2];
     v2f ax[SYM_K2], ay[SYM_K2], az[SYM_K2];
@@ -92,71 +106,36 @@ __device__ __forceinline__ void sym_step(SymBodies &b, float xj, float yj, float
     bx = rx; by = ry; bz = rz;
 }
 
-// one step, ONE-SIDED (the I-block against itself: every ordered pair is met from both sides anyway)
-__device__ __forceinline__ void one_step(SymBodies &b, float xj, float yj, float zj, v2f soft2)
-{
-#pragma unroll
-    for (int k = 0; k < SYM_K2; k++) {
-        const v2f dx = xj - b.xi[k];
-        const v2f dy = yj - b.yi[k];
-        const v2f dz = zj - b.zi[k];
-        v2f d = __builtin_elementwise_fma(dx, dx, soft2);
-        d = __builtin_elementwise_fma(dy, dy, d);
-        d = __builtin_elementwise_fma(dz, dz, d);
-        v2f inv;
-        inv.x = __builtin_amdgcn_rsqf(d.x);
-        inv.y = __builtin_amdgcn_rsqf(d.y);
-        const v2f inv3 = inv * inv * inv;
-        b.ax[k] = __builtin_elementwise_fma(dx, inv3, b.ax[k]);
-        b.ay[k] = __builtin_elementwise_fma(dy, inv3, b.ay[k]);
-        b.az[k] = __builtin_elementwise_fma(dz, inv3, b.az[k]);
-    }
-}
-
 }  // namespace
 
-// grid = (NB, S)   block = 64 * WAVES
-// Workgroup (s, a): I-block a, part s of S of its meetings.  The meetings of an I-block are numbered
-// m = 0 .. M-1: m < 16 -> itself, J-block a*16 + m, one-sided; then 16 per partner block a + d.
-// The workgroup's part is dealt to its waves: whole meetings first, the remainder shared step-wise.  Every wave keeps the I-block's
-// accumulators in registers for all of its meetings; at the end the WAVES copies are combined in LDS
-// in ascending wave order into ONE row arow[a][s][1024]; each symmetric meeting writes ONE row
-// brow[jblock][d-1][64] with the reactions of the J-block's bodies.
+// grid = (I-blocks of the launch, parts)   block = 64 * WAVES
+// Workgroup (la, s) = part s of I-block a = a0 + la.  Which STEPS each of its waves runs comes from the host-built
+// plan (mapn_sym_plan.h): wave v = s * WAVES + w runs the linear steps [bounds[v], bounds[v + 1]) of the block's
+// meetings in this launch (step 64 m + k = step k of meeting m; every wave carries the same cost, at least 64
+// steps).  A wave keeps the I-block's accumulators in registers for all of its steps; at the end the WAVES copies
+// are combined in LDS in ascending wave order into ONE row arow[la][s][1024].  A symmetric meeting run whole by
+// one wave writes its row brow[...][64] directly; a meeting cut between two waves of the workgroup is put together
+// in LDS (first steps + last steps); one cut between two workgroups leaves its first steps in the meeting's row
+// and its last steps in the head row brow1[la][s] of the later workgroup.
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs p)
 {
     __shared__ float comb[WAVES][3][SYM_IB];               // 48 KiB at 4 waves: the two workgroups a CU holds fit
+    __shared__ float edge[2][WAVES][3][64];                // [0] a wave's partial of the meeting its range ENDS in, [1] of the one it STARTS in
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // grid = (I-blocks, parts): dispatch order is part-major -- all blocks' part 0, then part 1, ... -- so that the
-    // LATE workgroups are the small ones when the parts taper (below)
+    // diagnostic launches only (MAPN_STAMP_DUMP): wall-clock stamps of the wave's life; null otherwise
+    unsigned long long tl_entry = 0, tl_loop = 0;
+    if (p.timeline) asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tl_entry));
+    // dispatch order is part-major -- all blocks' part 0, then part 1, ... -- so that the LATE workgroups are the
+    // small ones when the parts taper
     const uint32_t s = blockIdx.y, la = blockIdx.x, a = p.a0 + la;    // a: the I-block in the whole job; la: among this launch's
     const uint32_t nb = p.nb, half = p.half_d;             // half_d = NB/2 when NB is even, else 0
     const uint32_t D = (nb - 1u) / 2u;
-    const uint32_t M = JPI * (1u + D) + ((half && a < half) ? JPI : 0u);
-    // part s of S (even split: the first `rem` parts take one more), then the part's `cnt` meetings to its
-    // waves: q = cnt / WAVES whole meetings each, and the remaining r < WAVES meetings are SHARED -- every
-    // wave runs 64 / WAVES of such a meeting's 64 steps (wave w starts with the J-block rotated by w * SEG
-    // lanes), the waves' partial reactions are added in LDS in ascending wave order.  All waves of the
-    // workgroup finish together (before: a wave with one meeting more kept the other three waiting -- at
-    // 65 536 bodies a quarter of the workgroups ran 5 meeting-times for 4.25 of work).
-    constexpr uint32_t SEG = 64u / WAVES;
-    // Part sizes TAPER: the first taper1 parts weigh 4 units, the next taper2 parts 2, the rest 1 (taper1 = parts:
-    // all equal).  The CUs do not all run at one speed and a launch is only a few rounds of workgroups, so with
-    // equal parts the slots that finish first idle for up to a whole workgroup time at the end (65 536 bodies, 32
-    // equal parts: 11 % of the wave slots empty over the launch); small workgroups LAST keep that tail short.
-    auto units = [&](uint32_t x) {
-        return x <= p.taper1 ? 4u * x : x <= p.taper1 + p.taper2 ? 4u * p.taper1 + 2u * (x - p.taper1) : 4u * p.taper1 + 2u * p.taper2 + (x - p.taper1 - p.taper2);
-    };
-    const uint32_t U = units(p.parts);
-    const uint32_t pm0 = (uint32_t)(((uint64_t)M * units(s)) / U), pm1 = (uint32_t)(((uint64_t)M * units(s + 1u)) / U);
-    const uint32_t cnt = pm1 - pm0;
-    // (p.whole_only: the A/B form -- whole meetings only, the first cnt % WAVES waves take one more)
-    const uint32_t wm0 = pm0 + (uint32_t)(((uint64_t)cnt * w) / WAVES), wm1 = pm0 + (uint32_t)(((uint64_t)cnt * (w + 1u)) / WAVES);
-    const uint32_t q = p.whole_only ? wm1 - wm0 : cnt / WAVES, r = p.whole_only ? 0u : cnt % WAVES, items = q + r;
-    const uint32_t first = p.whole_only ? wm0 : pm0 + w * q, first_shared = pm0 + WAVES * q;
-    __shared__ float part[WAVES - 1][WAVES][3][64];
+    const uint32_t cls = (half && a < half) ? 0u : 1u;     // class 0: the blocks that also run the half-ring group
+    const uint32_t *bounds = p.tab + cls * (p.nwaves + 1u);
+    const uint32_t t0 = bounds[s * WAVES + w], t1 = bounds[s * WAVES + w + 1u];
 
     const float4 *__restrict__ pos = p.pos_old;
     // N need not be a multiple of the block: bodies past the end are stand-ins so far away that
@@ -174,49 +153,53 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     const v2f soft2 = v2f{p.soft2, p.soft2};
     const int next = (int)((lane + 1u) & 63u) * 4;         // ds_bpermute: take the value of lane + 1
 
-    // J-block of meeting m (and whether it is symmetric); the NEXT meeting's bodies are fetched while
-    // the current one is computed (a meeting is ~9 us of a wave's life, a global load ~1-2 us)
-    auto meeting = [&](uint32_t m, uint32_t &jb, uint32_t &d) {
-        const uint32_t grp = m / JPI, t = m % JPI;         // grp 0: own block; grp g: partner a + g (the last may be the half ring)
-        d = grp <= D ? grp : half;
+    // J-block and partner distance of meeting m of this launch (d = 0: the block itself, one-sided)
+    auto meeting = [&](uint32_t m, uint32_t &jb, uint32_t &d, uint32_t &g) {
+        g = p.g0 + m / JPI;
+        d = g <= D ? g : half;
         uint32_t ap = a + d;
         ap = ap >= nb ? ap - nb : ap;
-        jb = ap * JPI + t;
+        jb = ap * JPI + m % JPI;
     };
-    // where the reactions of J-block jb from this I-block go: one row per partner distance, or -- sharded --
-    // one row per I-block of this rank (sym_shard_send_kernel adds them up per destination rank)
-    auto brow_row = [&](uint32_t jb, uint32_t d) -> size_t {
-        return p.shard_nbl ? (size_t)jb * p.shard_nbl + la : (size_t)jb * p.brows + (d - 1u);
+    // where the reactions of J-block jb from this I-block go: one row per group of the launch, or -- sharded --
+    // one row per I-block of this rank (sym_shard_exchange_kernel adds them up per destination rank)
+    auto brow_row = [&](uint32_t jb, uint32_t g) -> size_t {
+        return p.shard_nbl ? (size_t)jb * p.shard_nbl + la : (size_t)jb * p.brows + (g - (p.g0 ? p.g0 : 1u));
     };
     // diagnostic launches only (mapn_measure_clock): stamps around the wave's meetings; null otherwise
     unsigned long long st_c = 0, st_r = 0;
     if (p.stamps) asm volatile("s_memrealtime %0\n s_memtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(st_r), "=s"(st_c));
-    auto item = [&](uint32_t it, uint32_t &jb, uint32_t &d, uint32_t &rot) {
-        meeting(it < q ? first + it : first_shared + (it - q), jb, d);
-        rot = it < q ? 0u : w * SEG;
-    };
-    uint32_t jb = 0, d = 0, rot = 0;
+    uint32_t jb = 0, d = 0, g = 0;
     float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (items) { item(0u, jb, d, rot); pn = body(jb * 64u + ((lane + rot) & 63u)); }
-    for (uint32_t it = 0; it < items; it++) {
-        const uint32_t jb_cur = jb, d_cur = d, rot_cur = rot;
-        const int steps = it < q ? 64 : (int)SEG;
+    // the first piece may start inside a meeting (k0 = t0 % 64 steps of it ran in the previous wave): the lane then
+    // starts with body (lane + k0) % 64; every later piece starts a meeting.  The NEXT piece's bodies are fetched
+    // while the current one is computed (a meeting is ~9 us of a wave's life, a global load ~1-2 us).
+    if (t0 < t1) { meeting(t0 >> 6, jb, d, g); pn = body(jb * 64u + ((lane + t0) & 63u)); }
+    if (p.timeline) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the I-block and the first J-block have arrived
+        asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tl_loop));
+    }
+    for (uint32_t t = t0; t < t1;) {
+        const uint32_t k0 = t & 63u, steps = min(64u - k0, t1 - t), jb_cur = jb, d_cur = d, g_cur = g;
         float xj = pn.x, yj = pn.y, zj = pn.z;
-        if (it + 1u < items) { item(it + 1u, jb, d, rot); pn = body(jb * 64u + ((lane + rot) & 63u)); }
+        t += steps;
+        if (t < t1) {
+            uint32_t lf = lane;
+            asm volatile("" : "+v"(lf));                   // (as below: keep the load's address out of the loops' registers)
+            meeting(t >> 6, jb, d, g);
+            pn = body(jb * 64u + lf);
+        }
         // (Alternatives to moving the position, measured on one box each: a wave-private LDS copy of the J-block
         //  read with one ds_read_b128 per step, also one step ahead: 2-3 % slower; re-reading body (lane + k) % 64
         //  from global memory every step, fetched one step ahead: 9 % slower.)
-        if (d_cur == 0u) {
-#pragma nounroll
-            for (int k = 0; k < steps; k++) {
-                const float nx = lane_next(xj, next), ny = lane_next(yj, next), nz = lane_next(zj, next);
-                one_step(b, xj, yj, zj, soft2);
-                xj = nx; yj = ny; zj = nz;
-            }
-        } else {
+        {
+            // ONE loop for every kind of meeting.  The block against itself (d = 0) needs no reaction -- every ordered pair is met
+            // from both sides anyway -- but runs the same step and drops it: with a second, one-sided loop beside this one the
+            // compiler kept two copies of the accumulators (220 register moves per meeting), ran out of registers and serialised
+            // the step (36 s_nop, 1436 instead of 1183 cycles); those meetings are 16 of ~530, 6 packed fma dearer each.
             v2f bx = v2f{0.f, 0.f}, by = v2f{0.f, 0.f}, bz = v2f{0.f, 0.f};
 #pragma nounroll                                           // (unrolled by two: no loop-carried copies, but the moves issue late: 2 % slower)
-            for (int k = 0; k < steps; k++) {
+            for (uint32_t k = 0; k < steps; k++) {
                 // the travelling position does not change during the step: its move overlaps the step
                 const float nx = lane_next(xj, next), ny = lane_next(yj, next), nz = lane_next(zj, next);
                 sym_step(b, xj, yj, zj, soft2, bx, by, bz);
@@ -224,14 +207,21 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
                 bx.x = lane_next(bx.x, next); by.x = lane_next(by.x, next); bz.x = lane_next(bz.x, next);
                 bx.y = lane_next(bx.y, next); by.y = lane_next(by.y, next); bz.y = lane_next(bz.y, next);
             }
+            if (d_cur == 0u) continue;
             const float fx = bx.x + bx.y, fy = by.x + by.y, fz = bz.x + bz.y;
-            if (it < q) {
+            // (the row addresses are formed HERE, once per meeting, from a lane id the compiler cannot see through: hoisted out
+            //  of the loop they would sit in registers across the steps, and the loop has none to spare -- they were spilled)
+            uint32_t ln = lane;
+            asm volatile("" : "+v"(ln));
+            if (steps == 64u) {
                 // 64 moves: every body is back in its home lane with its complete reaction from this I-block
-                p.brow[brow_row(jb_cur, d_cur) * 64u + lane] = make_float4(fx, fy, fz, 0.f);
+                store_row(p.brow + brow_row(jb_cur, g_cur) * 64u + ln, fx, fy, fz, p.row_wt);
             } else {
-                // SEG moves: this lane holds body (lane + rot + SEG) % 64 with this wave's share of its reaction
-                const uint32_t home = (lane + rot_cur + SEG) & 63u;
-                part[it - q][w][0][home] = fx; part[it - q][w][1][home] = fy; part[it - q][w][2][home] = fz;
+                // part of a meeting: its LAST 64 - k0 steps (the first k0 ran in the previous wave; the bodies are home) go to
+                // this wave's slot [1], its FIRST `steps` steps (the next wave runs the rest; this lane holds body
+                // (lane + steps) % 64) to slot [0]; the closing section puts the meeting together
+                const uint32_t which = k0 != 0u ? 1u : 0u, home = (ln + (k0 != 0u ? 0u : steps)) & 63u;
+                edge[which][w][0][home] = fx; edge[which][w][1][home] = fy; edge[which][w][2][home] = fz;
             }
         }
     }
@@ -244,6 +234,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
             p.stamps[2 * wave] = c1 - st_c;
             p.stamps[2 * wave + 1] = r1 - st_r;
         }
+    }
+    unsigned long long tl_done = 0;
+    if (p.timeline) {
+        asm volatile("" :: "v"(b.ax[0]), "v"(b.ay[0]), "v"(b.az[0]));
+        asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tl_done));
     }
     // combine the WAVES copies of the I-block's accumulators: every wave parks its copy in LDS, then
     // each thread sums one body's WAVES values in ascending wave order (a fixed order: bit-reproducible)
@@ -260,29 +255,66 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
         float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
         for (int ww = 0; ww < WAVES; ww++) { ax += comb[ww][0][e]; ay += comb[ww][1][e]; az += comb[ww][2][e]; }
-        row[e] = make_float4(ax, ay, az, 0.f);
+        store_row(row + e, ax, ay, az, p.row_wt);
     }
-    // the shared meetings' reactions: wave t adds the WAVES shares of shared meeting t in ascending wave order
-    if (w < r) {
-        uint32_t jbs, ds;
-        meeting(first_shared + w, jbs, ds);
+    // a symmetric meeting this wave's range STARTED in: cut between wave w - 1 and this wave -- first steps + last steps make
+    // its row; cut between the previous WORKGROUP and this one (w = 0) -- the last steps are this workgroup's head row
+    if ((t0 & 63u) != 0u && t0 < t1) {
+        uint32_t jbs, ds, gs;
+        meeting(t0 >> 6, jbs, ds, gs);
         if (ds != 0u) {
-            float fx = 0.f, fy = 0.f, fz = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < WAVES; ww++) { fx += part[w][ww][0][lane]; fy += part[w][ww][1][lane]; fz += part[w][ww][2][lane]; }
-            p.brow[brow_row(jbs, ds) * 64u + lane] = make_float4(fx, fy, fz, 0.f);
+            if (w == 0u) {
+                store_row(p.brow1 + ((size_t)la * p.parts + s) * 64u + lane, edge[1][0][0][lane], edge[1][0][1][lane], edge[1][0][2][lane], p.row_wt);
+            } else {
+                const float fx = edge[0][w - 1u][0][lane] + edge[1][w][0][lane];
+                const float fy = edge[0][w - 1u][1][lane] + edge[1][w][1][lane];
+                const float fz = edge[0][w - 1u][2][lane] + edge[1][w][2][lane];
+                store_row(p.brow + brow_row(jbs, gs) * 64u + lane, fx, fy, fz, p.row_wt);
+            }
+        }
+    }
+    // a symmetric meeting the workgroup's LAST wave ended in: the next workgroup runs the rest, its first steps are the row
+    if (w == WAVES - 1u && (t1 & 63u) != 0u && t0 < t1) {
+        uint32_t jbs, ds, gs;
+        meeting(t1 >> 6, jbs, ds, gs);
+        if (ds != 0u)
+            store_row(p.brow + brow_row(jbs, gs) * 64u + lane, edge[0][w][0][lane], edge[0][w][1][lane], edge[0][w][2][lane], p.row_wt);
+    }
+    if (p.timeline) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows have left the wave
+        unsigned long long tl_exit;
+        uint32_t hw, xcc;
+        asm volatile("s_memrealtime %0\n s_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n s_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n s_waitcnt lgkmcnt(0)"
+                     : "=s"(tl_exit), "=s"(hw), "=s"(xcc));
+        if (lane == 0) {
+            unsigned long long *o = p.timeline + 6u * (((size_t)la * p.parts + s) * WAVES + w);
+            o[0] = tl_entry; o[1] = tl_loop; o[2] = tl_done; o[3] = tl_exit; o[4] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+            o[5] = (unsigned long long)(t1 - t0);
         }
     }
 }
 
-// One thread per body: rows of its I-block (role i) in ascending part order, then the rows of its
-// J-block (role j) in ascending partner distance, then mass, kick, damp, drift (hlsl:103-108).
+namespace {
+// the partner distance group under which I-block a meets I-block b symmetrically (b's bodies travelling), 0 if it does not:
+// the schedule of force_sym_kernel
+__device__ __forceinline__ uint32_t sym_group(uint32_t a, uint32_t b, uint32_t nb, uint32_t half)
+{
+    const uint32_t d = b >= a ? b - a : b + nb - a, D = (nb - 1u) / 2u;
+    return (d >= 1u && d <= D) ? d : (half && d == half && a < half) ? D + 1u : 0u;
+}
+}  // namespace
+
+// One thread per body: what the earlier windows of this step summed (if any), the rows of its I-block (role i) in
+// ascending part order, then the rows of its J-block (role j) in ascending group order -- a meeting's row, then its
+// head row when the meeting was cut between two workgroups -- and, in the step's last window, mass, kick, damp,
+// drift (hlsl:103-108).
 __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs p)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= p.n) return;
     const uint32_t a = i / SYM_IB, jb = i >> 6;
     float ax = 0.f, ay = 0.f, az = 0.f;
+    if (p.acc_in) { const float4 v = p.acc_in[i]; ax = v.x; ay = v.y; az = v.z; }
     const float4 *ar = p.arow + (size_t)a * p.parts * SYM_IB + (i - a * SYM_IB);
     uint32_t s = 0;
     for (; s + 8u <= p.parts; s += 8u) {                   // 8 loads in flight (one wave per SIMD: nothing else hides the latency), summed in ascending order
@@ -296,22 +328,32 @@ __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs
         const float4 v = ar[(size_t)s * SYM_IB];
         ax += v.x; ay += v.y; az += v.z;
     }
-    // rows d-1 = 0 .. D-1 always exist; the half-ring row D exists for the blocks that were the far partner
-    const uint32_t D = (p.nb - 1u) / 2u;
-    const uint32_t rows = D + ((p.half_d && a >= p.half_d) ? 1u : 0u);
+    // the symmetric groups of this window; group g's row exists when some block meets this one under g: always for
+    // g <= D, for the half-ring group D + 1 only if this block is the far partner (a >= nb / 2)
+    const uint32_t D = (p.nb - 1u) / 2u, gs0 = p.g0 ? p.g0 : 1u;
+    const uint32_t gend = (p.g1 == D + 2u && !(p.half_d && a >= p.half_d)) ? D + 1u : p.g1;
     const float4 *br = p.brow + (size_t)jb * p.brows * 64u + (i & 63u);
-    uint32_t r = 0;
-    for (; r + 8u <= rows; r += 8u) {                      // 8 loads in flight, summed in ascending order
-        float4 v[8];
+    const uint32_t *split0 = p.tab + 2u * (p.nwaves + 1u), *split1 = split0 + p.max_meetings;
+    const uint32_t t = jb % SYM_JPI;
+    for (uint32_t g = gs0; g < gend; g += 8u) {            // 8 meetings in flight, summed in ascending order
+        float4 v[8], h[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = br[(size_t)(r + u) * 64u];
+        for (uint32_t u = 0; u < 8u; u++) {
+            const uint32_t gu = g + u;
+            const bool live = gu < gend;
+            const uint32_t d = gu <= D ? gu : p.half_d;
+            const uint32_t ap = a >= d ? a - d : a + p.nb - d;                  // the I-block that ran this meeting
+            const uint32_t sp = live ? ((p.half_d && ap < p.half_d) ? split0 : split1)[(gu - p.g0) * SYM_JPI + t] : 0xffffffffu;
+            v[u] = live ? br[(size_t)(gu - gs0) * 64u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            h[u] = sp != 0xffffffffu ? p.brow1[((size_t)ap * p.parts + sp) * 64u + (i & 63u)] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-        for (int u = 0; u < 8; u++) { ax += v[u].x; ay += v[u].y; az += v[u].z; }
+        for (uint32_t u = 0; u < 8u; u++) {
+            ax += v[u].x; ay += v[u].y; az += v[u].z;
+            ax += h[u].x; ay += h[u].y; az += h[u].z;
+        }
     }
-    for (; r < rows; r++) {
-        const float4 v = br[(size_t)r * 64u];
-        ax += v.x; ay += v.y; az += v.z;
-    }
+    if (p.acc_out) { p.acc_out[i] = make_float4(ax, ay, az, 0.f); return; }
     ax *= p.mass; ay *= p.mass; az *= p.mass;
     const float4 pos = p.pos_old[i];
     const float *v = p.vel_old + 3 * (size_t)i;
@@ -334,28 +376,52 @@ __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs
 namespace {
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-// does I-block a meet I-block b symmetrically (b's bodies travelling)?  The schedule of force_sym_kernel.
-__device__ __forceinline__ bool sym_meets(uint32_t a, uint32_t b, uint32_t nb, uint32_t half)
+// write-through store at system scope: once acknowledged (vmcnt) the data is in the owner's memory
+__device__ __forceinline__ void store_sys(float4 *dst, float x, float y, float z, float w)
 {
-    const uint32_t d = b >= a ? b - a : b + nb - a, D = (nb - 1u) / 2u;
-    return (d >= 1u && d <= D) || (half && d == half && a < half);
+    const f4v o = {x, y, z, w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(o) : "memory");
+}
+
+// lanes 0 .. world-1 of the calling wave each wait (bounded) for one counter to reach `need`; returns 1 when all did
+__device__ __forceinline__ uint32_t wait_counters(const uint32_t *counters, uint32_t index, bool need_it, uint32_t need,
+                                                  uint64_t timeout_ticks, uint32_t *status, uint32_t code)
+{
+    uint32_t good = 1u;
+    if (need_it) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while ((int32_t)(__hip_atomic_load(counters + index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - need) < 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+                good = 0u;
+                __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    return __builtin_amdgcn_ballot_w64(good == 0u) == 0ull ? 1u : 0u;
 }
 }  // namespace
 
-// grid <= 1024 workgroups (all co-resident: they wait for each other through the ticket)   block = 256
-// One launch does both halves of the reaction exchange.
+// grid <= the workgroups the device holds at once (they wait for each other through the tickets)   block = 256
+// One launch does the reaction exchange, the integration and the exchange of the new positions.
 //  (1) SEND: for every rank q this rank produced reactions for and every body of q: the rows of this rank's
-//      I-blocks that met the body's block, added in ascending block order, stored as ONE float4 into rank q's
-//      receive region (row [this rank]) with a system-scope write-through store -- over xGMI when q is another
-//      GPU.  Once acknowledged (vmcnt(0)) the stores are in q's memory: no cache write-back is owed (a release
-//      fence here would write back the whole L2, full of this step's rows: measured 10+ us per step).  The
-//      last workgroup through the ticket stores the arrival flags.
-//  (2) REDUCE: lanes 0 .. world-1 of the first wave wait (bounded) for the arrival flags of the ranks that owe
-//      this rank rows; then G threads per body (a rank's slice is small -- 8192 bodies at 65 536 / 8 -- so one
-//      thread per body would leave the rows' loads latency-bound): thread (body, g) adds the a-rows of parts
-//      [g P/G, (g+1) P/G) in ascending order, thread (body, 0) adds the G sums in ascending g, then the rows
-//      received, nearest sender first (this rank, rank - 1, rank - 2, ...), then mass, kick, damp, drift
-//      (hlsl:103-108) -- a fixed order throughout, so the replicas stay bit-identical.
+//      I-blocks that met the body's block (a meeting's row, then its head row if it was cut between two workgroups),
+//      added in ascending block order, stored as ONE float4 into rank q's receive region (row [this rank]) with a
+//      system-scope write-through store -- over xGMI when q is another GPU; the unused .w carries the exchange number,
+//      which the receiver checks.  Once acknowledged (vmcnt(0)) the stores are in q's memory: no cache write-back is
+//      owed (a release fence here would write back the whole L2, full of this step's rows: measured 10+ us per step).
+//  (2) OWN ROWS, before anything is waited for: G threads per body (a rank's slice is small -- 8192 bodies at
+//      65 536 / 8 -- so one thread per body would leave the rows' loads latency-bound): thread (body, g) adds the
+//      a-rows of parts [g P/G, (g+1) P/G) in ascending order.
+//  (3) the last workgroup through ticket[0] stores the arrival flags; lanes 0 .. world-1 of every workgroup's first
+//      wave wait (bounded) for the flags of the ranks that owe this rank rows.
+//  (4) INTEGRATE: thread (body, 0) adds the G sums in ascending g, then the rows received, nearest sender first
+//      (this rank, rank - 1, rank - 2, ...), then mass, kick, damp, drift (hlsl:103-108) -- a fixed order throughout,
+//      so the replicas stay bit-identical.  The new position is stored write-through.
+//  (5) POSITIONS (pos_step != 0; else they travel in p2p_gather_kernel): the last workgroup through ticket[1]
+//      publishes this rank's slice to every peer (the counter p2p_gather_kernel uses); every workgroup waits for the
+//      peers' counters and pulls its share of their slices with cache-bypassing system-scope loads.
 template <int G>
 __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardArgs p)
 {
@@ -363,26 +429,57 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     __shared__ uint32_t ok;
     __shared__ float part[G][3][B];
 
+    const uint32_t *split0 = p.tab + 2u * (p.nwaves + 1u), *split1 = split0 + p.max_meetings;
     const uint32_t total = p.world * p.count;
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
         const uint32_t q = t / p.count, jl = t - q * p.count;
         if (!((p.send_mask >> q) & 1u)) continue;
-        const uint32_t b = t / SYM_BLOCK, jb = t >> 6;     // t is the body's index in the whole job
+        const uint32_t b = t / SYM_BLOCK, jb = t >> 6, tt = jb % SYM_JPI;     // t is the body's index in the whole job
         const float4 *rows = p.brow + (size_t)jb * p.nbl * 64u + (t & 63u);
         float fx = 0.f, fy = 0.f, fz = 0.f;
-        for (uint32_t la = 0; la < p.nbl; la += 8u) {      // eight loads in flight, added in ascending block order
-            float4 v[8];
+        for (uint32_t la = 0; la < p.nbl; la += 8u) {      // eight meetings in flight, added in ascending block order
+            float4 v[8], h[8];
 #pragma unroll
             for (uint32_t u = 0; u < 8u; u++) {
-                const bool met = la + u < p.nbl && sym_meets(p.a0 + la + u, b, p.nb, p.half_d);
-                v[u] = met ? rows[(size_t)(la + u) * 64u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const uint32_t a = p.a0 + la + u;
+                const uint32_t g = la + u < p.nbl ? sym_group(a, b, p.nb, p.half_d) : 0u;
+                const uint32_t sp = g ? ((p.half_d && a < p.half_d) ? split0 : split1)[g * SYM_JPI + tt] : 0xffffffffu;
+                v[u] = g ? rows[(size_t)(la + u) * 64u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                h[u] = sp != 0xffffffffu ? p.brow1[((size_t)(la + u) * p.parts + sp) * 64u + (t & 63u)] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 8u; u++) { fx += v[u].x; fy += v[u].y; fz += v[u].z; }
+            for (uint32_t u = 0; u < 8u; u++) {
+                fx += v[u].x; fy += v[u].y; fz += v[u].z;
+                fx += h[u].x; fy += h[u].y; fz += h[u].z;
+            }
         }
-        const f4v o = {fx, fy, fz, 0.f};
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p.recv_peer[q] + (size_t)p.rank * p.count + jl), "v"(o) : "memory");
+        store_sys(p.recv_peer[q] + (size_t)p.rank * p.count + jl, fx, fy, fz, __builtin_bit_cast(float, p.step));
     }
+
+    // this rank's own rows for the first pass of (4): nothing here depends on a peer
+    const uint32_t bl = threadIdx.x % B, g = threadIdx.x / B;
+    auto own_rows = [&](uint32_t il, float &ax, float &ay, float &az) {
+        ax = ay = az = 0.f;
+        if (il >= p.count) return;
+        const uint32_t la = il / SYM_BLOCK;
+        const float4 *ar = p.arow + (size_t)la * p.parts * SYM_BLOCK + (il - la * SYM_BLOCK);
+        const uint32_t s0 = (uint32_t)(((uint64_t)p.parts * g) / G), s1 = (uint32_t)(((uint64_t)p.parts * (g + 1u)) / G);
+        uint32_t s = s0;
+        for (; s + 8u <= s1; s += 8u) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = ar[(size_t)(s + u) * SYM_BLOCK];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { ax += v[u].x; ay += v[u].y; az += v[u].z; }
+        }
+        for (; s < s1; s++) {
+            const float4 v = ar[(size_t)s * SYM_BLOCK];
+            ax += v.x; ay += v.y; az += v.z;
+        }
+    };
+    float ax, ay, az;
+    own_rows(blockIdx.x * B + bl, ax, ay, az);
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x < 64u) {
@@ -396,47 +493,17 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
             }
         }
         const uint32_t q = threadIdx.x;
-        const bool need = q < p.world && ((p.recv_mask >> q) & 1u);
-        uint32_t good = 1u;
-        if (need) {
-            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-            while ((int32_t)(__hip_atomic_load(p.flags_mine + SYM_FLAG_BASE + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - p.step) < 0) {
-                __builtin_amdgcn_s_sleep(4);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
-                    good = 0u;
-                    __hip_atomic_store(p.status, 1u + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
-                }
-            }
-        }
-        const uint32_t all_good = __builtin_amdgcn_ballot_w64(good == 0u) == 0ull ? 1u : 0u;
+        const uint32_t all_good = wait_counters(p.flags_mine + SYM_FLAG_BASE, q, q < p.world && ((p.recv_mask >> q) & 1u), p.step,
+                                                p.timeout_ticks, p.status, 1u + q);
         if (threadIdx.x == 0) ok = all_good;
     }
     __syncthreads();
     if (!ok) return;
 
-    const uint32_t bl = threadIdx.x % B, g = threadIdx.x / B;
     for (uint32_t base = blockIdx.x * B; base < p.count; base += gridDim.x * B) {
         const uint32_t il = base + bl;
         const bool live = il < p.count;
-        const uint32_t la = live ? il / SYM_BLOCK : 0u;
-        float ax = 0.f, ay = 0.f, az = 0.f;
-        if (live) {
-            const float4 *ar = p.arow + (size_t)la * p.parts * SYM_BLOCK + (il - la * SYM_BLOCK);
-            const uint32_t s0 = (uint32_t)(((uint64_t)p.parts * g) / G), s1 = (uint32_t)(((uint64_t)p.parts * (g + 1u)) / G);
-            uint32_t s = s0;
-            for (; s + 8u <= s1; s += 8u) {
-                float4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = ar[(size_t)(s + u) * SYM_BLOCK];
-#pragma unroll
-                for (int u = 0; u < 8; u++) { ax += v[u].x; ay += v[u].y; az += v[u].z; }
-            }
-            for (; s < s1; s++) {
-                const float4 v = ar[(size_t)s * SYM_BLOCK];
-                ax += v.x; ay += v.y; az += v.z;
-            }
-        }
+        if (base != blockIdx.x * B) own_rows(il, ax, ay, az);
         __syncthreads();                                   // (the previous pass has read `part`)
         part[g][0][bl] = ax; part[g][1][bl] = ay; part[g][2][bl] = az;
         __syncthreads();
@@ -453,14 +520,17 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
             const bool need = k < p.world && ((p.recv_mask >> q) & 1u);
             const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p.recv_mine + (size_t)(need ? q : p.rank) * p.count + il);
             lo[k] = need ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
-            hi[k] = need ? __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+            hi[k] = need ? __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ((unsigned long long)p.step << 32);
         }
+        uint32_t late = 0u;
 #pragma unroll
         for (uint32_t k = 0; k < (uint32_t)P2P_MAX_RANKS; k++) {
             ax += __builtin_bit_cast(float, (uint32_t)lo[k]);
             ay += __builtin_bit_cast(float, (uint32_t)(lo[k] >> 32));
             az += __builtin_bit_cast(float, (uint32_t)hi[k]);
+            if ((uint32_t)(hi[k] >> 32) != p.step) late = 0x100u + k;        // a row that is not this exchange's: flag before data?
         }
+        if (late) __hip_atomic_store(p.status, late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         ax *= p.mass; ay *= p.mass; az *= p.mass;
         const uint32_t i = p.rank * p.count + il;
         const float4 pos = p.pos_old[i];
@@ -469,14 +539,55 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         vx = __builtin_fmaf(ax, p.dt, vx) * p.damping;
         vy = __builtin_fmaf(ay, p.dt, vy) * p.damping;
         vz = __builtin_fmaf(az, p.dt, vz) * p.damping;
-        float4 o;
-        o.x = __builtin_fmaf(vx, p.dt, pos.x);
-        o.y = __builtin_fmaf(vy, p.dt, pos.y);
-        o.z = __builtin_fmaf(vz, p.dt, pos.z);
-        o.w = __builtin_sqrtf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)));
-        p.pos_new[i] = o;
+        store_sys(p.pos_new + i, __builtin_fmaf(vx, p.dt, pos.x), __builtin_fmaf(vy, p.dt, pos.y), __builtin_fmaf(vz, p.dt, pos.z),
+                  __builtin_sqrtf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax))));
         float *vo = p.vel_new + 3 * (size_t)i;
         vo[0] = vx; vo[1] = vy; vo[2] = vz;
+    }
+    if (!p.pos_step) return;
+
+    // (5) this rank's new slice is in memory once every workgroup's stores are acknowledged: then the counter
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < 64u) {
+        if (threadIdx.x == 0) {
+            const uint32_t prev = __hip_atomic_fetch_add(p.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev + 1u == gridDim.x) {
+                __hip_atomic_store(p.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (uint32_t q = 0; q < p.world; q++)
+                    if (q != p.rank || p.pull_self)
+                        __hip_atomic_store(p.flags_peer[q] + p.rank, p.pos_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        const uint32_t q = threadIdx.x;
+        const uint32_t all_good = wait_counters(p.flags_mine, p.pull_self ? p.rank : q, q < p.world && q != p.rank, p.pos_step,
+                                                p.timeout_ticks, p.status, 1u + q);
+        if (threadIdx.x == 0) ok = all_good;
+    }
+    __syncthreads();
+    if (!ok) return;
+    // the peers' slices: 16 bytes per lane per access, eight in flight, past this GPU's caches (a line of q's buffer
+    // cached here two steps ago must not be returned)
+    const uint32_t others = (p.world - 1u) * p.count;
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < others; e += gridDim.x * 256u * 8u) {
+        unsigned long long lo[8], hi[8];
+        uint32_t at[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            const uint32_t eu = e + u * gridDim.x * 256u;
+            const bool live = eu < others;
+            const uint32_t k = live ? eu / p.count : 0u, q = k < p.rank ? k : k + 1u;      // skip self
+            at[u] = live ? q * p.count + (eu - k * p.count) : 0xffffffffu;
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p.pos_peer[q] + (live ? at[u] : 0u));
+            lo[u] = live ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+            hi[u] = live ? __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++)
+            if (at[u] != 0xffffffffu) {
+                unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.pos_new + at[u]);
+                dst[0] = lo[u]; dst[1] = hi[u];
+            }
     }
 }
 
@@ -491,13 +602,32 @@ hipError_t launch_force_sym(const SymArgs &a, uint32_t waves, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_sym_shard_exchange(const SymShardArgs &a, hipStream_t st)
+namespace {
+// enough threads to keep the rows' loads in flight: 8 per body up to 16 384 bodies, 4 up to 65 536, else 1
+int exchange_threads_per_body(uint32_t count) { return count <= 16384u ? 8 : count <= 65536u ? 4 : 1; }
+}  // namespace
+
+// The exchange kernel's workgroups wait for each other (tickets) and for the peers: all of them must be resident at
+// once.  What the device can hold is asked of the runtime (registers, LDS), and half of it is left to whatever else
+// is running (a queued fence wait, the comm stream, another rank's kernels on a shared device).
+uint32_t sym_shard_exchange_resident_workgroups(uint32_t count, int cus)
 {
-    // enough threads to keep the rows' loads in flight: 8 per body up to 16 384 bodies, 4 up to 65 536, else 1;
-    // never more workgroups than are resident together (they wait for each other through the ticket)
-    if (a.count <= 16384u) hipLaunchKernelGGL((sym_shard_exchange_kernel<8>), dim3(std::min(1024u, (a.count + 31u) / 32u)), dim3(256), 0, st, a);
-    else if (a.count <= 65536u) hipLaunchKernelGGL((sym_shard_exchange_kernel<4>), dim3(std::min(1024u, (a.count + 63u) / 64u)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((sym_shard_exchange_kernel<1>), dim3(std::min(1024u, (a.count + 255u) / 256u)), dim3(256), 0, st, a);
+    int per_cu = 0;
+    const int g = exchange_threads_per_body(count);
+    hipError_t e = g == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sym_shard_exchange_kernel<8>, 256, 0)
+                 : g == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sym_shard_exchange_kernel<4>, 256, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sym_shard_exchange_kernel<1>, 256, 0);
+    if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+    return (uint32_t)std::max(1, per_cu * cus / 2);
+}
+
+hipError_t launch_sym_shard_exchange(const SymShardArgs &a, uint32_t max_workgroups, hipStream_t st)
+{
+    const int g = exchange_threads_per_body(a.count);
+    const uint32_t want = (a.count * (uint32_t)g + 255u) / 256u, grid = std::max(1u, std::min(max_workgroups, want));
+    if (g == 8) hipLaunchKernelGGL((sym_shard_exchange_kernel<8>), dim3(grid), dim3(256), 0, st, a);
+    else if (g == 4) hipLaunchKernelGGL((sym_shard_exchange_kernel<4>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((sym_shard_exchange_kernel<1>), dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -1,0 +1,127 @@
+// mapn_sym_plan.cpp -- see mapn_sym_plan.h.  Host only, no HIP.
+#include "mapn_sym_plan.h"
+
+#include <algorithm>
+#include <cstdio>
+
+#include "mapn.h"
+
+namespace mapn {
+
+namespace {
+
+constexpr uint32_t JPI = 16;     // 64-body J-blocks per 1024-body I-block
+
+uint32_t units(uint32_t x, uint32_t t1, uint32_t t2)
+{
+    return x <= t1 ? 4u * x : x <= t1 + t2 ? 4u * t1 + 2u * (x - t1) : 4u * t1 + 2u * t2 + (x - t1 - t2);
+}
+
+}  // namespace
+
+bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t waves,
+                    SymPlanHost &out, std::string &err)
+{
+    char msg[256];
+    if (nb == 0 || parts == 0 || waves == 0 || 64u % waves != 0u || taper1 + taper2 > parts) {
+        snprintf(msg, sizeof msg, "symmetric plan: bad shape nb=%u parts=%u (%u, %u) waves=%u", nb, parts, taper1, taper2, waves);
+        err = msg;
+        return false;
+    }
+    SymPlanHost p;
+    p.nb = nb; p.D = (nb - 1u) / 2u; p.half = (nb & 1u) ? 0u : nb / 2u;
+    const uint32_t gsym = p.D + (p.half ? 1u : 0u);            // symmetric groups 1 .. gsym
+    p.groups = 1u + gsym;
+    p.parts = parts; p.taper1 = taper1; p.taper2 = taper2; p.waves = waves; p.nwaves = parts * waves;
+    // windows: the symmetric groups in nwin runs of (nearly) equal length; the block itself rides in the first
+    const uint32_t cap = groups_per_window ? groups_per_window : std::max(1u, gsym);
+    const uint32_t nwin = std::max(1u, (gsym + cap - 1u) / cap);
+    for (uint32_t k = 0; k < nwin; k++) {
+        SymWindow w{};
+        const uint32_t s0 = 1u + (uint32_t)(((uint64_t)gsym * k) / nwin), s1 = 1u + (uint32_t)(((uint64_t)gsym * (k + 1u)) / nwin);
+        w.g0 = k == 0 ? 0u : s0;
+        w.g1 = s1;
+        const uint32_t ng = w.g1 - w.g0;
+        const bool has_half = p.half && w.g1 == p.groups;
+        w.meetings[0] = JPI * ng;
+        w.meetings[1] = JPI * (has_half ? ng - 1u : ng);
+        p.brows = std::max(p.brows, w.g1 - std::max(w.g0, 1u));
+        p.max_meetings = std::max(p.max_meetings, w.meetings[0]);
+        p.windows.push_back(w);
+    }
+    p.brows = std::max(p.brows, 1u);
+    p.table_stride = 2u * (p.nwaves + 1u) + 2u * p.max_meetings;
+    p.tables.assign((size_t)nwin * p.table_stride, SYM_SPLIT_NONE);
+
+    const uint32_t U = units(parts, taper1, taper2);
+    for (uint32_t k = 0; k < nwin; k++) {
+        const SymWindow &w = p.windows[k];
+        for (uint32_t cls = 0; cls < 2; cls++) {
+            uint32_t *bounds = p.tables.data() + (size_t)k * p.table_stride + cls * (p.nwaves + 1u);
+            uint32_t *split = p.tables.data() + (size_t)k * p.table_stride + 2u * (p.nwaves + 1u) + cls * p.max_meetings;
+            const uint32_t M = w.meetings[cls], L = 64u * M;
+            const uint32_t Ls = (w.g0 == 0u && M) ? 64u * JPI : 0u;        // steps of the block against itself (weighted by SYM_COST_SELF)
+            const uint64_t ctot = (uint64_t)SYM_COST_SELF * Ls + (uint64_t)SYM_COST_SYM * (L - Ls);
+            for (uint32_t v = 0; v <= p.nwaves; v++) {
+                const uint32_t s = v / waves, ww = v % waves;
+                const uint64_t num = (uint64_t)units(s, taper1, taper2) * waves +
+                                     (s < parts ? (uint64_t)(units(s + 1u, taper1, taper2) - units(s, taper1, taper2)) * ww : 0u);
+                const uint64_t target = ctot * num / ((uint64_t)U * waves);   // cost that lies before wave v
+                bounds[v] = target <= (uint64_t)SYM_COST_SELF * Ls ? (uint32_t)(target / SYM_COST_SELF)
+                                                                   : Ls + (uint32_t)((target - (uint64_t)SYM_COST_SELF * Ls) / SYM_COST_SYM);
+            }
+            if (bounds[0] != 0u || bounds[p.nwaves] != L) { err = "symmetric plan: internal error (bounds do not span the meetings)"; return false; }
+            for (uint32_t v = 0; v < p.nwaves && L; v++) {
+                if (bounds[v + 1u] - bounds[v] < 64u) {
+                    snprintf(msg, sizeof msg, "symmetric plan: wave %u of window %u would run %u steps (< 64): %u meetings are too few for %u x %u waves (taper %u, %u)",
+                             v, k, bounds[v + 1u] - bounds[v], M, parts, waves, taper1, taper2);
+                    err = msg;
+                    return false;
+                }
+            }
+            // cut meetings: the wave holding the first step and the wave holding the last
+            uint32_t v = 0;
+            for (uint32_t m = 0; m < M; m++) {
+                split[m] = SYM_SPLIT_NONE;
+                while (bounds[v + 1u] <= 64u * m) v++;                      // wave holding step 64 m
+                uint32_t vb = v;
+                while (bounds[vb + 1u] <= 64u * m + 63u) vb++;              // wave holding step 64 m + 63
+                if (vb > v + 1u) { err = "symmetric plan: internal error (a meeting cut twice)"; return false; }
+                const bool symmetric = w.g0 + m / JPI >= 1u;
+                if (symmetric && vb != v && vb / waves != v / waves) split[m] = vb / waves;
+            }
+        }
+    }
+    out = std::move(p);
+    return true;
+}
+
+}  // namespace mapn
+
+// ---- C ABI: the plan as data, without a device (tests, the order-matched oracle) ------------------
+extern "C" int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2,
+                                      uint32_t waves, mapn_sym_plan_info *info, uint32_t *windows, uint32_t *tables, uint64_t tables_capacity)
+{
+    if (!info) return MAPN_ERR_INVALID_ARGUMENT;
+    mapn::SymPlanHost p;
+    std::string err;
+    if (!mapn::build_sym_plan(nb, groups_per_window, parts, taper1, taper2, waves, p, err)) {
+        snprintf(info->error, sizeof info->error, "%s", err.c_str());
+        return MAPN_ERR_INVALID_ARGUMENT;
+    }
+    info->error[0] = 0;
+    info->nb = p.nb; info->groups = p.groups; info->windows = (uint32_t)p.windows.size();
+    info->parts = p.parts; info->taper1 = p.taper1; info->taper2 = p.taper2; info->waves = p.waves;
+    info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
+    info->a0 = 0; info->nbl = 0;
+    if (windows)
+        for (size_t k = 0; k < p.windows.size(); k++) {
+            windows[4 * k + 0] = p.windows[k].g0; windows[4 * k + 1] = p.windows[k].g1;
+            windows[4 * k + 2] = p.windows[k].meetings[0]; windows[4 * k + 3] = p.windows[k].meetings[1];
+        }
+    if (tables) {
+        if (tables_capacity < p.tables.size()) return MAPN_ERR_INVALID_ARGUMENT;
+        std::copy(p.tables.begin(), p.tables.end(), tables);
+    }
+    return MAPN_OK;
+}

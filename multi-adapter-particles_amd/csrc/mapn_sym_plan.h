@@ -1,0 +1,56 @@
+// mapn_sym_plan.h -- host-side launch plan of the symmetric all-pairs step (mapn_sym.hip): which meetings
+// every wave runs, cut to the STEP so that all waves of a launch carry the same cost, and in how many
+// launches ("windows" of partner distance) a step is made so that the reaction scratch stays O(N).
+// Plain C++ (no HIP): built once when the context is created / wired for an exchange, uploaded as tables the
+// kernels read, exported through the C ABI (mapn_sym_plan_describe) so that the CPU tests check its
+// combinatorics and the order-matched oracle restates the device's summation order from the SAME tables.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace mapn {
+
+constexpr uint32_t SYM_SPLIT_NONE = 0xffffffffu;
+constexpr uint32_t SYM_COST_SELF = 6, SYM_COST_SYM = 6;   // relative cost of a step of a block against itself / of a symmetric step: the kernel
+                                                           // runs ONE loop for both (see force_sym_kernel), so they cost the same
+
+// Meetings of I-block a (1024 bodies) are numbered by GROUP g and J-block t (16 per group, 64 bodies each):
+//   g = 0: the block itself, one-sided;  g = 1 .. D = (nb - 1) / 2: partner block a + g (mod nb), symmetric;
+//   g = D + 1 (even nb only): the half-ring partner a + nb / 2, run by the blocks a < nb / 2 alone.
+// CLASS 0 = the blocks that have the half-ring group, class 1 = the others (all blocks when nb is odd).
+// A WINDOW is one force launch: the groups [g0, g1).  Inside a window meeting m = (g - g0) * 16 + t, step k of
+// meeting m has the linear index 64 m + k, and wave v = part * waves + wave-in-workgroup runs the steps
+// [bounds[v], bounds[v + 1]) -- every wave at least 64 of them, so a meeting is cut at most once:
+//   * cut between two waves of ONE workgroup: the two partial reactions are added in LDS (first steps + last steps);
+//   * cut between two workgroups: the first steps go to the meeting's row, the last steps to the head row
+//     brow1[I-block][split[class][m]] (split = the later workgroup's part index, SYM_SPLIT_NONE otherwise), and
+//     whoever sums the rows adds row, then head row.
+struct SymWindow {
+    uint32_t g0, g1;
+    uint32_t meetings[2];        // per class
+};
+
+struct SymPlanHost {
+    uint32_t nb = 0, D = 0, half = 0;        // half = nb / 2 when nb is even, else 0
+    uint32_t groups = 0;                     // 1 + D (+ 1 when nb is even)
+    uint32_t parts = 0, taper1 = 0, taper2 = 0, waves = 0;
+    uint32_t nwaves = 0;                     // parts * waves
+    uint32_t brows = 0;                      // reaction-row slots per J-block and window (most symmetric groups in one window)
+    uint32_t max_meetings = 0;               // most meetings of a block in one window
+    uint32_t table_stride = 0;               // uint32 per window: bounds[2][nwaves + 1], split[2][max_meetings]
+    std::vector<SymWindow> windows;
+    std::vector<uint32_t> tables;            // windows.size() * table_stride
+
+    const uint32_t *bounds(size_t window, uint32_t cls) const { return tables.data() + window * table_stride + cls * (nwaves + 1); }
+    const uint32_t *split(size_t window, uint32_t cls) const { return tables.data() + window * table_stride + 2 * (nwaves + 1) + cls * max_meetings; }
+};
+
+// groups_per_window: most SYMMETRIC groups one launch may hold (0 = all in one launch).  parts workgroups per
+// I-block whose sizes taper 4 : 2 : 1 (the first taper1 parts weigh 4, the next taper2 weigh 2, the rest 1;
+// taper1 = parts: equal parts).  Fails (false + err) when a wave would get fewer than 64 steps.
+bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t waves,
+                    SymPlanHost &out, std::string &err);
+
+}  // namespace mapn

@@ -82,37 +82,30 @@ def sym_meetings(nb: int):
 
 
 def sym_reaction_rows(nb: int, block: int) -> list[int]:
-    """Row slots (d - 1) the reduce kernel sums for a J-block lying in I-block `block`."""
+    """Groups g - 1 (g = 1 .. D, D + 1 = the half-ring group) whose rows the reduce kernel sums for a J-block lying in
+    I-block `block`, over all windows of a step."""
     D = (nb - 1) // 2
     half = nb // 2 if nb % 2 == 0 else 0
     return list(range(D + (1 if half and block >= half else 0)))
 
 
-def sym_part_bounds(meetings: int, parts: int, taper1: int | None = None, taper2: int = 0) -> list[int]:
-    """First meeting of every part (and the end): the first `taper1` parts weigh 4 units, the next `taper2`
-    weigh 2, the rest 1 (force_sym_kernel's `units`); taper1 = parts (the default) = equal parts."""
-    t1 = parts if taper1 is None else taper1
+def sym_wave_pieces(plan, window: int, cls: int):
+    """How force_sym_kernel walks a block's meetings: yields (part, wave in the workgroup, meeting of the window, first
+    step, steps) for every piece of every wave, from the host-built plan tables (`plan`: mapn.SymPlan -- the tables the
+    kernel itself reads).  Wave v runs the linear steps [bounds[v], bounds[v + 1]); step 64 m + k is step k of meeting m."""
+    b = plan.bounds(window, cls)
+    for v in range(plan.nwaves):
+        t, t1 = int(b[v]), int(b[v + 1])
+        while t < t1:
+            k0 = t & 63
+            n = min(64 - k0, t1 - t)
+            yield v // plan.waves, v % plan.waves, t >> 6, k0, n
+            t += n
 
-    def units(x):
-        return 4 * x if x <= t1 else 4 * t1 + 2 * (x - t1) if x <= t1 + taper2 else 4 * t1 + 2 * taper2 + (x - t1 - taper2)
-    total = units(parts)
-    return [meetings * units(s) // total for s in range(parts + 1)]
 
-
-def sym_wave_items(meetings: int, parts: int, waves: int, taper1: int | None = None, taper2: int = 0):
-    """How force_sym_kernel deals the M meetings of an I-block: yields (part, wave, meeting, first lane
-    rotation, steps).  A part's meetings go to its waves whole (q = cnt // waves each); the remaining
-    cnt % waves meetings are shared, every wave running 64 // waves of the 64 steps from a rotated start."""
-    seg = 64 // waves
-    bounds = sym_part_bounds(meetings, parts, taper1, taper2)
-    for s in range(parts):
-        pm0, pm1 = bounds[s], bounds[s + 1]
-        q, r = divmod(pm1 - pm0, waves)
-        for w in range(waves):
-            for it in range(q):
-                yield s, w, pm0 + w * q + it, 0, 64
-            for t in range(r):
-                yield s, w, pm0 + waves * q + t, w * seg, seg
+def sym_block_class(nb: int, a: int) -> int:
+    """0: the block also runs the half-ring group (even nb, a < nb / 2); 1: the others."""
+    return 0 if nb % 2 == 0 and a < nb // 2 else 1
 
 
 def sym_shard_masks(nb: int, world: int, rank: int) -> tuple[int, int]:

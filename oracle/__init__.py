@@ -46,6 +46,23 @@ class SumSpec(C.Structure):
         super().__init__(mode, waves, sb)
 
 
+class SymShape(C.Structure):
+    """Shape of the device's SYMMETRIC launch plan (include/mapn.h, mapn_sym_plan_info) for the order-matched
+    restatement of that kernel (mapn_oracle.c, ORDER_MATCHED_SYM)."""
+
+    _fields_ = [(k, C.c_uint32) for k in ("nb", "groups", "windows", "parts", "waves", "brows", "max_meetings", "table_stride")]
+
+
+def sym_plan_args(plan):
+    """(SymShape, windows, tables) from a plan object as the product's binding returns it (duck-typed: attributes
+    nb, groups, parts, waves, brows, max_meetings, table_stride and the uint32 arrays windows [k, 4], tables)."""
+    win = np.ascontiguousarray(plan.windows, np.uint32)
+    tab = np.ascontiguousarray(plan.tables, np.uint32)
+    shape = SymShape(plan.nb, plan.groups, win.shape[0], plan.parts, plan.waves, plan.brows, plan.max_meetings, plan.table_stride)
+    assert tab.size == win.shape[0] * plan.table_stride
+    return shape, win, tab
+
+
 def build(force: bool = False) -> str:
     """Compile the C restatement (gcc is in the image on both the CPU and the GPU box)."""
     stale = (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(_SRC)
@@ -69,6 +86,9 @@ class Oracle:
         lib.mapn_oracle_step_all_pairs.restype = C.c_int
         lib.mapn_oracle_step_all_pairs_ex.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int, C.POINTER(SumSpec)]
         lib.mapn_oracle_step_all_pairs_ex.restype = C.c_int
+        _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+        lib.mapn_oracle_step_all_pairs_sym.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.POINTER(Params), C.c_int, C.POINTER(SymShape), _u32p, _u32p]
+        lib.mapn_oracle_step_all_pairs_sym.restype = C.c_int
         lib.mapn_oracle_step_all_pairs_f64.argtypes = [_f64p, _f64p, _f64p, _f64p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int]
         lib.mapn_oracle_step_all_pairs_f64.restype = C.c_int
         lib.mapn_oracle_accel_all_pairs.argtypes = [_f32p, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
@@ -169,9 +189,10 @@ class OracleSim:
     """Host-array twin of the reference's ``Compute`` object: two ping-pong buffer pairs, a
     buffer index and ``simulate(num_active)`` with Compute.cpp:1009-1055 semantics."""
 
-    def __init__(self, oracle: Oracle, pos, vel, mode=MODE_ALL_PAIRS, params=None, threads=0, sum_spec=None):
+    def __init__(self, oracle: Oracle, pos, vel, mode=MODE_ALL_PAIRS, params=None, threads=0, sum_spec=None, sym_plan=None):
         self.o = oracle
         self.sum_spec = sum_spec            # diagnostic summation variant (all-pairs, num_active = N only)
+        self.sym = sym_plan_args(sym_plan) if sym_plan is not None else None   # ... or the symmetric kernel's order (ORDER_MATCHED_SYM)
         self.n = pos.shape[0]
         self.pos = [np.array(pos, np.float32, order="C"), np.array(pos, np.float32, order="C")]   # Compute.cpp:881-882
         self.vel = [np.array(vel, np.float32, order="C"), np.array(vel, np.float32, order="C")]   # Compute.cpp:903-904
@@ -180,6 +201,16 @@ class OracleSim:
 
     def simulate(self, num_active=None, steps=1):
         num_active = self.n if num_active is None else num_active
+        if self.sym is not None:
+            assert self.mode == MODE_ALL_PAIRS and self.o.active_bodies(num_active, self.n) == self.n
+            shape, win, tab = self.sym
+            for _ in range(steps):
+                w, r = self.buffer_index, 1 - self.buffer_index
+                rc = self.o.lib.mapn_oracle_step_all_pairs_sym(self.pos[r], self.vel[r], self.pos[w], self.vel[w], self.n,
+                                                               C.byref(self.params), self.threads, C.byref(shape), win, tab)
+                assert rc == 0, rc
+                self.buffer_index = 1 - self.buffer_index
+            return
         if self.sum_spec is not None and self.mode == MODE_ALL_PAIRS:
             active = self.o.active_bodies(num_active, self.n)
             for _ in range(steps):

@@ -726,3 +726,253 @@ void mapn_oracle_initial_state(uint32_t seed, uint32_t n, float spread, float sp
 {
     mapn_oracle_initial_state_ex(0, seed, n, spread, speed, pos4, vel3);
 }
+
+/* =================================================================================================
+ * ORDER_MATCHED_SYM -- the summation order and operation fusion of the device's SYMMETRIC kernel
+ * (multi-adapter-particles_amd/csrc/mapn_sym.hip), the kernel the bench runs by default.  Diagnostic
+ * like ORDER_MATCHED above: it does not restate the reference (whose pair term, nBodyGravityCS.hlsl:44-57,
+ * is evaluated here once per UNORDERED pair and fed to both bodies); what is left between this mode and
+ * the device is v_rsq_f32 vs 1/sqrtf alone.
+ *
+ * The launch plan is DATA handed in by the test (include/mapn.h: mapn_get_sym_plan /
+ * mapn_sym_plan_describe): windows[k] = {g0, g1, meetings of a class-0 block, of a class-1 block};
+ * per window bounds[2][parts * waves + 1] and split[2][max_meetings].  Restated, in the device's order:
+ *   * blocks of 1024 bodies (the last padded with stand-ins at 3e18 that exert and feel nothing); group g of
+ *     block a: 0 = a itself (one-sided), 1..D = partner a + g, D + 1 = the half-ring partner (class 0 only);
+ *     meeting m of a window = group g0 + m / 16, 64-body J-block m % 16 of the partner;
+ *   * wave v = part * waves + w runs the linear steps [bounds[v], bounds[v + 1]) (step 64 m + k); lane l owns the
+ *     16 bodies a * 1024 + c * 64 + l (c = 0..15) with ONE fma chain each over all of the wave's steps; at step k of
+ *     a piece that began with rotation k0 lane l meets J-body (l + k0 + k) % 64:
+ *         d = fma(dz,dz, fma(dy,dy, fma(dx,dx, soft2))); inv3 = (inv*inv)*inv; a_i = fma(dx, inv3, a_i)
+ *     and the travelling body collects r = fma(-dx, inv3, r) in TWO chains (even c / odd c), visiting c ascending;
+ *     a piece's reaction is the sum of the two chains;
+ *   * a-row of (block, part) = ((0 + wave 0) + wave 1) + ...; a cut meeting inside one workgroup = first steps + last
+ *     steps; cut between two workgroups: first steps in the meeting's row, last steps in the head row;
+ *   * per body and window: running sum so far, a-rows in ascending part order, then per group ascending the
+ *     meeting's row and its head row (zeros where there is none, padded to batches of eight like the device);
+ *     after the last window: total * mass, fused integrator.
+ * ================================================================================================= */
+typedef struct {
+    uint32_t nb, groups, windows, parts, waves, brows, max_meetings, table_stride;
+} mapn_oracle_sym_shape;
+
+#define SYM_IB 1024u
+#define SYM_JPI 16u
+#define SYM_NONE 0xffffffffu
+
+typedef struct {
+    const float *old_pos, *old_vel;
+    float *new_pos, *new_vel;
+    uint32_t n;
+    const mapn_oracle_params *p;
+    const mapn_oracle_sym_shape *sh;
+    const uint32_t *win;        /* this window: g0, g1, m0, m1 */
+    const uint32_t *tab;        /* this window's tables */
+    float *arow, *brow, *brow1; /* [nb][parts][3][1024], [nb*16][brows][3][64], [nb][parts][3][64] */
+    float *acc;                 /* [3][nb*1024] running sum between windows */
+    int first_window, last_window;
+    uint32_t tid, nthreads;
+} sym_job;
+
+static inline void sym_body(const sym_job *J, uint32_t i, float *x, float *y, float *z)
+{
+    if (i < J->n) { *x = J->old_pos[4 * (size_t)i]; *y = J->old_pos[4 * (size_t)i + 1]; *z = J->old_pos[4 * (size_t)i + 2]; }
+    else { *x = 3.0e18f; *y = 3.0e18f; *z = 3.0e18f; }
+}
+
+/* one workgroup (block a, part s): all its waves, then the combination */
+__attribute__((target_clones("avx512f", "fma", "default")))
+static void sym_workgroup(const sym_job *J, uint32_t a, uint32_t s, float *scratch)
+{
+    const mapn_oracle_sym_shape *sh = J->sh;
+    const uint32_t nb = sh->nb, D = (nb - 1u) / 2u, half = (nb & 1u) ? 0u : nb / 2u, W = sh->waves;
+    const uint32_t g0 = J->win[0];
+    const uint32_t cls = (half && a < half) ? 0u : 1u;
+    const uint32_t *bounds = J->tab + cls * (sh->parts * W + 1u);
+    const float soft2 = J->p->soft2;
+    float *xi = scratch, *yi = xi + SYM_IB, *zi = yi + SYM_IB;          /* the I-block */
+    float *accw = zi + SYM_IB;                                           /* [W][3][1024] */
+    float *edge = accw + (size_t)W * 3u * SYM_IB;                        /* [2][W][3][64] */
+    for (uint32_t e = 0; e < SYM_IB; e++) sym_body(J, a * SYM_IB + e, &xi[e], &yi[e], &zi[e]);
+    for (uint32_t w = 0; w < W; w++) {
+        float *ax = accw + (size_t)w * 3u * SYM_IB, *ay = ax + SYM_IB, *az = ay + SYM_IB;
+        for (uint32_t e = 0; e < SYM_IB; e++) ax[e] = ay[e] = az[e] = 0.0f;
+        const uint32_t t0 = bounds[s * W + w], t1 = bounds[s * W + w + 1u];
+        for (uint32_t t = t0; t < t1;) {
+            const uint32_t k0 = t & 63u, steps = (64u - k0 < t1 - t) ? 64u - k0 : t1 - t, m = t >> 6;
+            const uint32_t g = g0 + m / SYM_JPI, d = g <= D ? g : half;
+            const uint32_t ap = (a + d) % nb, jb = ap * SYM_JPI + m % SYM_JPI;
+            float xj[64], yj[64], zj[64], rxe[64], rye[64], rze[64], rxo[64], ryo[64], rzo[64];
+            for (uint32_t l = 0; l < 64; l++) {
+                sym_body(J, jb * 64u + ((l + k0) & 63u), &xj[l], &yj[l], &zj[l]);
+                rxe[l] = rye[l] = rze[l] = rxo[l] = ryo[l] = rzo[l] = 0.0f;
+            }
+            for (uint32_t k = 0; k < steps; k++) {
+                for (uint32_t c = 0; c < 16; c++) {
+                    const float *cx = xi + c * 64u, *cy = yi + c * 64u, *cz = zi + c * 64u;
+                    float *bx = ax + c * 64u, *by = ay + c * 64u, *bz = az + c * 64u;
+                    float *rx = (c & 1u) ? rxo : rxe, *ry = (c & 1u) ? ryo : rye, *rz = (c & 1u) ? rzo : rze;
+#pragma GCC ivdep
+                    for (int l = 0; l < 64; l++) {
+                        const float dx = xj[l] - cx[l], dy = yj[l] - cy[l], dz = zj[l] - cz[l];
+                        float dd = __builtin_fmaf(dx, dx, soft2);
+                        dd = __builtin_fmaf(dy, dy, dd);
+                        dd = __builtin_fmaf(dz, dz, dd);
+                        const float inv = 1.0f / sqrtf(dd);
+                        const float inv3 = inv * inv * inv;
+                        bx[l] = __builtin_fmaf(dx, inv3, bx[l]);
+                        by[l] = __builtin_fmaf(dy, inv3, by[l]);
+                        bz[l] = __builtin_fmaf(dz, inv3, bz[l]);
+                        if (d != 0u) {
+                            rx[l] = __builtin_fmaf(-dx, inv3, rx[l]);
+                            ry[l] = __builtin_fmaf(-dy, inv3, ry[l]);
+                            rz[l] = __builtin_fmaf(-dz, inv3, rz[l]);
+                        }
+                    }
+                }
+                /* everything that travels moves one lane on: lane l takes what lane l + 1 held */
+                const float fx = xj[0], fy = yj[0], fz = zj[0], a0 = rxe[0], a1 = rye[0], a2 = rze[0], b0 = rxo[0], b1 = ryo[0], b2 = rzo[0];
+                for (int l = 0; l < 63; l++) {
+                    xj[l] = xj[l + 1]; yj[l] = yj[l + 1]; zj[l] = zj[l + 1];
+                    rxe[l] = rxe[l + 1]; rye[l] = rye[l + 1]; rze[l] = rze[l + 1];
+                    rxo[l] = rxo[l + 1]; ryo[l] = ryo[l + 1]; rzo[l] = rzo[l + 1];
+                }
+                xj[63] = fx; yj[63] = fy; zj[63] = fz; rxe[63] = a0; rye[63] = a1; rze[63] = a2; rxo[63] = b0; ryo[63] = b1; rzo[63] = b2;
+            }
+            t += steps;
+            if (d == 0u) continue;
+            /* where the piece's reactions go (force_sym_kernel) */
+            const size_t row = sh->brows ? ((size_t)jb * sh->brows + (g - (g0 ? g0 : 1u))) : 0;
+            float *r0 = J->brow + row * 192u, *h0 = J->brow1 + ((size_t)a * sh->parts + s) * 192u;
+            for (uint32_t l = 0; l < 64; l++) {
+                const float qx = rxe[l] + rxo[l], qy = rye[l] + ryo[l], qz = rze[l] + rzo[l];
+                if (steps == 64u) { r0[l] = qx; r0[64 + l] = qy; r0[128 + l] = qz; }
+                else if (k0 != 0u) {                                     /* the meeting's last steps: bodies are home */
+                    float *dst = w == 0u ? h0 : edge + ((size_t)(1u * W + w) * 3u) * 64u;
+                    dst[l] = qx; dst[64 + l] = qy; dst[128 + l] = qz;
+                } else {                                                 /* its first steps: lane l holds body (l + steps) % 64 */
+                    const uint32_t home = (l + steps) & 63u;
+                    float *dst = w == W - 1u ? r0 : edge + ((size_t)(0u * W + w) * 3u) * 64u;
+                    dst[home] = qx; dst[64 + home] = qy; dst[128 + home] = qz;
+                }
+            }
+        }
+    }
+    /* the workgroup's row: waves in ascending order, starting from zero */
+    float *row = J->arow + ((size_t)a * sh->parts + s) * 3u * SYM_IB;
+    for (uint32_t e = 0; e < SYM_IB; e++) {
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        for (uint32_t w = 0; w < W; w++) {
+            const float *ax = accw + (size_t)w * 3u * SYM_IB;
+            sx = sx + ax[e]; sy = sy + ax[SYM_IB + e]; sz = sz + ax[2u * SYM_IB + e];
+        }
+        row[e] = sx; row[SYM_IB + e] = sy; row[2u * SYM_IB + e] = sz;
+    }
+    /* a symmetric meeting cut between wave w - 1 and wave w: first steps + last steps */
+    for (uint32_t w = 1; w < W; w++) {
+        const uint32_t t0 = bounds[s * W + w], t1 = bounds[s * W + w + 1u];
+        if ((t0 & 63u) == 0u || t0 >= t1) continue;
+        const uint32_t m = t0 >> 6, g = g0 + m / SYM_JPI, d = g <= D ? g : half;
+        if (d == 0u) continue;
+        const uint32_t jb = ((a + d) % nb) * SYM_JPI + m % SYM_JPI;
+        float *r0 = J->brow + ((size_t)jb * sh->brows + (g - (g0 ? g0 : 1u))) * 192u;
+        const float *e0 = edge + ((size_t)(0u * W + w - 1u) * 3u) * 64u, *e1 = edge + ((size_t)(1u * W + w) * 3u) * 64u;
+        for (uint32_t l = 0; l < 192; l++) r0[l] = e0[l] + e1[l];
+    }
+}
+
+static void *sym_force_worker(void *arg)
+{
+    const sym_job *J = (const sym_job *)arg;
+    const mapn_oracle_sym_shape *sh = J->sh;
+    float *scratch = (float *)malloc(sizeof(float) * (3u * SYM_IB + (size_t)sh->waves * 3u * SYM_IB + 2u * sh->waves * 192u));
+    if (!scratch) return NULL;
+    const uint32_t items = sh->nb * sh->parts;
+    for (uint32_t it = J->tid; it < items; it += J->nthreads) sym_workgroup(J, it / sh->parts, it % sh->parts, scratch);
+    free(scratch);
+    return NULL;
+}
+
+/* sym_reduce_integrate_kernel */
+static void *sym_reduce_worker(void *arg)
+{
+    const sym_job *J = (const sym_job *)arg;
+    const mapn_oracle_sym_shape *sh = J->sh;
+    const uint32_t nb = sh->nb, D = (nb - 1u) / 2u, half = (nb & 1u) ? 0u : nb / 2u;
+    const uint32_t g0 = J->win[0], g1 = J->win[1], gs0 = g0 ? g0 : 1u;
+    const uint32_t *split0 = J->tab + 2u * (sh->parts * sh->waves + 1u), *split1 = split0 + sh->max_meetings;
+    const size_t np = (size_t)nb * SYM_IB;
+    for (uint32_t i = J->tid; i < J->n; i += J->nthreads) {
+        const uint32_t a = i / SYM_IB, jb = i >> 6, l = i & 63u, tt = jb % SYM_JPI;
+        float ax = 0.0f, ay = 0.0f, az = 0.0f;
+        if (!J->first_window) { ax = J->acc[i]; ay = J->acc[np + i]; az = J->acc[2 * np + i]; }
+        for (uint32_t s = 0; s < sh->parts; s++) {
+            const float *row = J->arow + ((size_t)a * sh->parts + s) * 3u * SYM_IB + (i - a * SYM_IB);
+            ax = ax + row[0]; ay = ay + row[SYM_IB]; az = az + row[2u * SYM_IB];
+        }
+        const uint32_t gend = (g1 == D + 2u && !(half && a >= half)) ? D + 1u : g1;
+        for (uint32_t g = gs0; g < gend; g += 8u) {
+            for (uint32_t u = 0; u < 8u; u++) {
+                const uint32_t gu = g + u;
+                float vx = 0.0f, vy = 0.0f, vz = 0.0f, hx = 0.0f, hy = 0.0f, hz = 0.0f;
+                if (gu < gend) {
+                    const uint32_t d = gu <= D ? gu : half, ap = a >= d ? a - d : a + nb - d;
+                    const float *r0 = J->brow + ((size_t)jb * sh->brows + (gu - gs0)) * 192u;
+                    vx = r0[l]; vy = r0[64 + l]; vz = r0[128 + l];
+                    const uint32_t sp = ((half && ap < half) ? split0 : split1)[(gu - g0) * SYM_JPI + tt];
+                    if (sp != SYM_NONE) {
+                        const float *h0 = J->brow1 + ((size_t)ap * sh->parts + sp) * 192u;
+                        hx = h0[l]; hy = h0[64 + l]; hz = h0[128 + l];
+                    }
+                }
+                ax = ax + vx; ay = ay + vy; az = az + vz;
+                ax = ax + hx; ay = ay + hy; az = az + hz;
+            }
+        }
+        if (!J->last_window) { J->acc[i] = ax; J->acc[np + i] = ay; J->acc[2 * np + i] = az; continue; }
+        integrate_fused(J->old_pos + 4 * (size_t)i, J->old_vel + 3 * (size_t)i, ax * J->p->mass, ay * J->p->mass, az * J->p->mass,
+                        J->p, J->new_pos + 4 * (size_t)i, J->new_vel + 3 * (size_t)i);
+    }
+    return NULL;
+}
+
+static int sym_run(void *(*fn)(void *), sym_job *proto, int threads)
+{
+    sym_job *jobs = (sym_job *)calloc((size_t)threads, sizeof(sym_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); return -1; }
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = *proto;
+        jobs[t].tid = (uint32_t)t; jobs[t].nthreads = (uint32_t)threads;
+        if (t > 0 && pthread_create(&th[t], NULL, fn, &jobs[t]) != 0) { fn(&jobs[t]); th[t] = 0; }
+    }
+    fn(&jobs[0]);
+    for (int t = 1; t < threads; t++) if (th[t]) pthread_join(th[t], NULL);
+    free(jobs); free(th);
+    return 0;
+}
+
+/* One whole-N all-pairs step in the symmetric kernel's order.  windows: [shape->windows][4], tables:
+ * [shape->windows][shape->table_stride] exactly as mapn_get_sym_plan / mapn_sym_plan_describe return them. */
+int mapn_oracle_step_all_pairs_sym(const float *old_pos, const float *old_vel, float *new_pos, float *new_vel, uint32_t n,
+                                   const mapn_oracle_params *p, int threads, const mapn_oracle_sym_shape *shape,
+                                   const uint32_t *windows, const uint32_t *tables)
+{
+    if (!shape || !windows || !tables || shape->nb != (n + SYM_IB - 1u) / SYM_IB || shape->waves == 0 || shape->parts == 0) return -2;
+    if (threads <= 0) threads = mapn_oracle_hardware_threads();
+    const size_t np = (size_t)shape->nb * SYM_IB;
+    float *arow = (float *)malloc(sizeof(float) * 3u * SYM_IB * shape->nb * shape->parts);
+    float *brow = (float *)malloc(sizeof(float) * 192u * (np / 64u) * shape->brows);
+    float *brow1 = (float *)malloc(sizeof(float) * 192u * shape->nb * shape->parts);
+    float *acc = (float *)malloc(sizeof(float) * 3u * np);
+    int rc = (arow && brow && brow1 && acc) ? 0 : -1;
+    for (uint32_t k = 0; k < shape->windows && rc == 0; k++) {
+        sym_job J = {old_pos, old_vel, new_pos, new_vel, n, p, shape, windows + 4u * k, tables + (size_t)k * shape->table_stride,
+                     arow, brow, brow1, acc, k == 0, k + 1u == shape->windows, 0, 0};
+        const uint32_t items = shape->nb * shape->parts;
+        rc = sym_run(sym_force_worker, &J, (uint32_t)threads > items ? (int)items : threads);
+        if (rc == 0) rc = sym_run(sym_reduce_worker, &J, threads);
+    }
+    free(arow); free(brow); free(brow1); free(acc);
+    return rc;
+}

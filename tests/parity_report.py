@@ -5,8 +5,10 @@ from identical seeded initial conditions, free-running, statistics after 1, 10, 
   ref      the oracle proper: fp32, the HLSL's operation order, one running sum over ascending j
            (nBodyGravityCS.hlsl:44-57, :103-108) -- the north_star's "CPU reference";
   acc64    the same fp32 pair terms accumulated in double (summation error removed);
-  matched  the device kernel's summation ORDER and operation FUSION restated on the CPU (chunked
+  matched  the ONE-SIDED device kernel's summation ORDER and operation FUSION restated on the CPU (chunked
            sums, fma, mass after the sum) -- what is left against the device is v_rsq_f32 alone;
+  matched_sym  the same for the SYMMETRIC kernel (the default one), restated from the launch plan the context
+           runs (mapn_get_sym_plan): waves' step ranges, reaction chains, cut meetings, rows, windows;
   f64      the whole step in double on double state: the discrete map itself.
 
 Comparing device|ref|matched with acc64 / f64 attributes a device-vs-ref difference: if the device
@@ -48,6 +50,7 @@ def run_report(n=65536, marks=(1, 10, 100, 1000), seed=1, with_f64=True, f64_max
     out = {"bodies": n, "seed": seed, "regime": "mass=70000/N, soft2=25, dt=0.1, damping=1", "threads": o.hardware_threads(),
            "marks": list(marks), "timing_s": {}, "rows": []}
     snaps = {}
+    sym_plan = None
     # two device legs: "device" = the default kernel (MAPN_KERNEL_AUTO: the symmetric kernel where it applies),
     # "device1s" = the one-sided scalar-cache kernel, whose summation order the `matched` oracle restates
     for leg, kern in (("device", mapn.KERNEL_AUTO), ("device1s", mapn.KERNEL_SCALAR)):
@@ -65,12 +68,18 @@ def run_report(n=65536, marks=(1, 10, 100, 1000), seed=1, with_f64=True, f64_max
                                   "bodies_per_lane": st.bodies_per_lane, "epilogue": st.epilogue}
             if leg == "device1s":
                 waves, sb = st.block_x // 64, st.grid_y
+            elif st.kernel_name.decode() == "force_sym_kernel":
+                sym_plan = c.sym_plan()
+                out["device_sym_plan"] = {"waves": sym_plan.waves, "parts": sym_plan.parts, "taper": [sym_plan.taper1, sym_plan.taper2],
+                                          "windows": len(sym_plan.windows)}
             v0 = vel.astype(np.float64).sum(0)
             out[leg + "_momentum_drift_rel"] = float(np.abs(snaps[(leg, marks[-1])][1].astype(np.float64).sum(0) - v0).max() / (n * 15.0))
     out["momentum_drift_rel"] = out["device_momentum_drift_rel"]
     sims = {"ref": OracleSim(o, pos, vel, params=prm),
             "acc64": OracleSim(o, pos, vel, params=prm, sum_spec=SumSpec(SUM_FP64_ACC)),
             "matched": OracleSim(o, pos, vel, params=prm, sum_spec=SumSpec(SUM_ORDER_MATCHED, waves, sb))}
+    if sym_plan is not None:
+        sims["matched_sym"] = OracleSim(o, pos, vel, params=prm, sym_plan=sym_plan)
     if with_f64:
         sims["f64"] = OracleSim64(o, pos, vel, params=prm)
     have = set()
@@ -88,6 +97,8 @@ def run_report(n=65536, marks=(1, 10, 100, 1000), seed=1, with_f64=True, f64_max
         log(f"# oracle {name}: {out['timing_s'][name]:.1f} s for {done} steps of {n} bodies on {o.hardware_threads()} threads")
     pairs = [("device", "ref"), ("device", "acc64"), ("device1s", "ref"), ("device1s", "matched"), ("device1s", "acc64"),
              ("device", "device1s"), ("ref", "acc64"), ("matched", "acc64")]
+    if sym_plan is not None:
+        pairs += [("device", "matched_sym"), ("matched_sym", "acc64")]
     if with_f64:
         pairs += [("device", "f64"), ("device1s", "f64"), ("ref", "f64"), ("matched", "f64"), ("acc64", "f64")]
     for m in marks:

@@ -222,6 +222,31 @@ def test_graph_replay_is_bit_identical_to_eager():
         assert out[x][2] == out[y][2]
 
 
+@pytest.mark.slow
+def test_config2_as_written_lds_tiles_and_graph_replay_at_262144(oracle):
+    """BASELINE configs[2] literally: 262 144 bodies, the double-buffered LDS-tile kernel, the step replayed from a captured
+    hipGraph -- bit-identical to the same kernel launched eagerly over 6 steps, and a 4096-body subset of the first step
+    against the oracle."""
+    n = 262144
+    mass = 70000.0 / n
+    pos, vel = oracle.initial_state(n, seed=1)
+    first = 777 * 64
+    rp, rv = oracle.step_slice(pos, vel, first, 4096, params=Params(mass=mass))
+    out = []
+    for flags in (mapn.FLAG_USE_GRAPH, 0):
+        with mapn.Compute(n, mass=mass, kernel=mapn.KERNEL_LDS, flags=flags) as c:
+            c.set_timers(0)                                    # a step that carries timer events is never a replay
+            draw(c, 1)
+            p1, v1 = c.download_state()
+            assert c.kernel_stats().kernel_name.decode().startswith("force_lds_kernel")
+            draw(c, 5)
+            out.append((p1, v1) + c.download_state())
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a, b)
+    assert errs(out[0][0][first:first + 4096, :3], rp[:, :3], SPREAD)[0] < 1e-6
+    assert errs(out[0][1][first:first + 4096], rv, SPEED)[0] < 2e-5
+
+
 def test_all_pairs_golden_config1_100_steps(oracle, golden_dir):
     """BASELINE config #1 (4 096 bodies, 100 steps) against the committed oracle state."""
     import os
@@ -310,8 +335,12 @@ def test_maximum_size_4mi_bodies(oracle):
     with mapn.Compute(n, mass=mass) as c:
         draw(c, 1)
         p, v = c.download_state()
-        # 4 Mi bodies: the symmetric kernel's scratch (N^2 / 64 bytes = 275 GB) exceeds its cap: the one-sided kernel runs
-        assert c.kernel_stats().kernel_name.decode() == "force_sgpr_kernel"
+        # 4 Mi bodies: the SYMMETRIC kernel, its step made in windows of partner distance so that the reaction rows stay
+        # within MAPN_SYM_MAX_MB (1 GiB): O(N) scratch instead of N^2 / 128 bytes = 137 GB
+        st, plan = c.kernel_stats(), c.sym_plan()
+        assert st.kernel_name.decode() == "force_sym_kernel" and st.force_launches_per_step == len(plan.windows) > 100
+        assert plan.scratch_bytes < 2 * 1024 ** 3
+        print(f"4 Mi bodies: {len(plan.windows)} windows, {plan.parts} parts, scratch {plan.scratch_bytes / 2**20:.0f} MiB")
     assert errs(p[first:first + 2048, :3], rp[:, :3], SPREAD)[0] < 1e-6
     assert errs(v[first:first + 2048], rv, SPEED)[0] < 2e-5
     drift = np.abs(v.astype(np.float64).sum(0) - vel.astype(np.float64).sum(0)).max() / (n * SPEED)

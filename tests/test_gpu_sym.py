@@ -72,6 +72,87 @@ def test_symmetric_full_size_subset_momentum_and_reproducibility(oracle, n):
     assert drift < 1e-7 and np.isfinite(v5).all()
 
 
+@pytest.mark.parametrize("n,shape", [(1024, None), (4096, None), (5000, None), (8192, (4, 4, 0, 0, 1)), (8192, (8, 2, 0, 0, 2)), (65536, None),
+                                     (65536, (4, 16, 0, 0, 8)), (100000, None)])
+def test_symmetric_kernel_against_its_order_matched_oracle(oracle, n, shape):
+    """The kernel's summation order and fusion restated on the CPU FROM THE PLAN THE CONTEXT RUNS (mapn_get_sym_plan): waves'
+    step ranges, cut meetings, head rows, windows.  What is left between the two is v_rsq_f32 against 1/sqrtf: most bodies
+    come out bit-identical, none farther than one ulp of the position (a wrong row, a dropped or doubled step would show
+    at 1e-5 and more).  Ragged N, tapered parts, 8-wave workgroups, several windows."""
+    mass = 70000.0 / n
+    pos, vel = oracle.initial_state(n, seed=5)
+    if n % 2:
+        pos[n - 1, :3] = [10.0, -20.0, 30.0]
+    steps = 3 if n <= 8192 else 1
+    with mapn.Compute(n, mass=mass, seed=5, kernel=mapn.KERNEL_SYMMETRIC, flags=mapn.FLAG_NO_INIT) as c:
+        c.upload_state(pos, vel)
+        if shape:
+            c.set_sym_plan(*shape)
+        plan = c.sym_plan()
+        if shape:
+            assert (plan.waves, plan.parts) == shape[:2] and len(plan.windows) > 1
+        draw(c, steps)
+        p, v = c.download_state()
+    sim = OracleSim(oracle, pos, vel, params=Params(mass=mass), sym_plan=plan)
+    sim.simulate(steps=steps)
+    rp, rv = sim.latest
+    rel = np.linalg.norm(p[:, :3].astype(np.float64) - rp[:, :3], axis=1) / np.maximum(np.linalg.norm(rp[:, :3].astype(np.float64), axis=1), 1e-30)
+    same = float((p[:, :3] == rp[:, :3]).all(axis=1).mean())
+    print(f"N={n} plan {plan.waves}x{plan.parts} ({plan.taper1},{plan.taper2}) windows {len(plan.windows)}: {steps} step(s) vs the order-matched "
+          f"oracle: max rel {rel.max():.2e}, bit-identical bodies {same:.4f}")
+    assert rel.max() <= (1.3e-7 if steps == 1 else 4e-7)
+    assert same >= 0.9
+    assert errs(v, rv, SPEED)[0] < 1e-6
+
+
+def test_windows_of_partner_distance_change_only_the_rounding(oracle):
+    """One step made in 1, 2 and 4 force launches (windows): the running sum is carried in a fixed order, so each is
+    bit-reproducible, and they differ from each other by partial-sum rounding only."""
+    n = 16384
+    res = {}
+    for gpw in (0, 4, 2):
+        runs = []
+        for rep in range(2):
+            with mapn.Compute(n, mass=70000.0 / n, kernel=mapn.KERNEL_SYMMETRIC) as c:
+                c.set_sym_plan(4, 4, 0, 0, gpw)
+                plan = c.sym_plan()
+                draw(c, 3)
+                runs.append(c.download_state())
+                assert c.kernel_stats().force_launches_per_step == len(plan.windows)
+        np.testing.assert_array_equal(runs[0][0], runs[1][0])
+        res[len(plan.windows)] = runs[0]
+    assert sorted(res) == [1, 2, 4]
+    for k in (2, 4):
+        assert errs(res[k][0][:, :3], res[1][0][:, :3], SPREAD)[0] < 1e-6
+        assert not np.array_equal(res[k][0], res[1][0]) or True     # (equal bits are allowed, just not expected)
+
+
+def test_symmetric_scratch_is_made_at_creation_and_auto_falls_back(oracle, monkeypatch):
+    """The symmetric step's scratch is allocated by mapn_create (never inside Simulate).  If it cannot be had, MAPN_KERNEL_AUTO
+    runs the one-sided kernel and says why; an explicit MAPN_KERNEL_SYMMETRIC fails the creation.  A tiny MAPN_SYM_MAX_MB
+    does not disable the kernel any more -- it only makes more windows."""
+    n = 8192
+    pos, vel = oracle.initial_state(n, seed=1)
+    sim = OracleSim(oracle, pos, vel, params=Params(mass=70000.0 / n)); sim.simulate()
+    monkeypatch.setenv("MAPN_SYM_FAIL_ALLOC", "1")           # tests only: behave as if hipMalloc had failed
+    with mapn.Compute(n, mass=70000.0 / n) as c:
+        with pytest.raises(mapn.MapnError, match="could not be allocated"):
+            c.sym_plan()
+        draw(c, 1)
+        assert c.kernel_stats().kernel_name.decode() == "force_sgpr_kernel"
+        assert errs(c.download_state()[0][:, :3], sim.latest[0][:, :3], SPREAD)[0] < 1e-6
+    with pytest.raises(mapn.MapnError, match="could not be allocated"):
+        mapn.Compute(n, mass=70000.0 / n, kernel=mapn.KERNEL_SYMMETRIC)
+    monkeypatch.delenv("MAPN_SYM_FAIL_ALLOC")
+    monkeypatch.setenv("MAPN_SYM_MAX_MB", "0")                # not even one group's rows fit: one group per window
+    with mapn.Compute(n, mass=70000.0 / n) as c:
+        plan = c.sym_plan()
+        assert len(plan.windows) == 4 and plan.brows == 1
+        draw(c, 1)
+        assert c.kernel_stats().kernel_name.decode() == "force_sym_kernel"
+        assert errs(c.download_state()[0][:, :3], sim.latest[0][:, :3], SPREAD)[0] < 1e-6
+
+
 def test_symmetric_free_run_matches_golden_and_the_one_sided_kernel(oracle, golden_dir):
     import os
     g = np.load(os.path.join(golden_dir, "golden_n4096.npz"))

@@ -2,14 +2,15 @@
 vs the CPU oracle on identical initial conditions -- with the statistic NAMED and the
 difference ATTRIBUTED.
 
-Four CPU trajectories (tests/parity_report.py): `ref` (the oracle proper: fp32, HLSL order, one
+Five CPU trajectories (tests/parity_report.py): `matched_sym` (the symmetric kernel's order restated from its launch plan), `ref` (the oracle proper: fp32, HLSL order, one
 running sum), `acc64` (same pair terms, double accumulation), `matched` (the device's summation
 order and fma fusion restated on the CPU; only v_rsq_f32 vs 1/sqrtf is left) and `f64` (the step in
 double on double state).  Statements asserted, all on ||dx_i|| / ||x_i|| over the 65 536 bodies:
 
   T1  device vs ref after 1000 steps: median <= 1e-5, RMS <= 5e-5, >= 99.9 % of the bodies within
       1e-4.  The MAXIMUM over bodies is NOT within 1e-4 (a handful of bodies that passed close to
-      another one amplify a 1-ulp difference: SURVEY F4's chaos) and is bounded at 5e-3 only.
+      another one amplify a 1-ulp difference: SURVEY F4's chaos): bounded at 1e-3 (measured 4.1e-4 .. 4.2e-4), and at
+      most 12 bodies lie beyond 1e-4 (measured 7 .. 9).
   T2  device vs ref after 100 steps: max <= 2e-6 (every body far inside 1e-4).
   T3  attribution: the device is no farther from either yardstick than the reference-order oracle is --
       err(device, acc64) <= 1.5 x err(ref, acc64) for median, RMS AND max at 100 and 1000 steps, and
@@ -18,7 +19,8 @@ double on double state).  Statements asserted, all on ||dx_i|| / ||x_i|| over th
       I.e. the device-vs-ref difference is the fp32 summation order of `ref` itself (one running sum
       over 65 536 terms), amplified by the dynamics -- not a kernel defect.  Measured: device vs acc64
       after 1000 steps max 9.7e-5 (NO body beyond 1e-4), ref vs acc64 max 4.3e-4 (9 bodies beyond).
-  T4  one-sided device kernel vs matched (only v_rsq_f32 differs): tighter than T1/T2 by the bounds written below.
+  T4  each device kernel vs ITS order-matched oracle (only v_rsq_f32 differs): "device1s" vs `matched`, "device" (the symmetric
+      kernel) vs `matched_sym` -- tighter than T1/T2 by the bounds written below.
 
 T1-T3 are asserted for BOTH device kernels: "device" = MAPN_KERNEL_AUTO (the symmetric kernel at this size,
 csrc/mapn_sym.hip) and "device1s" = the one-sided scalar-cache kernel whose summation order `matched` restates.
@@ -60,7 +62,8 @@ def test_t1_device_vs_reference_order_oracle_after_1000_steps(report, leg):
     assert r["median"] <= 1e-5
     assert r["rms"] <= 5e-5
     assert r["frac_within_1e-4"] >= 0.999
-    assert r["max"] <= 5e-3            # NOT <= 1e-4: see the module docstring and BASELINE.md section 4
+    assert r["max"] <= 1e-3            # NOT <= 1e-4: see the module docstring and BASELINE.md section 4 (measured 4.2e-4)
+    assert r["n_over_1e-4"] <= 12      # measured 7 (symmetric kernel) and 9 (one-sided)
     assert report[leg + "_momentum_drift_rel"] < 1e-7
 
 
@@ -89,11 +92,12 @@ def test_t3_device_is_no_farther_from_the_yardsticks_than_the_oracle_is(report, 
                 assert dev["max"] <= 3e-4 and dev["n_over_1e-4"] <= 3, dev
 
 
-def test_t4_device_vs_order_matched_oracle_differs_by_rsq_only(report):
-    r1, r100, r1000 = (_row(report, s, "device1s", "matched") for s in (1, 100, 1000))
-    print("one-sided device vs matched:", r1, r100, r1000)
+@pytest.mark.parametrize("leg,yardstick", [("device1s", "matched"), ("device", "matched_sym")])
+def test_t4_device_vs_order_matched_oracle_differs_by_rsq_only(report, leg, yardstick):
+    r1, r100, r1000 = (_row(report, s, leg, yardstick) for s in (1, 100, 1000))
+    print(leg, "vs", yardstick, ":", r1, r100, r1000, report.get("device_sym_plan"))
     assert r1["max"] <= 1.3e-7                 # one step: <= 1 ulp of the position
     assert r100["max"] <= 1e-6 and r100["median"] <= 3e-8
     assert r1000["median"] <= 5e-6 and r1000["rms"] <= 3e-5
-    d_ref = _row(report, 1000, "device1s", "ref")
+    d_ref = _row(report, 1000, leg, "ref")
     assert r1000["median"] <= d_ref["median"]   # tighter than against the reference-order oracle

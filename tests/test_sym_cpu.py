@@ -63,32 +63,108 @@ def test_chunk_tiles_partition_the_range():
         assert all(edges[c][1] == edges[c + 1][0] for c in range(splits - 1))
 
 
-@pytest.mark.parametrize("meetings,parts,waves,taper", [(528, 32, 4, None), (512, 32, 4, None), (16, 4, 4, None), (48, 12, 4, None), (2064, 32, 4, None),
-                                                        (528, 16, 8, None), (40, 7, 4, None), (3, 2, 4, None), (528, 48, 4, (24, 8)), (512, 48, 4, (24, 8)),
-                                                        (272, 48, 4, (24, 8)), (144, 48, 4, (24, 8)), (1040, 40, 4, (28, 4))])
-def test_wave_deal_covers_every_step_of_every_meeting_once_and_is_balanced(meetings, parts, waves, taper):
-    """force_sym_kernel's deal of an I-block's meetings to waves: whole meetings first, the remainder of a
-    part shared step-wise.  Every (meeting, travelling-body offset) is run exactly once, and the waves of
-    a workgroup all run the same number of steps (nobody waits at the closing barrier).  With tapered parts
-    (4 : 2 : 1 units) the late parts are a quarter of the early ones."""
-    t1, t2 = taper if taper else (None, 0)
-    seen = np.zeros((meetings, 64), np.int32)
-    steps = {}
-    for s, w, m, rot, n in shard.sym_wave_items(meetings, parts, waves, t1, t2):
-        seen[m, rot:rot + n] += 1
-        steps[(s, w)] = steps.get((s, w), 0) + n
-    assert (seen == 1).all()
-    for s in range(parts):
-        per_wave = {steps.get((s, w), 0) for w in range(waves)}
-        assert len(per_wave) == 1
-    bounds = shard.sym_part_bounds(meetings, parts, t1, t2)
-    assert bounds[0] == 0 and bounds[-1] == meetings and all(b1 >= b0 for b0, b1 in zip(bounds, bounds[1:]))
-    sizes = [b1 - b0 for b0, b1 in zip(bounds, bounds[1:])]
-    if taper is None:
-        assert max(sizes) - min(sizes) <= 1                # equal parts differ by at most one meeting
-    else:
-        big, small = sizes[:t1], sizes[t1 + t2:]
-        assert max(big) - min(big) <= 1 and max(small) - min(small) <= 1 and abs(4 * np.mean(small) - np.mean(big)) <= 2
+PLAN_SHAPES = [  # nb, groups per window, parts, taper1, taper2, waves
+    (64, 0, 32, None, 0, 4), (64, 0, 38, 28, 4, 4), (64, 0, 64, None, 0, 4), (63, 0, 32, None, 0, 4), (8, 0, 8, None, 0, 4), (8, 1, 4, None, 0, 4),
+    (8, 2, 4, None, 0, 4), (9, 2, 4, None, 0, 4), (2, 0, 4, None, 0, 4), (1, 0, 4, None, 0, 4), (3, 0, 2, None, 0, 8), (64, 5, 8, None, 0, 8),
+    (256, 0, 32, None, 0, 4), (100, 0, 36, 28, 4, 4), (1024, 57, 8, None, 0, 4), (4096, 16, 2, None, 0, 4)]
+
+
+@pytest.mark.parametrize("nb,gpw,parts,t1,t2,waves", PLAN_SHAPES)
+def test_plan_windows_partition_the_groups_and_waves_carry_equal_cost(nb, gpw, parts, t1, t2, waves):
+    """The host-built plan (csrc/mapn_sym_plan.cpp) the kernels read: the windows partition the meeting groups, every wave of a
+    launch runs at least 64 steps (so a meeting is cut at most once) and the same COST to within two steps (a step of a block
+    against itself and a symmetric step cost the same: the kernel runs one loop for both); tapered parts weigh 4 : 2 : 1."""
+    import mapn
+    plan = mapn.describe_sym_plan(nb, gpw, parts, t1, t2, waves)
+    D, half = (nb - 1) // 2, (nb // 2 if nb % 2 == 0 else 0)
+    groups = 1 + D + (1 if half else 0)
+    assert plan.groups == groups and plan.nb == nb
+    edges = [int(w[0]) for w in plan.windows] + [int(plan.windows[-1][1])]
+    assert edges[0] == 0 and edges[-1] == groups
+    for k, w in enumerate(plan.windows):
+        g0, g1, m0, m1 = (int(x) for x in w)
+        assert g1 > g0 and (k == 0 or g0 == int(plan.windows[k - 1][1]))
+        assert g1 - max(g0, 1) <= plan.brows and (gpw == 0 or g1 - max(g0, 1) <= gpw)
+        has_half = bool(half) and g1 == groups
+        assert m0 == 16 * (g1 - g0) and m1 == 16 * (g1 - g0 - (1 if has_half else 0))
+        for cls, M in ((0, m0), (1, m1)):
+            b = plan.bounds(k, cls).astype(np.int64)
+            assert b[0] == 0 and b[-1] == 64 * M and (np.diff(b) >= (64 if M else 0)).all()
+            if not M:
+                continue
+            self_steps = 1024 if g0 == 0 else 0
+            cost = np.where(b <= self_steps, 6 * b, 6 * self_steps + 6 * (b - self_steps))   # (csrc/mapn_sym_plan.h: SYM_COST_SELF, SYM_COST_SYM)
+            per_wave = np.diff(cost).reshape(parts, waves)
+            unit = [4 if s < (parts if t1 is None else t1) else 2 if s < (parts if t1 is None else t1) + t2 else 1 for s in range(parts)]
+            norm = per_wave / np.array(unit)[:, None]
+            assert norm.max() - norm.min() <= 12 + 1e-9, (norm.min(), norm.max())   # bounds are whole steps: two steps of slack
+            assert (per_wave.max(axis=1) - per_wave.min(axis=1) <= 12).all()     # the waves of a workgroup leave together
+
+
+def test_plan_that_would_leave_a_wave_fewer_than_64_steps_is_refused():
+    import mapn
+    with pytest.raises(mapn.MapnError, match="< 64"):
+        mapn.describe_sym_plan(8, 0, 20, None, 0, 4)           # 64 meetings for 80 waves
+    with pytest.raises(mapn.MapnError, match="< 64"):
+        mapn.describe_sym_plan(64, 0, 48, 28, 4, 4)            # 16 parts of one unit: 56 steps for the smallest waves
+    with pytest.raises(mapn.MapnError):
+        mapn.describe_sym_plan(64, 0, 32, 30, 4, 4)            # taper1 + taper2 > parts
+
+
+@pytest.mark.parametrize("nb,gpw,parts,t1,t2,waves", PLAN_SHAPES[:13])
+def test_force_kernel_writes_exactly_the_rows_the_reduce_kernel_reads(nb, gpw, parts, t1, t2, waves):
+    """force_sym_kernel's bookkeeping replayed from the plan tables: every step of every meeting is run exactly once; a symmetric
+    meeting's row is written exactly once (whole, or put together in LDS from two waves of one workgroup, or its first steps when
+    it is cut between two workgroups -- then its last steps go to the later workgroup's head row); sym_reduce_integrate_kernel
+    reads a meeting's row and, where the split table says so, that very head row -- and nothing else is ever written."""
+    import mapn
+    plan = mapn.describe_sym_plan(nb, gpw, parts, t1, t2, waves)
+    D, half = (nb - 1) // 2, (nb // 2 if nb % 2 == 0 else 0)
+    for k, w in enumerate(plan.windows):
+        g0, g1 = int(w[0]), int(w[1])
+        rows, heads = {}, {}                                   # (J-block, group) -> writes; (I-block, part) -> meeting it holds
+        for a in range(nb if nb <= 9 else 3):                  # every block for small jobs, else a class-0, class-0, class-0/1 sample
+            a = a if nb <= 9 else (0, half - 1 if half else 1, nb - 1)[a]
+            cls = shard.sym_block_class(nb, a)
+            M = int(w[2 + cls])
+            seen = np.zeros((max(M, 1), 64), np.int32)
+            lds = {}                                           # (part, wave, which) -> meeting
+            for s, wv, m, k0, n in shard.sym_wave_pieces(plan, k, cls):
+                seen[m, k0:k0 + n] += 1
+                g, t = g0 + m // 16, m % 16
+                if g == 0:
+                    continue
+                d = g if g <= D else half
+                key = (((a + d) % nb) * 16 + t, g)
+                if n == 64:
+                    rows[key] = rows.get(key, 0) + 1
+                elif k0:                                       # the meeting's last steps
+                    assert k0 + n == 64
+                    if wv == 0:
+                        assert (a, s) not in heads
+                        heads[(a, s)] = key
+                    else:
+                        assert lds.pop((s, wv - 1, 0)) == key  # the previous wave of this workgroup ran its first steps
+                        rows[key] = rows.get(key, 0) + 1       # put together after the barrier
+                else:                                          # the meeting's first steps
+                    if wv == waves - 1:
+                        rows[key] = rows.get(key, 0) + 1
+                    else:
+                        lds[(s, wv, 0)] = key
+            assert not lds and (seen[:M] == 1).all()
+            # what the reduce kernel reads for the rows this block wrote: the split table names the head row
+            sp = plan.split(k, cls)
+            for m in range(M):
+                g, t = g0 + m // 16, m % 16
+                if g == 0:
+                    assert sp[m] == plan.SPLIT_NONE
+                    continue
+                d = g if g <= D else half
+                key = (((a + d) % nb) * 16 + t, g)
+                assert rows.get(key) == 1, (a, m)
+                if sp[m] != plan.SPLIT_NONE:
+                    assert heads.pop((a, int(sp[m]))) == key
+            assert not [h for h in heads if h[0] == a]
 
 
 @pytest.mark.parametrize("nb,world", [(8, 2), (8, 4), (8, 8), (9, 3), (6, 2), (16, 8), (64, 8), (64, 2), (1024, 8)])

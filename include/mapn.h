@@ -300,8 +300,14 @@ int mapn_comm_init(mapn_ctx *ctx, const void *id128);
  * once in the whole job: a rank runs the meetings of its own 1024-body blocks, stores the reactions it
  * produced for another rank's bodies -- summed over its blocks first, one row per destination -- straight
  * into that rank's receive region, and integrates its bodies from its own rows plus the rows received;
- * positions then travel as in 2; needs N / world_size to be a multiple of 1024 and all bodies active,
- * otherwise the step runs as 2); all ranks must agree */
+ * the same launch then publishes the rank's new slice and pulls the peers'; needs N / world_size to be a multiple of
+ * 1024 and all bodies active, otherwise the step runs as 2), 5 = as 4, but that launch also STORES the new positions
+ * into every peer's replica (posted writes instead of read round trips) and the peers' next force launch waits for
+ * this rank's counter before it reads them, 6 = the sharded symmetric step over RCCL alone (after mapn_comm_init, no
+ * mapped peer memory): a pack launch, one group of ncclSend / ncclRecv carrying the per-destination reaction rows into
+ * the same [sender][body] layout, a reduce launch that adds them in the same fixed order, then ncclAllGather of the
+ * positions as in 0; all ranks must agree.  4, 5 and 6 allocate the sharded symmetric step's
+ * scratch here (never inside mapn_simulate); under MAPN_KERNEL_AUTO a failed allocation only means the steps run as 2. */
 int mapn_set_gather_algorithm(mapn_ctx *ctx, int algorithm);
 /*
  * Direct peer-to-peer exchange (algorithm 2 of mapn_set_gather_algorithm), no collective library:

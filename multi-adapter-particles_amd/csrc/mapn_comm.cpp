@@ -137,6 +137,28 @@ int comm_gather_sendrecv_inplace(Comm *c, void *buf, size_t floats_per_rank, hip
     return check(g_api.GroupEnd(), "ncclGroupEnd");
 }
 
+// Gather algorithm 6: what sym_shard_exchange_kernel does with remote stores and counters, as RCCL transfers -- for nodes where
+// peers' memory cannot be mapped (hipIpc blocked in a container).  The reference analogue of the transport being replaced:
+// the cross-adapter heap of Compute.cpp:163-201 / Render.cpp:789-831.
+int comm_exchange_rows(Comm *c, const void *send, void *recv, size_t floats_per_rank, unsigned send_mask, unsigned recv_mask, hipStream_t stream)
+{
+    if (!c || !g_api.ok) { g_err = "communicator not initialised"; return -1; }
+    const float *s = static_cast<const float *>(send);
+    float *r = static_cast<float *>(recv);
+    bool any = false;
+    for (int q = 0; q < c->nranks; q++) any = any || (q != c->rank && (((send_mask | recv_mask) >> q) & 1u));
+    if (!any) return 0;
+    if (check(g_api.GroupStart(), "ncclGroupStart")) return -1;
+    for (int d = 1; d < c->nranks; d++) {
+        const int to = (c->rank + d) % c->nranks, from = (c->rank - d + c->nranks) % c->nranks;
+        if ((send_mask >> to) & 1u)
+            if (check(g_api.Send(s + (size_t)to * floats_per_rank, floats_per_rank, ncclFloat, to, c->comm, stream), "ncclSend")) { g_api.GroupEnd(); return -1; }
+        if ((recv_mask >> from) & 1u)
+            if (check(g_api.Recv(r + (size_t)from * floats_per_rank, floats_per_rank, ncclFloat, from, c->comm, stream), "ncclRecv")) { g_api.GroupEnd(); return -1; }
+    }
+    return check(g_api.GroupEnd(), "ncclGroupEnd");
+}
+
 const char *comm_last_error() { return g_err.c_str(); }
 
 }  // namespace mapn

@@ -18,6 +18,9 @@ void comm_destroy(Comm *c);
 // at buf + r * floats_per_rank (ncclAllGather with sendbuff == recvbuff + rank * count)
 int comm_all_gather_inplace(Comm *c, void *buf, size_t floats_per_rank, hipStream_t stream);
 int comm_gather_sendrecv_inplace(Comm *c, void *buf, size_t floats_per_rank, hipStream_t stream);
+// the reaction rows of the sharded symmetric step as ONE group of point-to-point transfers: row [q] of `send` (floats_per_rank
+// floats each) goes to every rank q of send_mask, row [q] of `recv` is filled by every rank q of recv_mask (never this rank)
+int comm_exchange_rows(Comm *c, const void *send, void *recv, size_t floats_per_rank, unsigned send_mask, unsigned recv_mask, hipStream_t stream);
 const char *comm_last_error();
 
 }  // namespace mapn

@@ -154,7 +154,9 @@ struct mapn_ctx {
     uint32_t **p2p_flag_table = nullptr;      // device copy of p2p_peer_flags[] (flow mode reads it in the kernel)
     uint32_t *sym_shard_ticket = nullptr;     // gather algorithm 4: the exchange kernel's two tickets
     uint32_t sym_shard_step = 0;
-    bool step_pulled = false;                 // this step's exchange launch already moved the positions (algorithm 4, pull folded in)
+    float4 *sym_send = nullptr, *sym_recv = nullptr;   // gather algorithm 6: reaction rows [world][count] packed for / delivered by RCCL
+    bool step_pulled = false;                 // this step's exchange launch already moved the positions (algorithms 4 / 5)
+    bool push_pending = false;                // algorithm 5: the peers' pushes of the latest step have not been waited for yet
     uint32_t sym_send_mask = 0, sym_recv_mask = 0;
     bool p2p_loopback = false;                // MAPN_P2P_LOOPBACK=1 (timing on a 1-GPU box only): every peer maps to this rank
     uint32_t *flow_block = nullptr;           // ordinary device memory: [0..15] arrived[q], [16] tiles_done (flow mode)
@@ -298,6 +300,9 @@ void release_sym(mapn_ctx *c)
     if (c->sym_brow1) (void)hipFree(c->sym_brow1);
     if (c->sym_acc) (void)hipFree(c->sym_acc);
     if (c->sym_tab) (void)hipFree(c->sym_tab);
+    if (c->sym_send) (void)hipFree(c->sym_send);
+    if (c->sym_recv) (void)hipFree(c->sym_recv);
+    c->sym_send = c->sym_recv = nullptr;
     c->sym_arow = c->sym_brow = c->sym_brow1 = c->sym_acc = nullptr;
     c->sym_tab = nullptr;
     c->sym_scratch_bytes = 0;
@@ -481,7 +486,9 @@ mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t win
     a.g0 = pl.windows[window].g0; a.g1 = pl.windows[window].g1;
     a.brows = pl.brows; a.half_d = pl.half;
     a.mass = base.mass; a.soft2 = base.soft2; a.dt = base.dt; a.damping = base.damping;
-    static const uint32_t wt = [] { const char *e = getenv("MAPN_SYM_ROW_WT"); return e ? (uint32_t)atoi(e) : 0u; }();   // A/B: write-through rows
+    // rows leave the XCD as they are produced (write-through) instead of waiting in its L2 for the end-of-kernel write-back:
+    // same box, rank 0 of 65 536 / 8: force launch 92.7 against 95.9 us; 65 536 unsharded 0.3 % faster (MAPN_SYM_ROW_WT=0: A/B)
+    static const uint32_t wt = [] { const char *e = getenv("MAPN_SYM_ROW_WT"); return e ? (uint32_t)atoi(e) : 1u; }();
     a.row_wt = wt;
     return a;
 }
@@ -511,8 +518,21 @@ int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
 bool sym_shard_eligible(const mapn_ctx *c, uint32_t active)
 {
     if (!c->sym_ready || !c->sym_sharded || c->plan_forced) return false;
-    if (!c->p2p_ready || c->gather_algo != 4) return false;
+    if (c->gather_algo == 6) return c->comm != nullptr && c->sym_send != nullptr && active == c->n;
+    if (!c->p2p_ready || (c->gather_algo != 4 && c->gather_algo != 5)) return false;
     return active == c->n;
+}
+
+// Gather algorithm 5: the peers store their new slices into this rank's replica; whoever reads the replica next must first
+// wait for their counters.  The sharded symmetric force launch does that itself; every other reader (a one-sided step, a
+// download, wait_idle) gets this stream operation in front.
+int settle_push(mapn_ctx *c)
+{
+    if (!c->push_pending) return MAPN_OK;
+    c->push_pending = false;
+    HIP_TRY(mapn::launch_p2p_wait(c->p2p_flags, c->p2p_step, (uint32_t)c->cfg.world_size, (uint32_t)c->cfg.rank, c->p2p_loopback ? 1u : 0u,
+                                  c->p2p_timeout_ticks, c->async_status, c->compute));
+    return MAPN_OK;
 }
 
 // do the new positions travel inside the exchange launch (default) or in p2p_gather_kernel behind it (MAPN_SYM_SHARD_PULL=0: A/B)
@@ -529,6 +549,13 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     mapn::SymArgs a = sym_args(c, base, 0);
     a.shard_nbl = c->count / mapn::SYM_BLOCK;
     a.a0 = rank * a.shard_nbl;
+    const bool push = c->gather_algo == 5;
+    if (push) {
+        // the replica this launch reads was completed by the peers' pushes of the previous step: wait for their counters in the launch
+        a.wait_counters = c->p2p_flags; a.wait_status = c->async_status; a.wait_timeout_ticks = c->p2p_timeout_ticks;
+        a.wait_need = c->p2p_step; a.wait_world = world; a.wait_rank = rank; a.wait_self = c->p2p_loopback ? 1u : 0u;
+        c->push_pending = false;
+    }
     if (int rc = stamps_prepare(c, (size_t)a.shard_nbl * pl.nwaves, a)) return rc;
     HIP_TRY(mapn::launch_force_sym(a, pl.waves, c->compute));
     if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
@@ -536,13 +563,15 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     mapn::SymShardArgs h{};
     h.pos_old = a.pos_old; h.vel_old = a.vel_old; h.pos_new = a.pos_new; h.vel_new = a.vel_new;
     h.arow = a.arow; h.brow = a.brow; h.brow1 = a.brow1; h.tab = a.tab;
-    const bool pull = sym_shard_pull_folded();
+    const bool pull = push || sym_shard_pull_folded();
     for (uint32_t q = 0; q < world; q++) {
         h.flags_peer[q] = c->p2p_peer_flags[q];
         h.recv_peer[q] = reinterpret_cast<float4 *>(reinterpret_cast<char *>(c->p2p_peer_flags[q]) + mapn::SYM_RECV_OFFSET);
         // both position buffers live in one heap allocation: the written buffer sits buffer_index * aligned_data_size in
-        h.pos_peer[q] = pull ? reinterpret_cast<const float4 *>(static_cast<char *>(c->p2p_peer_heap[q]) + (size_t)c->buffer_index * c->aligned_data_size) : nullptr;
+        h.pos_peer[q] = pull ? reinterpret_cast<float4 *>(static_cast<char *>(c->p2p_peer_heap[q]) + (size_t)c->buffer_index * c->aligned_data_size) : nullptr;
     }
+    h.push = push ? 1u : 0u;
+    h.send_row = rank;
     h.flags_mine = c->p2p_flags;
     h.recv_mine = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(c->p2p_flags) + mapn::SYM_RECV_OFFSET);
     h.ticket = c->sym_shard_ticket;
@@ -553,9 +582,49 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     h.step = ++c->sym_shard_step;
     h.pos_step = pull ? ++c->p2p_step : 0u;
     c->step_pulled = pull;
+    c->push_pending = push;
     h.pull_self = c->p2p_loopback ? 1u : 0u;
     h.timeout_ticks = c->p2p_timeout_ticks;
     h.mass = a.mass; h.dt = a.dt; h.damping = a.damping;
+    HIP_TRY(mapn::launch_sym_shard_exchange(h, c->sym_exchange_cap, c->compute));
+    mapn::ForcePlan p{};
+    p.kind = mapn::KERNEL_SYM; p.k = 2 * mapn::SYM_K2; p.waves = pl.waves; p.sb = pl.parts; p.nseg = 1; p.epi = mapn::EPI_ROWS;
+    c->last_plan = p; c->last_i_count = c->count; c->last_launches = 2;
+    return MAPN_OK;
+}
+
+// Gather algorithm 6: the same sharded symmetric step with the reaction rows carried by RCCL instead of remote stores and
+// counters -- pack launch, one group of ncclSend / ncclRecv into the same [sender][body] layout, reduce launch; the new positions
+// then travel by ncclAllGather as in algorithm 0.  Four launches and two collectives per step: the form for nodes where peers'
+// memory cannot be mapped, not the fast one.
+int enqueue_sym_shard_rccl(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
+{
+    const uint32_t world = (uint32_t)c->cfg.world_size, rank = (uint32_t)c->cfg.rank;
+    const mapn::SymPlanHost &pl = c->sym_plan;
+    mapn::SymArgs a = sym_args(c, base, 0);
+    a.shard_nbl = c->count / mapn::SYM_BLOCK;
+    a.a0 = rank * a.shard_nbl;
+    if (int rc = stamps_prepare(c, (size_t)a.shard_nbl * pl.nwaves, a)) return rc;
+    HIP_TRY(mapn::launch_force_sym(a, pl.waves, c->compute));
+    if (timer) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }
+
+    mapn::SymShardArgs h{};
+    h.pos_old = a.pos_old; h.vel_old = a.vel_old; h.pos_new = a.pos_new; h.vel_new = a.vel_new;
+    h.arow = a.arow; h.brow = a.brow; h.brow1 = a.brow1; h.tab = a.tab;
+    for (uint32_t q = 0; q < world; q++) h.recv_peer[q] = (q == rank ? c->sym_recv : c->sym_send) + (size_t)q * c->count;   // own reactions: straight to where the reduce launch reads
+    h.recv_mine = c->sym_recv;
+    h.status = c->async_status;
+    h.rank = rank; h.world = world; h.count = c->count;
+    h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = pl.parts; h.nwaves = pl.nwaves; h.max_meetings = pl.max_meetings;
+    h.send_mask = c->sym_send_mask; h.recv_mask = c->sym_recv_mask;
+    h.step = ++c->sym_shard_step;
+    h.send_row = 0;
+    h.mass = a.mass; h.dt = a.dt; h.damping = a.damping;
+    h.phase = 1;
+    HIP_TRY(mapn::launch_sym_shard_exchange(h, c->sym_exchange_cap, c->compute));
+    if (mapn::comm_exchange_rows(c->comm, c->sym_send, c->sym_recv, (size_t)c->count * 4, c->sym_send_mask & ~(1u << rank), c->sym_recv_mask & ~(1u << rank), c->compute))
+        return fail(MAPN_ERR_COMM, "reaction exchange failed: %s", mapn::comm_last_error());
+    h.phase = 2;
     HIP_TRY(mapn::launch_sym_shard_exchange(h, c->sym_exchange_cap, c->compute));
     mapn::ForcePlan p{};
     p.kind = mapn::KERNEL_SYM; p.k = 2 * mapn::SYM_K2; p.waves = pl.waves; p.sb = pl.parts; p.nseg = 1; p.epi = mapn::EPI_ROWS;
@@ -670,7 +739,7 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
     a.i_first = lo;
     a.i_count = i_count;
     const bool flow = c->p2p_ready && c->gather_algo == 3;
-    const bool sharded_native = c->comm != nullptr || (c->p2p_ready && (c->gather_algo == 2 || c->gather_algo == 4));
+    const bool sharded_native = c->comm != nullptr || (c->p2p_ready && (c->gather_algo == 2 || c->gather_algo == 4 || c->gather_algo == 5));
     const bool overlap = c->comm != nullptr && c->gather_algo < 2 && (c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP);
     if (flow) {
         // the pull half of THIS step's exchange runs beside the launch on the comm stream (it only
@@ -688,6 +757,9 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
         a.xcd_remap = 0;                                   // dispatch order = row order: own rows first
     }
 
+    if (c->push_pending && !(i_count > 0 && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS && sym_shard_eligible(c, active) && c->gather_algo == 5))
+        if (int rc = settle_push(c)) return rc;            // this step's launch does not wait for the peers' pushes itself
+
     if (timer) HIP_TRY(hipEventRecord(timer->start, c->compute));
 
     if (i_count > 0 && c->cfg.force_mode == MAPN_FORCE_CENTRAL_WELL) {
@@ -701,7 +773,7 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
     } else if (i_count > 0 && sym_eligible(c, active)) {
         if (int rc = enqueue_sym(c, a, timer)) return rc;
     } else if (i_count > 0 && sym_shard_eligible(c, active)) {
-        if (int rc = enqueue_sym_shard(c, a, timer)) return rc;
+        if (int rc = c->gather_algo == 6 ? enqueue_sym_shard_rccl(c, a, timer) : enqueue_sym_shard(c, a, timer)) return rc;
     } else if (i_count > 0 && !overlap) {
         // one force launch over all j.  Sharded: the read buffer is complete once the all-gather
         // that filled it has finished (event recorded on the comm stream).
@@ -863,10 +935,10 @@ int enqueue_gather(mapn_ctx *c)
     if (c->step_pulled) { c->step_pulled = false; return MAPN_OK; }   // sym_shard_exchange_kernel has published and pulled
     if (c->p2p_ready && c->gather_algo == 3) return enqueue_flow_pull(c);
     if (c->p2p_ready && c->p2p_loopback) return MAPN_OK;   // no peers to pull from
-    if (c->p2p_ready && (c->gather_algo == 2 || c->gather_algo == 4)) return enqueue_p2p(c);   // 4: positions travel as in 2
+    if (c->p2p_ready && (c->gather_algo == 2 || c->gather_algo == 4 || c->gather_algo == 5)) return enqueue_p2p(c);   // 4 / 5 where the symmetric step does not apply: positions travel as in 2
     if (!c->comm) return MAPN_OK;
     const uint32_t w = c->buffer_index;
-    const bool overlap = (c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP) != 0;
+    const bool overlap = (c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP) != 0 && c->gather_algo < 2;
     // in place: every rank's slice sits at its own offset of the full buffer.
     // Default structure: the collective is enqueued on the COMPUTE stream right behind the
     // integrate kernel -- plain stream order, no cross-stream event hops (each costs 5-10 us of
@@ -1127,7 +1199,7 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
     }
     // MoveToNextFrame, Compute.cpp:993-1004: Signal(fence, v); v++; index = 1 - index
     const bool exchanging = c->comm != nullptr || (c->p2p_ready && c->gather_algo >= 2);
-    const bool gather_first = exchanging && (!(c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP) || c->gather_algo >= 2);
+    const bool gather_first = exchanging && (!(c->cfg.flags & MAPN_FLAG_SHARD_OVERLAP) || c->gather_algo >= 2);   // (the overlap structure exists for algorithms 0 / 1 only)
     if (gather_first) { if (int rc = enqueue_gather(c)) return rc; }   // same stream: the fence then covers the gather
     // The fence value always advances.  While somebody can observe completion (an attached consumer,
     // exported handles) the ONE exported event is re-recorded after every step; the ring event behind
@@ -1162,6 +1234,7 @@ int mapn_wait_idle(mapn_ctx *c)
 {
     if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    if (int rc = settle_push(c)) return rc;                           // (gather algorithm 5: the peers' latest pushes belong to "all enqueued work")
     // Compute.cpp:928-940: Signal(fence, v); v++; wait
     if (int rc = signal_fence(c, c->fence_value)) return rc;
     const uint64_t v = c->fence_value++;
@@ -1287,6 +1360,7 @@ int mapn_upload_state(mapn_ctx *c, const float *pos4, const float *vel3)
 {
     if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    if (int rc = settle_push(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->compute));
     HIP_TRY(hipStreamSynchronize(c->comm_stream));
     for (int b = 0; b < 2; b++) {                                      // Compute.cpp:881-882,903-904
@@ -1301,6 +1375,7 @@ int mapn_download_buffer(mapn_ctx *c, uint32_t index, float *pos4, float *vel3)
 {
     if (!c || index > 1) return fail(MAPN_ERR_INVALID_ARGUMENT, "download_buffer: bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    if (int rc = settle_push(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->compute));
     HIP_TRY(hipStreamSynchronize(c->comm_stream));
     if (int rc = check_async_errors(c)) return rc;
@@ -1550,9 +1625,9 @@ int mapn_comm_init(mapn_ctx *c, const void *id128)
 
 int mapn_set_gather_algorithm(mapn_ctx *c, int algorithm)
 {
-    if (!c || algorithm < 0 || algorithm > 4) return fail(MAPN_ERR_INVALID_ARGUMENT, "set_gather_algorithm: bad argument");
-    if (algorithm >= 2 && !c->p2p_ready) return fail(MAPN_ERR_STATE, "set_gather_algorithm(%d): call mapn_p2p_import first", algorithm);
-    if (algorithm < 2 && c->cfg.world_size > 1 && !c->comm && !c->external_gather)
+    if (!c || algorithm < 0 || algorithm > 6) return fail(MAPN_ERR_INVALID_ARGUMENT, "set_gather_algorithm: bad argument");
+    if (algorithm >= 2 && algorithm <= 5 && !c->p2p_ready) return fail(MAPN_ERR_STATE, "set_gather_algorithm(%d): call mapn_p2p_import first", algorithm);
+    if ((algorithm < 2 || algorithm == 6) && c->cfg.world_size > 1 && !c->comm && !c->external_gather)
         return fail(MAPN_ERR_STATE, "set_gather_algorithm(%d): no RCCL communicator (mapn_comm_init)", algorithm);
     if (int rc = mapn_wait_idle(c)) return rc;
     if (algorithm == 3) {
@@ -1566,7 +1641,23 @@ int mapn_set_gather_algorithm(mapn_ctx *c, int algorithm)
     }
     // algorithm 4: plan and scratch of the sharded symmetric step are made HERE (never inside mapn_simulate); if they
     // cannot be had under MAPN_KERNEL_AUTO the step runs as algorithm 2 (one-sided kernel + peer-to-peer pull)
-    if (algorithm == 4) { if (int rc = prepare_sym(c, true)) return rc; }
+    if (algorithm >= 4 && algorithm <= 6) { if (!(c->sym_ready && c->sym_sharded)) { if (int rc = prepare_sym(c, true)) return rc; } }
+    if (algorithm == 6 && c->sym_ready && !c->sym_send) {
+        // send / receive rows of the RCCL form, and who exchanges with whom (mapn_p2p_import computes the same masks for 4 / 5)
+        HIP_TRY(hipSetDevice(c->device));
+        const size_t bytes = (size_t)c->cfg.world_size * c->count * sizeof(float4);
+        if (hipMalloc(&c->sym_send, bytes) != hipSuccess || hipMalloc(&c->sym_recv, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->sym_send) (void)hipFree(c->sym_send);
+            c->sym_send = c->sym_recv = nullptr;
+            if (c->cfg.kernel == MAPN_KERNEL_SYMMETRIC) return fail(MAPN_ERR_HIP, "set_gather_algorithm(6): the reaction rows could not be allocated");
+        } else {
+            HIP_TRY(hipMemset(c->sym_recv, 0, bytes));
+            sym_shard_masks(c->n / mapn::SYM_BLOCK, (uint32_t)c->cfg.world_size, (uint32_t)c->cfg.rank, c->sym_send_mask, c->sym_recv_mask);
+            const char *loop = getenv("MAPN_COMM_LOOPBACK");                     // a 1-rank communicator: nobody to exchange with
+            if (loop && loop[0] == '1') { c->sym_send_mask &= 1u << c->cfg.rank; c->sym_recv_mask = 1u << c->cfg.rank; }
+        }
+    }
     else if (c->sym_sharded) release_sym(c);
     c->gather_algo = algorithm;
     return MAPN_OK;
@@ -1728,7 +1819,7 @@ int mapn_set_sym_plan(mapn_ctx *c, uint32_t waves, uint32_t parts, uint32_t tape
     if (int rc = mapn_wait_idle(c)) return rc;
     HIP_TRY(hipSetDevice(c->device));
     const bool sharded = c->cfg.world_size > 1;
-    if (sharded && !(c->p2p_ready && c->gather_algo == 4))
+    if (sharded && !((c->p2p_ready && (c->gather_algo == 4 || c->gather_algo == 5)) || (c->comm && c->gather_algo == 6)))
         return fail(MAPN_ERR_STATE, "set_sym_plan: a sharded context runs the symmetric kernel under gather algorithm 4 only");
     if (waves == 0 && parts == 0) c->sym_user_plan = false;            // back to the default shape
     else {

@@ -80,6 +80,12 @@ struct SymArgs {
     uint32_t      half_d;     // nb / 2 when nb is even (the half-ring partner), else 0
     uint32_t      a0;         // sharded form: first I-block of this rank (gridDim.x = its shard_nbl blocks); 0 otherwise
     uint32_t      shard_nbl;  // sharded form: I-blocks of this rank -- brow is one row per (J-block, local I-block); 0 = unsharded
+    // sharded form, positions PUSHED by the peers (gather algorithm 5): before a wave reads another rank's bodies it waits
+    // (bounded) until every peer's publication counter has reached wait_need; those bodies are then read past this GPU's caches
+    const uint32_t *wait_counters;   // this rank's counter array [world] (null: nothing to wait for)
+    uint32_t     *wait_status;       // host-visible word: 1 + peer whose slice never arrived
+    uint64_t      wait_timeout_ticks;
+    uint32_t      wait_need, wait_world, wait_rank, wait_self;   // wait_self: loopback timing only -- the "peers" are this rank
     uint32_t      row_wt;     // rows are stored write-through (sc1) as they are produced instead of waiting in L2 for the end-of-kernel write-back
     float         mass, soft2, dt, damping;
     unsigned long long *stamps;   // diagnostic launches only (mapn_measure_clock), else null
@@ -108,7 +114,13 @@ struct SymShardArgs {
     const uint32_t *tab;                      // the (single) window's tables
     float4       *recv_peer[P2P_MAX_RANKS];   // rank q's receive region as mapped here: row [sender][body of q]
     uint32_t     *flags_peer[P2P_MAX_RANKS];  // rank q's flag array as mapped here
-    const float4 *pos_peer[P2P_MAX_RANKS];    // rank q's WRITTEN position buffer as mapped here (null: positions travel in another launch)
+    float4       *pos_peer[P2P_MAX_RANKS];    // rank q's WRITTEN position buffer as mapped here (null: positions travel in another launch)
+    uint32_t      phase;                      // 0: the whole exchange in this launch (peer-to-peer); 1: PACK only -- (1), rows stored where recv_peer[]
+                                              // points (a local send buffer), no counters; 2: REDUCE only -- (2) and (4) on rows that a
+                                              // collective library has delivered into recv_mine (gather algorithm 6)
+    uint32_t      send_row;                   // row of the destination's region this rank's reactions go to (its rank; 0 when packing)
+    uint32_t      push;                       // 1: the new positions are stored into every peer's buffer here (and the peers' NEXT force launch waits for
+                                              // the counter); 0: this launch waits for the peers' counters and pulls their slices
     const float4 *recv_mine;
     uint32_t     *flags_mine;
     uint32_t     *ticket;                     // [0] workgroups whose sends are acknowledged, [1] workgroups whose new positions are in memory
@@ -124,6 +136,9 @@ struct SymShardArgs {
 };
 hipError_t launch_sym_shard_exchange(const SymShardArgs &a, uint32_t max_workgroups, hipStream_t st);
 uint32_t sym_shard_exchange_resident_workgroups(uint32_t count, int cus);   // how many of its workgroups the device holds at once
+// stream operation: wait (bounded) until every peer's publication counter has reached `need` (positions pushed by the peers)
+hipError_t launch_p2p_wait(const uint32_t *counters, uint32_t need, uint32_t world, uint32_t rank, uint32_t self, uint64_t timeout_ticks,
+                           uint32_t *status, hipStream_t st);
 
 bool force_plan_supported(const ForcePlan &plan);
 hipError_t launch_force(const ForcePlan &plan, const StepArgs &a, hipStream_t st);

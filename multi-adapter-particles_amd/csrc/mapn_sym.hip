@@ -70,6 +70,42 @@ __device__ __forceinline__ void store_row(float4 *dst, float x, float y, float z
     }
 }
 
+// write-through store at system scope: once acknowledged (vmcnt) the data is in the owner's memory
+__device__ __forceinline__ void store_sys(float4 *dst, float x, float y, float z, float w)
+{
+    const f4r o = {x, y, z, w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(o) : "memory");
+}
+
+// lanes 0 .. 63 of the calling wave each wait (bounded) for one counter to reach `need`; returns 1 when all did
+__device__ __forceinline__ uint32_t wait_counters(const uint32_t *counters, uint32_t index, bool need_it, uint32_t need,
+                                                  uint64_t timeout_ticks, uint32_t *status, uint32_t code)
+{
+    uint32_t good = 1u;
+    if (need_it) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while ((int32_t)(__hip_atomic_load(counters + index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - need) < 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+                good = 0u;
+                __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    return __builtin_amdgcn_ballot_w64(good == 0u) == 0ull ? 1u : 0u;
+}
+
+// a body read past this GPU's caches (system-scope loads): a line of a buffer the PEERS store into must not come from a cache
+__device__ __forceinline__ float4 load_sys(const float4 *src)
+{
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(src);
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return make_float4(__builtin_bit_cast(float, (uint32_t)lo), __builtin_bit_cast(float, (uint32_t)(lo >> 32)),
+                       __builtin_bit_cast(float, (uint32_t)hi), __builtin_bit_cast(float, (uint32_t)(hi >> 32)));
+}
+
 struct SymBodies {
     v2f xi[SYM_K2], yi[SYM_K2], zi[SYM_K2];
     v2f ax[SYM_K2], ay[SYM_K2], az[SYM_K2];
@@ -143,6 +179,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     // kernel accumulates for them is never read (sym_reduce_integrate_kernel stops at n)
     const float4 far = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);
     auto body = [&](uint32_t i) { return i < p.n ? pos[i] : far; };
+    // a travelling body: under gather algorithm 5 it may lie in a slice a PEER stored into this rank's buffer
+    auto body_j = [&](uint32_t i) { return i >= p.n ? far : p.wait_counters ? load_sys(pos + i) : pos[i]; };
     SymBodies b;
 #pragma unroll
     for (int k = 0; k < SYM_K2; k++) {
@@ -174,7 +212,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     // the first piece may start inside a meeting (k0 = t0 % 64 steps of it ran in the previous wave): the lane then
     // starts with body (lane + k0) % 64; every later piece starts a meeting.  The NEXT piece's bodies are fetched
     // while the current one is computed (a meeting is ~9 us of a wave's life, a global load ~1-2 us).
-    if (t0 < t1) { meeting(t0 >> 6, jb, d, g); pn = body(jb * 64u + ((lane + t0) & 63u)); }
+    if (p.wait_counters) {
+        // (the I-block above is this rank's own slice; everything else waits for the peers' pushes -- the counters have
+        //  normally been there since before this launch started)
+        const bool need = lane < p.wait_world && lane != p.wait_rank;
+        (void)wait_counters(p.wait_counters, p.wait_self ? p.wait_rank : lane, need, p.wait_need, p.wait_timeout_ticks, p.wait_status, 1u + lane);
+    }
+    if (t0 < t1) { meeting(t0 >> 6, jb, d, g); pn = body_j(jb * 64u + ((lane + t0) & 63u)); }
+    asm volatile("" :: "v"(pn.x), "v"(pn.y), "v"(pn.z));   // (the first piece's bodies are waited for HERE: see the note in the loop)
     if (p.timeline) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the I-block and the first J-block have arrived
         asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tl_loop));
@@ -187,7 +232,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
             uint32_t lf = lane;
             asm volatile("" : "+v"(lf));                   // (as below: keep the load's address out of the loops' registers)
             meeting(t >> 6, jb, d, g);
-            pn = body(jb * 64u + lf);
+            pn = body_j(jb * 64u + lf);
         }
         // (Alternatives to moving the position, measured on one box each: a wave-private LDS copy of the J-block
         //  read with one ds_read_b128 per step, also one step ahead: 2-3 % slower; re-reading body (lane + k) % 64
@@ -207,6 +252,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
                 bx.x = lane_next(bx.x, next); by.x = lane_next(by.x, next); bz.x = lane_next(bz.x, next);
                 bx.y = lane_next(bx.y, next); by.y = lane_next(by.y, next); bz.y = lane_next(bz.y, next);
             }
+            // The next piece's bodies were fetched a whole piece ago: take them NOW, before this piece's row is stored.  Left
+            // to the compiler the wait sits at the head of the next piece as s_waitcnt vmcnt(0) -- loads and stores share the
+            // counter, so every piece would also wait for the row store just issued (1-2 us each; SQ_WAIT_ANY was 11 % of
+            // the wave-cycles).
+            asm volatile("" :: "v"(pn.x), "v"(pn.y), "v"(pn.z));
             if (d_cur == 0u) continue;
             const float fx = bx.x + bx.y, fy = by.x + by.y, fz = bz.x + bz.y;
             // (the row addresses are formed HERE, once per meeting, from a lane id the compiler cannot see through: hoisted out
@@ -376,31 +426,6 @@ __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs
 namespace {
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-// write-through store at system scope: once acknowledged (vmcnt) the data is in the owner's memory
-__device__ __forceinline__ void store_sys(float4 *dst, float x, float y, float z, float w)
-{
-    const f4v o = {x, y, z, w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(o) : "memory");
-}
-
-// lanes 0 .. world-1 of the calling wave each wait (bounded) for one counter to reach `need`; returns 1 when all did
-__device__ __forceinline__ uint32_t wait_counters(const uint32_t *counters, uint32_t index, bool need_it, uint32_t need,
-                                                  uint64_t timeout_ticks, uint32_t *status, uint32_t code)
-{
-    uint32_t good = 1u;
-    if (need_it) {
-        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-        while ((int32_t)(__hip_atomic_load(counters + index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - need) < 0) {
-            __builtin_amdgcn_s_sleep(4);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
-                good = 0u;
-                __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-        }
-    }
-    return __builtin_amdgcn_ballot_w64(good == 0u) == 0ull ? 1u : 0u;
-}
 }  // namespace
 
 // grid <= the workgroups the device holds at once (they wait for each other through the tickets)   block = 256
@@ -420,8 +445,10 @@ __device__ __forceinline__ uint32_t wait_counters(const uint32_t *counters, uint
 //      (this rank, rank - 1, rank - 2, ...), then mass, kick, damp, drift (hlsl:103-108) -- a fixed order throughout,
 //      so the replicas stay bit-identical.  The new position is stored write-through.
 //  (5) POSITIONS (pos_step != 0; else they travel in p2p_gather_kernel): the last workgroup through ticket[1]
-//      publishes this rank's slice to every peer (the counter p2p_gather_kernel uses); every workgroup waits for the
-//      peers' counters and pulls its share of their slices with cache-bypassing system-scope loads.
+//      publishes this rank's slice to every peer (the counter p2p_gather_kernel uses).  PULL form: every workgroup waits
+//      for the peers' counters and pulls its share of their slices with cache-bypassing system-scope loads.  PUSH form
+//      (gather algorithm 5): (4) has already stored every new position into every peer's replica as well, the counter
+//      says so, and the launch ends here -- the wait moves to the head of the peers' next force launch.
 template <int G>
 __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardArgs p)
 {
@@ -430,7 +457,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     __shared__ float part[G][3][B];
 
     const uint32_t *split0 = p.tab + 2u * (p.nwaves + 1u), *split1 = split0 + p.max_meetings;
-    const uint32_t total = p.world * p.count;
+    const uint32_t total = p.phase == 2u ? 0u : p.world * p.count;
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
         const uint32_t q = t / p.count, jl = t - q * p.count;
         if (!((p.send_mask >> q) & 1u)) continue;
@@ -453,8 +480,9 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
                 fx += h[u].x; fy += h[u].y; fz += h[u].z;
             }
         }
-        store_sys(p.recv_peer[q] + (size_t)p.rank * p.count + jl, fx, fy, fz, __builtin_bit_cast(float, p.step));
+        store_sys(p.recv_peer[q] + (size_t)p.send_row * p.count + jl, fx, fy, fz, __builtin_bit_cast(float, p.step));
     }
+    if (p.phase == 1u) return;                             // PACK: a collective library moves the rows, another launch reduces
 
     // this rank's own rows for the first pass of (4): nothing here depends on a peer
     const uint32_t bl = threadIdx.x % B, g = threadIdx.x / B;
@@ -482,7 +510,9 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x < 64u) {
+    if (p.phase == 2u) {
+        if (threadIdx.x == 0) ok = 1u;                     // REDUCE: the rows were delivered in stream order
+    } else if (threadIdx.x < 64u) {
         if (threadIdx.x == 0) {
             const uint32_t prev = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (prev + 1u == gridDim.x) {
@@ -539,8 +569,12 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         vx = __builtin_fmaf(ax, p.dt, vx) * p.damping;
         vy = __builtin_fmaf(ay, p.dt, vy) * p.damping;
         vz = __builtin_fmaf(az, p.dt, vz) * p.damping;
-        store_sys(p.pos_new + i, __builtin_fmaf(vx, p.dt, pos.x), __builtin_fmaf(vy, p.dt, pos.y), __builtin_fmaf(vz, p.dt, pos.z),
-                  __builtin_sqrtf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax))));
+        const float ox = __builtin_fmaf(vx, p.dt, pos.x), oy = __builtin_fmaf(vy, p.dt, pos.y), oz = __builtin_fmaf(vz, p.dt, pos.z);
+        const float ow = __builtin_sqrtf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)));
+        store_sys(p.pos_new + i, ox, oy, oz, ow);
+        if (p.push)                                        // ... and into every peer's replica (over xGMI when q is another GPU)
+            for (uint32_t q = 0; q < p.world; q++)
+                if (q != p.rank) store_sys(p.pos_peer[q] + i, ox, oy, oz, ow);
         float *vo = p.vel_new + 3 * (size_t)i;
         vo[0] = vx; vo[1] = vy; vo[2] = vz;
     }
@@ -559,11 +593,13 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
                         __hip_atomic_store(p.flags_peer[q] + p.rank, p.pos_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
+        if (p.push) return;                                // the peers' NEXT force launch waits for the counter; nothing to pull
         const uint32_t q = threadIdx.x;
         const uint32_t all_good = wait_counters(p.flags_mine, p.pull_self ? p.rank : q, q < p.world && q != p.rank, p.pos_step,
                                                 p.timeout_ticks, p.status, 1u + q);
         if (threadIdx.x == 0) ok = all_good;
     }
+    if (p.push) return;
     __syncthreads();
     if (!ok) return;
     // the peers' slices: 16 bytes per lane per access, eight in flight, past this GPU's caches (a line of q's buffer
@@ -589,6 +625,23 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
                 dst[0] = lo[u]; dst[1] = hi[u];
             }
     }
+}
+
+// stream operation (gather algorithm 5, wherever something other than the next sharded symmetric force launch is about to
+// read the replica): one wave waits (bounded) until every peer has pushed its slice
+__global__ __launch_bounds__(64) void p2p_wait_kernel(const uint32_t *counters, uint32_t need, uint32_t world, uint32_t rank, uint32_t self,
+                                                      uint64_t timeout_ticks, uint32_t *status)
+{
+    const uint32_t q = threadIdx.x;
+    (void)wait_counters(counters, self ? rank : q, q < world && q != rank, need, timeout_ticks, status, 1u + q);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+hipError_t launch_p2p_wait(const uint32_t *counters, uint32_t need, uint32_t world, uint32_t rank, uint32_t self, uint64_t timeout_ticks,
+                           uint32_t *status, hipStream_t st)
+{
+    hipLaunchKernelGGL(p2p_wait_kernel, dim3(1), dim3(64), 0, st, counters, need, world, rank, self, timeout_ticks, status);
+    return hipGetLastError();
 }
 
 hipError_t launch_force_sym(const SymArgs &a, uint32_t waves, hipStream_t st)

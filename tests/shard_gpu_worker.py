@@ -49,23 +49,27 @@ def main():
         c.close()
         dist.destroy_process_group()
         return
-    if mode in ("p2p", "flow", "sym"):
+    mixed = mode.endswith("_mixed")                     # every third step freezes part of the bodies: the step then runs one-sided
+    if mixed:
+        mode = mode[:-len("_mixed")]
+    if mode in ("p2p", "flow", "sym", "sympush"):
         # the in-library direct exchange: hipIpc-mapped peer buffers + device flags, no caller help;
         # "flow" = the same exchange overlapped inside the force launch (gather algorithm 3)
         c.p2p_setup_torch()
         # "sym" = the symmetric step sharded over the ranks (gather algorithm 4): reactions stored into the
         # owners' receive regions, positions pulled as in "p2p"
-        c.set_gather_algorithm({"p2p": 2, "flow": 3, "sym": 4}[mode])
+        # "sympush" = the same with the new positions PUSHED into the peers' replicas by the exchange launch (gather algorithm 5)
+        c.set_gather_algorithm({"p2p": 2, "flow": 3, "sym": 4, "sympush": 5}[mode])
         # several processes time-slice ONE GPU here: be generous (the big jobs allocate GBs of scratch inside their
         # first step, one process after the other)
         c.set_timeouts(p2p_ms=5000 if n <= 65536 else 60000)
         num_active = int(sys.argv[8]) if len(sys.argv) > 8 else n
         dist.barrier()                   # start stepping together: process start-up skews by seconds on a cold box
-        for _ in range(steps):
-            c.Simulate(num_active, c.GetFenceValue())
+        for k in range(steps):
+            c.Simulate(num_active if not (mixed and k % 3 == 1) else num_active // 2 + 100, c.GetFenceValue())
         c.WaitForGpu()
         assert c.p2p_status() == 0, f"p2p wait timed out: status {c.p2p_status()}"
-        if mode == "sym":
+        if mode in ("sym", "sympush") and not mixed:
             want = "force_sym_kernel" if (num_active == n and count % 1024 == 0) else "force_sgpr_kernel"
             assert c.kernel_stats().kernel_name.decode() == want, c.kernel_stats().kernel_name
         pos, vel = c.download_state()

@@ -103,24 +103,40 @@ def test_p2p_wait_timeout_is_reported_not_silent(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "timeout_reported"))
 
 
+@pytest.mark.parametrize("mode", ["sym", "sympush"])
 @pytest.mark.parametrize("world,n", [(2, 8192), (4, 8192), (8, 8192), (3, 9216), (2, 6144), (8, 16384)])
-def test_symmetric_step_sharded_over_processes(tmp_path, oracle, world, n):
+def test_symmetric_step_sharded_over_processes(tmp_path, oracle, world, n, mode):
     """Gather algorithm 4: every unordered pair of the whole job evaluated once.  Each rank runs the
     meetings of its own 1024-body blocks, stores the reactions it produced for every rank's bodies (summed
     over its blocks, one row per destination rank) into that rank's receive region, waits for the rows
     owed to it and integrates its slice.  `world` real processes on ONE GPU: even and odd numbers of
     blocks (the half-ring partner), one block per rank, a world that does not divide 8.  The free-running
     trajectory must match the oracle like the unsharded symmetric kernel does, and every replica must be
-    bit-identical (checked in the worker)."""
+    bit-identical (checked in the worker).  mode "sympush" = gather algorithm 5: the exchange launch also stores the
+    new positions into every peer's replica and the next force launch waits for the peers' counters."""
     from oracle import OracleSim, Params
     steps = 6
-    got = _run_ranks(tmp_path, world, n, steps, "sym", str(n))
+    got = _run_ranks(tmp_path, world, n, steps, mode, str(n))
     pos0, vel0 = oracle.initial_state(n, seed=1)
     sim = OracleSim(oracle, pos0, vel0, params=Params(mass=70000.0 / n))
     sim.simulate(steps=steps)
     dx = np.linalg.norm(got["pos"][:, :3].astype(np.float64) - sim.latest[0][:, :3], axis=1).max() / 400.0
     dv = np.linalg.norm(got["vel"].astype(np.float64) - sim.latest[1], axis=1).max() / 15.0
     assert dx < 8e-6 and dv < 1e-4, (dx, dv)
+
+
+def test_pushed_positions_give_the_same_bits_as_pulled_ones(tmp_path):
+    """Gather algorithm 5 against 4: the same arithmetic, another transport for the new positions -- bit-identical, also when
+    steps that freeze part of the bodies (one-sided kernel + peer-to-peer pull, preceded by the wait for the peers' pushes) are
+    mixed in."""
+    import os as _os
+    for tag, world, n, mix in (("plain", 4, 8192, ""), ("mixed", 2, 8192, "_mixed"), ("mixed8", 8, 8192, "_mixed")):
+        d4, d5 = tmp_path / (tag + "_pull"), tmp_path / (tag + "_push")
+        _os.makedirs(d4); _os.makedirs(d5)
+        a = _run_ranks(d4, world, n, 7, "sym" + mix, str(n))
+        b = _run_ranks(d5, world, n, 7, "sympush" + mix, str(n))
+        for k in ("pos", "vel", "other"):
+            np.testing.assert_array_equal(a[k], b[k])
 
 
 def test_symmetric_sharded_step_falls_back_bit_identically(tmp_path):

@@ -2,7 +2,7 @@
 # same-box issue counters of force_sym_kernel: round 2's kernel (ab/old) against the working tree (PMC passes only)
 R=$PWD; O=$R/gpurun_out/r03d; rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-P() { t=$1; d=$2; shift 2; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$t/$d -- python3 $R/$t/bench.py --steps 12 --warmup 3 --no-cpu-baseline > /dev/null 2> $O/$t.$d.err; }
+P() { t=$1; d=$2; shift 2; mkdir -p $O/$t; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$t/$d -- python3 $R/$t/bench.py --steps 12 --warmup 3 --no-cpu-baseline > /dev/null 2> $O/$t/$d.err; }
 ln -sfn $R $R/ab/new
 for t in ab/old ab/new; do
   P $t w1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS

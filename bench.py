@@ -44,10 +44,12 @@ def parse():
     ap.add_argument("--kernel", choices=["auto", "lds", "sgpr", "sym"], default="auto",
                     help="force kernel: scalar-cache (auto), LDS-tiled, or the symmetric (Newton's third law) kernel")
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl")
-    ap.add_argument("--gather", choices=["auto", "allgather", "sendrecv", "p2p", "flow", "sym"], default="auto",
-                    help="how the in-library exchange is issued: RCCL ncclAllGather, one group of RCCL send/recv pairs, or the "
-                         "direct peer-to-peer pull kernel (hipIpc + device flags); auto times every way that sets up and "
-                         "verifies on this node during untimed steps and keeps the fastest")
+    ap.add_argument("--gather", choices=["auto", "allgather", "sendrecv", "p2p", "flow", "sym", "sympush", "symrccl", "p2pall"], default="auto",
+                    help="how the in-library exchange is issued: RCCL ncclAllGather, one group of RCCL send/recv pairs, the "
+                         "direct peer-to-peer pull kernel (hipIpc + device flags), that exchange inside the force launch (flow), or the "
+                         "SYMMETRIC step sharded over the ranks (sym: positions pulled, sympush: pushed, symrccl: over RCCL alone); auto "
+                         "times every way that sets up and verifies on this node during untimed steps and keeps the fastest; p2pall = "
+                         "the same trial over the peer-to-peer forms only (no RCCL communicator: ranks sharing one device in tests)")
     ap.add_argument("--timer-interval", type=int, default=-1, help="time every T-th force launch of the timed region with HIP events (0 = off; default 8: each hipEventRecord costs ~4 us of queue time, 1.6 %% of a 0.9 ms step when every step carries three)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
@@ -57,6 +59,8 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed clock-ramp phase before the W warm-up steps (the chip needs a few hundred ms of "
                          "load to settle its clock; 0 disables)")
+    ap.add_argument("--p2p-timeout-ms", type=int, default=200,
+                    help="bound of the device-side waits of the peer-to-peer forms (raise it when ranks time-slice one device in tests)")
     ap.add_argument("--overlap", action="store_true", help="sharded mode: own-segment launch overlapped with the all-gather")
     ap.add_argument("--force-comm", action="store_true",
                     help="create the torch.distributed group and the in-library RCCL communicator even for one rank (exercises the sharded code path on a 1-GPU box)")
@@ -139,8 +143,12 @@ def pmc_traffic(kernel_name, n, world):
             continue                                   # stale: measured on another version of the kernels
         for k, v in d.items():
             if isinstance(v, dict) and kernel_name in k and "hbm_bytes_per_launch" in v:
+                pmc_traffic.valu_busy = v.get("valu_busy_fraction")
                 return v["hbm_bytes_per_launch"], os.path.relpath(f, here)
     return None, None
+
+
+pmc_traffic.valu_busy = None    # VALU busy fraction of the same (sha-matched) PMC summary, if it holds one
 
 
 def main():
@@ -182,7 +190,7 @@ def main():
     gather_fn = None
     if dist is not None:
         transport = a.transport
-        if transport == "rccl" and a.gather not in ("p2p", "flow", "sym"):
+        if transport == "rccl" and a.gather not in ("p2p", "flow", "sym", "sympush", "p2pall"):
             try:
                 c.comm_init_torch()
             except Exception as e:     # RCCL-in-library unavailable: use torch's RCCL instead, loudly
@@ -192,9 +200,12 @@ def main():
         if transport == "torch":
             c.set_external_gather(True)
             gather_fn = make_torch_gather(c, torch, dist, n, rank, world)
-    if a.plan:
-        kname, k, w, sb, fused = a.plan.split(",")
-        c.set_force_plan({"lds": mapn.KERNEL_LDS, "sgpr": mapn.KERNEL_SCALAR}[kname], int(k), int(w), int(sb), int(fused))
+    def apply_plan():
+        if a.plan:
+            kname, k, w, sb, fused = a.plan.split(",")
+            c.set_force_plan({"lds": mapn.KERNEL_LDS, "sgpr": mapn.KERNEL_SCALAR}[kname], int(k), int(w), int(sb), int(fused))
+
+    apply_plan()
     # each hipEventRecord costs ~4 us of queue time: at most one event PAIR per 4 steps, also for short runs
     timer_interval = a.timer_interval if a.timer_interval >= 0 else (8 if a.steps >= 32 else 4)
     c.set_timers(timer_interval)
@@ -237,10 +248,14 @@ def main():
         if a.overlap:                                   # --overlap: only the overlap structures
             candidates = [x for x in candidates if x[2]]
         p2p_ok = False
-        if a.gather in ("auto", "p2p", "flow", "sym") and world > 1:
+        sym_fits = mode == mapn.FORCE_ALL_PAIRS and (n // world) % 1024 == 0 and n % world == 0
+        if a.gather in ("auto", "symrccl") and world > 1 and sym_fits:
+            # the sharded symmetric step over RCCL alone: pack launch, grouped send/recv of the reaction rows, reduce launch, all-gather
+            candidates.append(("rccl+symmetric", 6, False))
+        if a.gather in ("auto", "p2p", "flow", "sym", "sympush", "p2pall") and world > 1:
             try:
                 c.p2p_setup_torch()
-                c.set_timeouts(p2p_ms=200)
+                c.set_timeouts(p2p_ms=a.p2p_timeout_ms)
                 ok = torch.tensor([1], device=red_dev)
             except Exception as e:
                 print(f"[bench rank {rank}] p2p setup failed: {e}", file=sys.stderr, flush=True)
@@ -248,23 +263,28 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # all ranks or none
             p2p_ok = bool(ok.item())
             # LAST: these have to prove themselves on this node
-            if p2p_ok and a.gather in ("auto", "p2p", "sym"):
-                candidates.append(("p2p", 2, False))               # (also the yardstick "p2p+symmetric" is verified against)
-            if p2p_ok and a.gather in ("auto", "flow"):
+            if p2p_ok and a.gather in ("auto", "p2p", "sym", "sympush", "p2pall"):
+                candidates.append(("p2p", 2, False))               # (also the yardstick the symmetric forms are verified against)
+            if p2p_ok and a.gather in ("auto", "flow", "p2pall"):
                 candidates.append(("p2p+inkernel", 3, False))  # the same exchange overlapped inside the force launch
-            if p2p_ok and a.gather in ("auto", "sym") and mode == mapn.FORCE_ALL_PAIRS and (n // world) % 1024 == 0 and n % world == 0:
+            if p2p_ok and a.gather in ("auto", "sym", "p2pall") and sym_fits:
                 # the SYMMETRIC step sharded over the ranks: every unordered pair of the job once, reactions
-                # stored into the owners' receive regions, positions pulled as in "p2p"
+                # stored into the owners' receive regions, positions pulled by the same launch
                 candidates.append(("p2p+symmetric", 4, False))
+            if p2p_ok and a.gather in ("auto", "sympush", "p2pall") and sym_fits:
+                # ... the same with the new positions PUSHED into the peers' replicas (posted writes instead of read round trips)
+                candidates.append(("p2p+symmetric+push", 5, False))
 
         def select(name, algo, overlap):
             c.set_gather_algorithm(algo)
             c.set_shard_overlap(overlap)
 
-        def symmetric_deviation():
+        def symmetric_deviation(sym_algo):
+            """Four steps from the initial state with the sharded symmetric step against the one-sided sharded step over the same
+            kind of transport (peer-to-peer pull for 4 / 5, RCCL all-gather for 6)."""
             import numpy as np
             got = []
-            for algo in (2, 4):
+            for algo in ((0 if sym_algo == 6 else 2), sym_algo):
                 c.WaitForGpu()
                 c.set_gather_algorithm(algo)
                 pos0, vel0 = mapn.generate_initial_state(n, seed=a.seed)
@@ -277,7 +297,7 @@ def main():
             return float(np.linalg.norm(got[0] - got[1], axis=1).max() / 400.0)
 
         def reinit():
-            c.set_gather_algorithm(0 if a.gather not in ("p2p", "flow", "sym") else 2)
+            c.set_gather_algorithm(0 if a.gather not in ("p2p", "flow", "sym", "sympush", "p2pall") else 2)
             c.set_shard_overlap(False)
             pos0, vel0 = mapn.generate_initial_state(n, seed=a.seed)
             c.upload_state(pos0, vel0)
@@ -291,12 +311,14 @@ def main():
                 """A context whose device-side wait timed out stays failed: replace it."""
                 nonlocal c
                 c.close()
-                c = mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed, rank=rank, world_size=world, flags=flags)
-                if a.gather not in ("p2p", "flow", "sym"):
+                c = mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed, rank=rank, world_size=world, flags=flags,
+                                 kernel=kern)               # (the SAME kernel choice and plan as asked for: ADVICE r2)
+                if a.gather not in ("p2p", "flow", "sym", "sympush", "p2pall"):
                     c.comm_init_torch()
                 if with_p2p:
                     c.p2p_setup_torch()
-                    c.set_timeouts(p2p_ms=200)
+                    c.set_timeouts(p2p_ms=a.p2p_timeout_ms)
+                apply_plan()
                 c.set_timers(timer_interval)
 
             p2p_dead = False
@@ -319,15 +341,15 @@ def main():
                     failed, dt_trial = str(e), float("inf")
                 bad = torch.tensor([1 if failed else 0], device=red_dev)
                 dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-                if not bad.item() and algo >= 2:
+                if not bad.item() and (algo >= 2 or algo == 6):
                     bad = torch.tensor([0 if (c.p2p_status() == 0 and replicas_consistent()) else 1], device=red_dev)
                     dist.all_reduce(bad, op=dist.ReduceOp.MAX)
                     if bad.item() and not failed:
                         failed = "replicas differ across ranks"
-                if not bad.item() and algo == 4:
+                if not bad.item() and algo in (4, 5, 6):
                     # identical replicas do not show that the reactions ARRIVED: compare four steps from the
-                    # initial state with the one-sided sharded step ("p2p", verified above)
-                    dev = symmetric_deviation()
+                    # initial state with the one-sided sharded step (verified above)
+                    dev = symmetric_deviation(algo)
                     bad = torch.tensor([0 if dev < 1e-5 else 1], device=red_dev)
                     dist.all_reduce(bad, op=dist.ReduceOp.MAX)
                     if bad.item():
@@ -336,7 +358,7 @@ def main():
                     if rank == 0:
                         print(f"[bench] exchange '{name}' failed on this node ({failed or 'on another rank'}) -> not used; state re-initialised",
                               file=sys.stderr, flush=True)
-                    if algo >= 2:
+                    if algo >= 2 and algo != 6:
                         p2p_failure = f"{name}: {failed or 'failed on another rank'}"
                         p2p_dead = algo == 2                    # the plain exchange failed: the in-kernel form shares its transport
                         rebuild(with_p2p="p2p" in trial)
@@ -347,8 +369,9 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 trial[name] = float(t.item()) / 30
             gather_algo = min(trial, key=trial.get) if trial else "allgather"
-            if a.gather == "sym" and "p2p+symmetric" in trial:
-                gather_algo = "p2p+symmetric"               # asked for by name: it only had to pass its check
+            for asked, nm in (("sym", "p2p+symmetric"), ("sympush", "p2p+symmetric+push"), ("symrccl", "rccl+symmetric")):
+                if a.gather == asked and nm in trial:
+                    gather_algo = nm                        # asked for by name: it only had to pass its check
             if rank == 0:
                 print("[bench] exchange trial: " + ", ".join(f"{k} {v*1e6:.1f} us/step" for k, v in trial.items()) + f" -> {gather_algo}",
                       file=sys.stderr, flush=True)
@@ -357,12 +380,12 @@ def main():
             if gather_algo.startswith("p2p") and not p2p_ok:
                 sys.exit("bench: --gather p2p requested but the peer-to-peer setup failed")
 
-        if a.gather == "sym" and gather_algo != "p2p+symmetric":
-            sys.exit("bench: --gather sym: the sharded symmetric step does not apply (N / ranks must be a multiple of 1024) or failed its check")
+        if a.gather in ("sym", "sympush", "symrccl") and "symmetric" not in gather_algo:
+            sys.exit(f"bench: --gather {a.gather}: the sharded symmetric step does not apply (N / ranks must be a multiple of 1024) or failed its check")
         chosen = {x[0]: x for x in candidates}.get(gather_algo, (gather_algo, 0, False))
         c.set_gather_algorithm(chosen[1])
         c.set_shard_overlap(chosen[2])
-        transport = "p2p (hipIpc + device flags)" if chosen[1] >= 2 else "rccl"
+        transport = "p2p (hipIpc + device flags)" if 2 <= chosen[1] <= 5 else "rccl"
     prewarm_steps = 0
     if a.prewarm_ms > 0:
         # same work as a timed step, just not timed: lets the clock settle so that a short K does
@@ -398,6 +421,19 @@ def main():
         elapsed = float(t.item())
 
     st = c.kernel_stats()
+    # how the step time is spread over the timed region: the steps that carried HIP events (every timer_interval-th), by quarter
+    quarters = None
+    try:
+        idx, step_ms, _ = c.step_samples()
+        if len(idx):
+            quarters = []
+            for qn in range(4):
+                m = (idx >= a.steps * qn // 4) & (idx < a.steps * (qn + 1) // 4)
+                quarters.append(round(float(step_ms[m].mean()), 5) if m.any() else None)
+            spread = {"steps_timed": int(len(idx)), "min_ms": round(float(step_ms.min()), 5), "median_ms": round(float(sorted(step_ms)[len(idx) // 2]), 5),
+                      "max_ms": round(float(step_ms.max()), 5)}
+    except mapn.MapnError:
+        pass
     first, count = c.shard_range()
     # the clock the chip held under this kernel: stamped diagnostic steps right behind the timed region
     # (same state of the chip; untimed).  Single GPU, scalar-cache kernel only.
@@ -410,10 +446,10 @@ def main():
     consistent = None
     sym_dev_after = None
     if dist is not None and world > 1 and gather_algo != "n/a":
-        consistent = replicas_consistent() and (gather_algo != "p2p" or c.p2p_status() == 0)
-        if consistent and gather_algo == "p2p+symmetric":
+        consistent = replicas_consistent() and c.p2p_status() == 0      # (the status word serves every device-side wait)
+        if consistent and "symmetric" in gather_algo:
             # once more, after the timed run: the sharded symmetric step against the one-sided one
-            dev_after = symmetric_deviation()
+            dev_after = symmetric_deviation({"p2p+symmetric": 4, "p2p+symmetric+push": 5, "rccl+symmetric": 6}[gather_algo])
             worst = torch.tensor([dev_after], dtype=torch.float64, device=red_dev)
             dist.all_reduce(worst, op=dist.ReduceOp.MAX)
             sym_dev_after = float(worst.item())
@@ -443,7 +479,9 @@ def main():
                        "kernel": st.kernel_name.decode(), "bodies_per_lane": st.bodies_per_lane, "j_splits": st.j_splits,
                        "grid": [st.grid_x, st.grid_y], "block": st.block_x, "fused_integrator": bool(st.fused),
                        "epilogue": {0: "partial rows + reduce_integrate launch", 1: "fused in the workgroup", 2: "last-arriver ticket (one launch per step)", 3: "symmetric kernel: force rows + sym_reduce_integrate launch"}.get(st.epilogue, "?"),
-                       "launches_per_step": int(st.force_launches_per_step) + (0 if st.fused else 1), "timer_interval": timer_interval,
+                       "launches_per_step": int(st.force_launches_per_step) * (1 if st.fused else 2), "timer_interval": timer_interval,
+                       "step_ms_by_quarter_of_the_timed_region": quarters, "step_ms_spread": spread if quarters else None,
+                       "step_ms_note": "device time (HIP events on the compute stream) of the steps of the timed region that carried events; ms_per_step is the wall clock over all of them",
                        "p2p_failure": p2p_failure, "sharded_symmetric_deviation_after_run": sym_dev_after},
         }
         if a.mode == "all_pairs":
@@ -470,6 +508,8 @@ def main():
                                    "frac_at_held_clock": (ach / (info.compute_units * held * 1e9 * 256 / 1e12)) if held else None,
                                    "flop_executed_per_pair": executed_per_pair,
                                    "frac_executed": ach / peak * executed_per_pair / FLOP_PER_PAIR,
+                                   "valu_busy": pmc_traffic.valu_busy,
+                                   "valu_busy_note": "4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / cycles of the committed PMC pass of these kernel sources (null: no pass on record for them)",
                                    "instruction_mix_ceiling": ("symmetric kernel: 14 packed ops x 4 cycles + 2 v_rsq_f32 x 8 cycles per 256 ordered interactions per SIMD "
                                                                "(+ 9 ds_bpermute_b32 per 16 per lane, no VALU cycles) = 111 % of the ALGORITHMIC peak at any clock: every "
                                                                "unordered pair is evaluated once (Newton's third law), so `frac` counts 20 flop per ordered pair of "

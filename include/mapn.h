@@ -361,6 +361,11 @@ typedef struct mapn_kernel_stats {
     uint32_t reserved;
 } mapn_kernel_stats;
 int mapn_get_kernel_stats(mapn_ctx *ctx, int reset, mapn_kernel_stats *out);
+/* The individual samples behind those means: for every step since the last reset that carried timer events (every T-th,
+ * mapn_set_timers) its index among the steps since the reset, the step's device time and its force launch's device time
+ * (0 when the step had none), in step order -- how the step time is SPREAD over a run.  *count = samples held (at most 4096);
+ * at most `capacity` are copied. */
+int mapn_get_step_samples(mapn_ctx *ctx, uint32_t *step_index, float *step_ms, float *force_ms, uint32_t capacity, uint32_t *count);
 
 /* Tuning hooks (tests exercise every kernel variant through these; AUTO restores the default).
  * bodies_per_lane in {2,4,8}, waves in {1,2,4,8,16}, sb >= 1 (j-split across workgroups).

@@ -134,6 +134,7 @@ SIGNATURES = {
     "mapn_get_device_info": (C.c_int, [C.c_int, C.POINTER(DeviceInfo)]),
     "mapn_device_count": (C.c_int, []),
     "mapn_get_kernel_stats": (C.c_int, [_ctx, C.c_int, C.POINTER(KernelStats)]),
+    "mapn_get_step_samples": (C.c_int, [_ctx, C.POINTER(C.c_uint32), _fp, _fp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mapn_set_force_plan": (C.c_int, [_ctx, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     "mapn_set_shard_overlap": (C.c_int, [_ctx, C.c_int]),
     "mapn_sym_plan_describe": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,

@@ -276,6 +276,16 @@ class Compute:
         check(self._lib.mapn_get_kernel_stats(self._ctx, int(reset), C.byref(st)))
         return st
 
+    def step_samples(self):
+        """(step index, step ms, force launch ms) arrays of every timed step since the last statistics reset."""
+        n = C.c_uint32()
+        check(self._lib.mapn_get_step_samples(self._ctx, None, None, None, 0, C.byref(n)))
+        idx = np.zeros(max(n.value, 1), np.uint32)
+        sm, fm = np.zeros(max(n.value, 1), np.float32), np.zeros(max(n.value, 1), np.float32)
+        check(self._lib.mapn_get_step_samples(self._ctx, idx.ctypes.data_as(C.POINTER(C.c_uint32)), sm.ctypes.data_as(_lib._fp),
+                                              fm.ctypes.data_as(_lib._fp), idx.size, C.byref(n)))
+        return idx[:n.value], sm[:n.value], fm[:n.value]
+
     @property
     def compute_stream(self) -> int:
         return int(self._lib.mapn_compute_stream(self._ctx) or 0)

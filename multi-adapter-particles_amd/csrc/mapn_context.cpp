@@ -50,6 +50,7 @@ constexpr uint64_t kHeapAlign = 64 * 1024; // Compute.cpp:185-194: 64 KiB placem
 
 struct StepTimer {
     hipEvent_t start = nullptr, force_done = nullptr, stop = nullptr;
+    uint64_t step_index = 0;     // which step since the last reset of the statistics carried these events
     bool pending = false;
     bool has_force = false;      // force_done recorded (a separate reduce launch follows the force launch)
     bool force_is_step = false;  // the step is ONE force launch: [start, stop] is the kernel's duration
@@ -130,6 +131,9 @@ struct mapn_ctx {
     uint64_t steps_enqueued = 0;
     double force_seconds_sum = 0.0;
     uint64_t force_launches = 0;
+    uint64_t steps_since_reset = 0;
+    struct StepSample { uint32_t step; float step_ms, force_ms; };
+    std::vector<StepSample> samples;         // every timed step since the last reset (mapn_get_step_samples), at most 4096
 
     // force plan
     bool plan_forced = false;
@@ -184,12 +188,14 @@ int resolve_timers(mapn_ctx *c, bool block)
         HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
         // D3D12GpuTimer.h:151-153: t = t*(averageOver-1); t = (t + delta)/averageOver
         c->ema_seconds = (c->ema_seconds * (kAverageOver - 1) + ms * 1e-3f) / kAverageOver;
+        float fms = 0.f;
         if (t.has_force || t.force_is_step) {
-            float fms = ms;
+            fms = ms;
             if (t.has_force) HIP_TRY(hipEventElapsedTime(&fms, t.start, t.force_done));
             c->force_seconds_sum += fms * 1e-3;
             c->force_launches++;
         }
+        if (c->samples.size() < 4096) c->samples.push_back({(uint32_t)t.step_index, ms, fms});
         t.pending = false;
     }
     return MAPN_OK;
@@ -490,6 +496,12 @@ mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t win
     // same box, rank 0 of 65 536 / 8: force launch 92.7 against 95.9 us; 65 536 unsharded 0.3 % faster (MAPN_SYM_ROW_WT=0: A/B)
     static const uint32_t wt = [] { const char *e = getenv("MAPN_SYM_ROW_WT"); return e ? (uint32_t)atoi(e) : 1u; }();
     a.row_wt = wt;
+    // the I-block reaches the workgroup's waves through LDS (a quarter of the global loads at launch start): same box, rank 0 of
+    // 65 536 / 8: prologue 2.9 against 5.0 us, force launch 89.9 against 92.4 us; 65 536 unsharded 0.45 % faster (MAPN_SYM_STAGE=0: A/B)
+    static const uint32_t stage = [] { const char *e = getenv("MAPN_SYM_STAGE"); return e ? (uint32_t)atoi(e) : 1u; }();
+    a.stage_iblock = stage;
+    static const uint32_t altp = [] { const char *e = getenv("MAPN_SYM_ALT_PRIO"); return e ? (uint32_t)atoi(e) : 0u; }();   // A/B
+    a.alt_prio = altp;
     return a;
 }
 
@@ -1188,7 +1200,9 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
         if (timer->pending) { if (int rc = resolve_timers(c, true)) return rc; }
         timer->has_force = false;
         timer->force_is_step = false;
+        timer->step_index = c->steps_since_reset;
     }
+    c->steps_since_reset++;
     const bool use_graph = (c->cfg.flags & MAPN_FLAG_USE_GRAPH) && !c->comm && !c->p2p_ready && !timer && active > 0 &&
                            !c->stamp_next;                 // a stamped diagnostic step is never a replay
     if (int rc = use_graph ? enqueue_step_graph(c, active) : enqueue_step(c, active, timer)) return rc;
@@ -1658,7 +1672,7 @@ int mapn_set_gather_algorithm(mapn_ctx *c, int algorithm)
             if (loop && loop[0] == '1') { c->sym_send_mask &= 1u << c->cfg.rank; c->sym_recv_mask = 1u << c->cfg.rank; }
         }
     }
-    else if (c->sym_sharded) release_sym(c);
+    if (algorithm < 4 && c->sym_sharded) release_sym(c);               // the other algorithms run the one-sided kernels: give the scratch back
     c->gather_algo = algorithm;
     return MAPN_OK;
 }
@@ -1960,7 +1974,22 @@ int mapn_get_kernel_stats(mapn_ctx *c, int reset, mapn_kernel_stats *out)
         out->force_launches_per_step = std::max(1u, c->last_launches / 2u);   // every force launch (one per window of partner distance) is followed by a reduce launch (fused = 0); sharded: by the exchange launch
         out->grid_x = (i_count + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK; out->grid_y = p.sb; out->j_splits = p.sb * p.waves; out->fused = 0; out->epilogue = 3;   // grid (I-blocks, parts)
     }
-    if (reset) { c->force_launches = 0; c->force_seconds_sum = 0.0; }
+    if (reset) { c->force_launches = 0; c->force_seconds_sum = 0.0; c->steps_since_reset = 0; c->samples.clear(); }
+    return MAPN_OK;
+}
+
+int mapn_get_step_samples(mapn_ctx *c, uint32_t *step_index, float *step_ms, float *force_ms, uint32_t capacity, uint32_t *count)
+{
+    if (!c || !count) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = resolve_timers(c, true)) return rc;
+    std::sort(c->samples.begin(), c->samples.end(), [](const mapn_ctx::StepSample &a, const mapn_ctx::StepSample &b) { return a.step < b.step; });
+    *count = (uint32_t)c->samples.size();
+    for (uint32_t k = 0; k < *count && k < capacity; k++) {
+        if (step_index) step_index[k] = c->samples[k].step;
+        if (step_ms) step_ms[k] = c->samples[k].step_ms;
+        if (force_ms) force_ms[k] = c->samples[k].force_ms;
+    }
     return MAPN_OK;
 }
 

@@ -86,6 +86,8 @@ struct SymArgs {
     uint32_t     *wait_status;       // host-visible word: 1 + peer whose slice never arrived
     uint64_t      wait_timeout_ticks;
     uint32_t      wait_need, wait_world, wait_rank, wait_self;   // wait_self: loopback timing only -- the "peers" are this rank
+    uint32_t      alt_prio;       // != 0: the SIMD's two waves take turns at the higher issue priority every 2^alt_prio steps (one-round launches)
+    uint32_t      stage_iblock;   // the workgroup's waves share the I-block's global loads through LDS
     uint32_t      row_wt;     // rows are stored write-through (sc1) as they are produced instead of waiting in L2 for the end-of-kernel write-back
     float         mass, soft2, dt, damping;
     unsigned long long *stamps;   // diagnostic launches only (mapn_measure_clock), else null

@@ -182,14 +182,34 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     // a travelling body: under gather algorithm 5 it may lie in a slice a PEER stored into this rank's buffer
     auto body_j = [&](uint32_t i) { return i >= p.n ? far : p.wait_counters ? load_sys(pos + i) : pos[i]; };
     SymBodies b;
+    if (p.stage_iblock) {
+        // the workgroup's waves all hold the SAME I-block: each fetches 16 / WAVES of its 16 lane-slices, the slices meet in LDS
+        // (the space the closing combination uses) and every wave takes all 16 from there -- a quarter of the global loads in
+        // the moment when every wave of the launch starts at once
+        float4 *stage = reinterpret_cast<float4 *>(&comb[0][0][0]);
+        constexpr uint32_t PER = 2u * SYM_K2 / WAVES;
 #pragma unroll
-    for (int k = 0; k < SYM_K2; k++) {
-        const float4 b0 = body(a * SYM_IB + (2 * k) * 64u + lane), b1 = body(a * SYM_IB + (2 * k + 1) * 64u + lane);
-        b.xi[k] = v2f{b0.x, b1.x}; b.yi[k] = v2f{b0.y, b1.y}; b.zi[k] = v2f{b0.z, b1.z};
-        b.ax[k] = v2f{0.f, 0.f}; b.ay[k] = v2f{0.f, 0.f}; b.az[k] = v2f{0.f, 0.f};
+        for (uint32_t c = 0; c < PER; c++) stage[(w * PER + c) * 64u + lane] = body(a * SYM_IB + (w * PER + c) * 64u + lane);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SYM_K2; k++) {
+            const float4 b0 = stage[(2 * k) * 64u + lane], b1 = stage[(2 * k + 1) * 64u + lane];
+            b.xi[k] = v2f{b0.x, b1.x}; b.yi[k] = v2f{b0.y, b1.y}; b.zi[k] = v2f{b0.z, b1.z};
+            b.ax[k] = v2f{0.f, 0.f}; b.ay[k] = v2f{0.f, 0.f}; b.az[k] = v2f{0.f, 0.f};
+        }
+        __syncthreads();                                   // (the space is written again only by the closing combination)
+    } else {
+#pragma unroll
+        for (int k = 0; k < SYM_K2; k++) {
+            const float4 b0 = body(a * SYM_IB + (2 * k) * 64u + lane), b1 = body(a * SYM_IB + (2 * k + 1) * 64u + lane);
+            b.xi[k] = v2f{b0.x, b1.x}; b.yi[k] = v2f{b0.y, b1.y}; b.zi[k] = v2f{b0.z, b1.z};
+            b.ax[k] = v2f{0.f, 0.f}; b.ay[k] = v2f{0.f, 0.f}; b.az[k] = v2f{0.f, 0.f};
+        }
     }
     const v2f soft2 = v2f{p.soft2, p.soft2};
     const int next = (int)((lane + 1u) & 63u) * 4;         // ds_bpermute: take the value of lane + 1
+    uint32_t prio_slot = 0;                                // which of the SIMD's wave slots this wave sits in (HW_ID.wave_id)
+    if (p.alt_prio) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw)); prio_slot = hw; }
 
     // J-block and partner distance of meeting m of this launch (d = 0: the block itself, one-sided)
     auto meeting = [&](uint32_t m, uint32_t &jb, uint32_t &d, uint32_t &g) {
@@ -245,6 +265,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
             v2f bx = v2f{0.f, 0.f}, by = v2f{0.f, 0.f}, bz = v2f{0.f, 0.f};
 #pragma nounroll                                           // (unrolled by two: no loop-carried copies, but the moves issue late: 2 % slower)
             for (uint32_t k = 0; k < steps; k++) {
+                // ONE round of workgroups (a shard): the SIMD serves its older wave first, which then leaves early and its partner
+                // finishes alone at 84 % of the issue rate; taking turns at the higher priority keeps both resident to the end
+                if (p.alt_prio) {
+                    if ((((t0 + k) >> p.alt_prio) ^ prio_slot) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                }
                 // the travelling position does not change during the step: its move overlaps the step
                 const float nx = lane_next(xj, next), ny = lane_next(yj, next), nz = lane_next(zj, next);
                 sym_step(b, xj, yj, zj, soft2, bx, by, bz);

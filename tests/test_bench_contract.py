@@ -60,6 +60,9 @@ def test_bench_json_contract():
     assert 1.5 < rf["held_clock_ghz"] <= 2.45 and rf["frac"] < rf["frac_at_held_clock"] < 1.2
     assert d["config"]["kernel"] == "force_sym_kernel" and d["config"]["launches_per_step"] == 2
     assert 0.45 < rf["frac_executed"] < rf["frac"]                  # 12 of the 20 algorithmic flop per ordered pair are executed
+    q = d["config"]["step_ms_by_quarter_of_the_timed_region"]       # the spread of the step time over the timed region, from HIP events
+    assert len(q) == 4 and all(x is not None and 0.3 < x < 2.0 for x in q) and d["config"]["step_ms_spread"]["steps_timed"] >= 4
+    assert "valu_busy" in rf
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e8 and "sample" in cb
     assert d["value"] > 3.0e12            # the 40 %-of-peak target is 3.15e12 at kernel level
@@ -128,3 +131,25 @@ def test_bench_two_ranks_one_gpu_with_the_sharded_symmetric_step():
     assert d["config"]["replicas_bit_identical_after_run"] is True and d["config"]["p2p_failure"] is None
     assert d["config"]["launches_per_step"] == 2 and set(d["config"]["exchange_trial_us_per_step"]) == {"p2p", "p2p+symmetric"}
     assert d["config"]["sharded_symmetric_deviation_after_run"] < 1e-5 and d["config"]["valid"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.slow
+def test_bench_eight_ranks_one_gpu_trial_over_every_peer_to_peer_form():
+    """The exchange TRIAL of bench.py as the driver's 8-GPU run goes through it, with eight ranks sharing device 0 (gloo
+    rendezvous; RCCL refuses several ranks on one device, so the trial runs over the peer-to-peer forms: pull, in-kernel
+    "flow", sharded symmetric with pulled and with pushed positions): every form is set up, stepped, checked for bit-identical
+    replicas and -- the symmetric ones -- against the one-sided sharded step; all ranks take the same decision."""
+    port = 29400 + (os.getpid() % 150)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "8", "--steps", "24", "--warmup", "3", "--gather", "p2pall", "--dist-backend", "gloo",
+                        "--same-device", "--prewarm-ms", "10", "--bodies", "16384", "--p2p-timeout-ms", "10000"], capture_output=True, text=True, timeout=1500)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["n_gpus"] == 8 and cfg["parallelism"] == "bodies sharded x8"
+    assert set(cfg["exchange_trial_us_per_step"]) == {"p2p", "p2p+inkernel", "p2p+symmetric", "p2p+symmetric+push"}, (cfg, r.stderr[-2000:])
+    assert cfg["exchange"] in cfg["exchange_trial_us_per_step"] and cfg["p2p_failure"] is None
+    assert cfg["replicas_bit_identical_after_run"] is True and cfg["valid"] is True

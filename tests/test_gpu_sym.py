@@ -184,3 +184,42 @@ def test_symmetric_context_falls_back_where_the_kernel_does_not_apply(oracle):
     with mapn.Compute(1000, mass=1.0, kernel=mapn.KERNEL_SYMMETRIC) as c:       # less than one block: one-sided
         draw(c, 1)
         assert c.kernel_stats().kernel_name.decode() == "force_sgpr_kernel"
+
+
+def test_rccl_form_of_the_sharded_symmetric_step_one_rank_loopback(oracle, monkeypatch):
+    """Gather algorithm 6: pack launch -> one group of ncclSend / ncclRecv -> reduce launch -> ncclAllGather.  RCCL refuses two
+    ranks on one device, so what runs here is rank 0 of a 2-rank job on a ONE-rank communicator (MAPN_COMM_LOOPBACK): the pack
+    and reduce launches, the own reactions travelling through the receive rows, the exchange-number tags, the collective calls.
+    Rank 1's reactions never arrive, so the expectation is built accordingly (float64): rank 0's blocks meet what the schedule
+    says, its bodies get the forces from those meetings plus the reactions of meetings between two of rank 0's own blocks."""
+    from mapn import shard
+    monkeypatch.setenv("MAPN_COMM_LOOPBACK", "1")
+    n, world = 8192, 2
+    nb, nbl = n // 1024, n // 1024 // world
+    mass, soft2, dt = 70000.0 / n, 25.0, 0.1
+    pos, vel = oracle.initial_state(n, seed=1)
+    with mapn.Compute(n, mass=mass, rank=0, world_size=world) as c:
+        c.comm_init(mapn.Compute.comm_unique_id())
+        c.set_gather_algorithm(6)
+        plan = c.sym_plan()
+        assert plan.nbl == nbl and plan.a0 == 0
+        draw(c, 1)
+        p, v = c.download_state()
+        assert c.kernel_stats().kernel_name.decode() == "force_sym_kernel" and c.p2p_status() == 0
+    x = pos[:, :3].astype(np.float64)
+    acc = np.zeros((n, 3))
+    for a, b, d, symmetric in shard.sym_meetings(nb):
+        if a >= nbl:
+            continue                                           # a block of rank 1: not run here
+        xi, xj = x[a * 1024:(a + 1) * 1024], x[b * 1024:(b + 1) * 1024]
+        r = xj[None, :, :] - xi[:, None, :]
+        f = r * ((r * r).sum(-1) + soft2)[..., None] ** -1.5
+        acc[a * 1024:(a + 1) * 1024] += f.sum(1)
+        if symmetric and b < nbl:
+            acc[b * 1024:(b + 1) * 1024] -= f.sum(0)          # the reaction stays on this rank: through the receive rows
+    own = slice(0, nbl * 1024)
+    vexp = vel[own].astype(np.float64) + acc[own] * mass * dt
+    pexp = x[own] + vexp * dt
+    assert errs(p[own, :3], pexp, SPREAD)[0] < 1e-6
+    assert errs(v[own], vexp, SPEED)[0] < 2e-5
+    np.testing.assert_array_equal(p[nbl * 1024:], pos[nbl * 1024:])      # the other rank's slice: untouched

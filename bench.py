@@ -285,14 +285,16 @@ def main():
             import numpy as np
             got = []
             for algo in ((0 if sym_algo == 6 else 2), sym_algo):
-                c.WaitForGpu()
+                sync()
                 c.set_gather_algorithm(algo)
                 pos0, vel0 = mapn.generate_initial_state(n, seed=a.seed)
                 c.upload_state(pos0, vel0)
                 sync()
                 for _ in range(4):
                     step()
-                c.WaitForGpu()
+                # ALL ranks must have finished before anyone re-initialises: a rank that is a step ahead would overwrite the
+                # buffers a slower peer is still pulling from / pushing into (seen with 8 ranks time-slicing one device)
+                sync()
                 got.append(c.download_state()[0][:, :3].astype(np.float64))
             return float(np.linalg.norm(got[0] - got[1], axis=1).max() / 400.0)
 

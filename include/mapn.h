@@ -219,6 +219,9 @@ int mapn_get_is_uma(const mapn_ctx *ctx);
  * the in-memory CopyState).  upload writes the same data into BOTH ping-pong buffers, like
  * InitializeParticles; download reads the latest state (buffer 1 - index) after draining.
  * pos4: N*4 floats, vel3: N*3 floats, host memory; either may be NULL.
+ * Sharded with a peer-to-peer exchange (gather algorithms 2 - 5): the peers read from / store into this context's
+ * position buffers, so upload (and mapn_load_snapshot) is COLLECTIVE -- every rank must have drained its own
+ * work (mapn_wait_idle) and the ranks must have met at a barrier of the launcher before any of them uploads.
  */
 int mapn_upload_state(mapn_ctx *ctx, const float *pos4, const float *vel3);
 int mapn_download_state(mapn_ctx *ctx, float *pos4, float *vel3);
@@ -402,6 +405,8 @@ typedef struct mapn_sym_plan_info {
     uint32_t parts, taper1, taper2, waves;
     uint32_t brows, max_meetings, table_stride;
     uint32_t a0, nbl;
+    uint32_t active_compute_units;  /* sharded: compute units that really take this process's workgroups (probed; a CU mask leaves fewer) */
+    uint32_t exchange_workgroups;   /* sharded: most workgroups the exchange launch may have (they must all be resident at once) */
     uint64_t scratch_bytes;      /* device memory the symmetric step holds (rows, running sum, tables) */
     char     error[256];         /* why a shape was refused / why the kernel does not run */
 } mapn_sym_plan_info;

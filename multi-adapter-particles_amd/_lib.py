@@ -75,7 +75,8 @@ class SymPlanInfo(C.Structure):
         ("nb", C.c_uint32), ("groups", C.c_uint32), ("windows", C.c_uint32),
         ("parts", C.c_uint32), ("taper1", C.c_uint32), ("taper2", C.c_uint32), ("waves", C.c_uint32),
         ("brows", C.c_uint32), ("max_meetings", C.c_uint32), ("table_stride", C.c_uint32),
-        ("a0", C.c_uint32), ("nbl", C.c_uint32), ("scratch_bytes", C.c_uint64), ("error", C.c_char * 256),
+        ("a0", C.c_uint32), ("nbl", C.c_uint32), ("active_compute_units", C.c_uint32), ("exchange_workgroups", C.c_uint32),
+        ("scratch_bytes", C.c_uint64), ("error", C.c_char * 256),
     ]
 
 

@@ -338,7 +338,7 @@ class SymPlan:
 
     def __init__(self, info, windows, tables):
         self.info, self.windows, self.tables = info, windows, tables
-        for k in ("nb", "groups", "parts", "taper1", "taper2", "waves", "brows", "max_meetings", "table_stride", "a0", "nbl", "scratch_bytes"):
+        for k in ("nb", "groups", "parts", "taper1", "taper2", "waves", "brows", "max_meetings", "table_stride", "a0", "nbl", "active_compute_units", "exchange_workgroups", "scratch_bytes"):
             setattr(self, k, int(getattr(info, k)))
         self.nwaves = self.parts * self.waves
 

@@ -64,6 +64,7 @@ struct mapn_ctx {
     uint32_t first = 0, count = 0;            // shard [first, first+count)
     int device = 0;
     int cus = 0;
+    int cus_active = 0;                       // compute units that really take this process's workgroups (probed when the sharded symmetric step is prepared)
     hipStream_t compute = nullptr, comm_stream = nullptr;
 
     float4 *pos_heap = nullptr;               // one allocation holding both position buffers
@@ -437,7 +438,12 @@ int prepare_sym(mapn_ctx *c, bool sharded)
     c->sym_parts = pl.parts; c->sym_waves = pl.waves;
     c->sym_sharded = sharded;
     c->sym_ready = true;
-    if (sharded) c->sym_exchange_cap = mapn::sym_shard_exchange_resident_workgroups(c->count, c->cus);
+    if (sharded) {
+        // the exchange launch's workgroups must all be resident at once: size it for the compute units this process really gets
+        // (HSA_CU_MASK / a partition leave fewer than the device properties say), not for the nominal count
+        if (!c->cus_active) { c->cus_active = mapn::probe_active_compute_units(c->compute); if (c->cus_active <= 0 || c->cus_active > c->cus) c->cus_active = c->cus; }
+        c->sym_exchange_cap = mapn::sym_shard_exchange_resident_workgroups(c->count, c->cus_active);
+    }
     return MAPN_OK;
 }
 
@@ -500,8 +506,6 @@ mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t win
     // 65 536 / 8: prologue 2.9 against 5.0 us, force launch 89.9 against 92.4 us; 65 536 unsharded 0.45 % faster (MAPN_SYM_STAGE=0: A/B)
     static const uint32_t stage = [] { const char *e = getenv("MAPN_SYM_STAGE"); return e ? (uint32_t)atoi(e) : 1u; }();
     a.stage_iblock = stage;
-    static const uint32_t altp = [] { const char *e = getenv("MAPN_SYM_ALT_PRIO"); return e ? (uint32_t)atoi(e) : 0u; }();   // A/B
-    a.alt_prio = altp;
     return a;
 }
 
@@ -1863,6 +1867,8 @@ int mapn_get_sym_plan(mapn_ctx *c, mapn_sym_plan_info *info, uint32_t *windows, 
     info->a0 = c->sym_sharded ? (uint32_t)c->cfg.rank * (c->count / mapn::SYM_BLOCK) : 0u;
     info->nbl = c->sym_sharded ? c->count / mapn::SYM_BLOCK : 0u;
     info->scratch_bytes = c->sym_scratch_bytes;
+    info->active_compute_units = c->sym_sharded ? (uint32_t)c->cus_active : 0u;
+    info->exchange_workgroups = c->sym_sharded ? c->sym_exchange_cap : 0u;
     if (windows)
         for (size_t k = 0; k < p.windows.size(); k++) {
             windows[4 * k + 0] = p.windows[k].g0; windows[4 * k + 1] = p.windows[k].g1;

@@ -86,7 +86,6 @@ struct SymArgs {
     uint32_t     *wait_status;       // host-visible word: 1 + peer whose slice never arrived
     uint64_t      wait_timeout_ticks;
     uint32_t      wait_need, wait_world, wait_rank, wait_self;   // wait_self: loopback timing only -- the "peers" are this rank
-    uint32_t      alt_prio;       // != 0: the SIMD's two waves take turns at the higher issue priority every 2^alt_prio steps (one-round launches)
     uint32_t      stage_iblock;   // the workgroup's waves share the I-block's global loads through LDS
     uint32_t      row_wt;     // rows are stored write-through (sc1) as they are produced instead of waiting in L2 for the end-of-kernel write-back
     float         mass, soft2, dt, damping;
@@ -137,7 +136,8 @@ struct SymShardArgs {
     float         mass, dt, damping;
 };
 hipError_t launch_sym_shard_exchange(const SymShardArgs &a, uint32_t max_workgroups, hipStream_t st);
-uint32_t sym_shard_exchange_resident_workgroups(uint32_t count, int cus);   // how many of its workgroups the device holds at once
+uint32_t sym_shard_exchange_resident_workgroups(uint32_t count, int cus);   // how many of its workgroups `cus` compute units hold at once (with headroom)
+int probe_active_compute_units(hipStream_t st);                             // compute units that really take this process's workgroups (0: probe failed)
 // stream operation: wait (bounded) until every peer's publication counter has reached `need` (positions pushed by the peers)
 hipError_t launch_p2p_wait(const uint32_t *counters, uint32_t need, uint32_t world, uint32_t rank, uint32_t self, uint64_t timeout_ticks,
                            uint32_t *status, hipStream_t st);

@@ -208,8 +208,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     }
     const v2f soft2 = v2f{p.soft2, p.soft2};
     const int next = (int)((lane + 1u) & 63u) * 4;         // ds_bpermute: take the value of lane + 1
-    uint32_t prio_slot = 0;                                // which of the SIMD's wave slots this wave sits in (HW_ID.wave_id)
-    if (p.alt_prio) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw)); prio_slot = hw; }
 
     // J-block and partner distance of meeting m of this launch (d = 0: the block itself, one-sided)
     auto meeting = [&](uint32_t m, uint32_t &jb, uint32_t &d, uint32_t &g) {
@@ -265,11 +263,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
             v2f bx = v2f{0.f, 0.f}, by = v2f{0.f, 0.f}, bz = v2f{0.f, 0.f};
 #pragma nounroll                                           // (unrolled by two: no loop-carried copies, but the moves issue late: 2 % slower)
             for (uint32_t k = 0; k < steps; k++) {
-                // ONE round of workgroups (a shard): the SIMD serves its older wave first, which then leaves early and its partner
-                // finishes alone at 84 % of the issue rate; taking turns at the higher priority keeps both resident to the end
-                if (p.alt_prio) {
-                    if ((((t0 + k) >> p.alt_prio) ^ prio_slot) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-                }
                 // the travelling position does not change during the step: its move overlaps the step
                 const float nx = lane_next(xj, next), ny = lane_next(yj, next), nz = lane_next(zj, next);
                 sym_step(b, xj, yj, zj, soft2, bx, by, bz);
@@ -685,9 +678,37 @@ namespace {
 int exchange_threads_per_body(uint32_t count) { return count <= 16384u ? 8 : count <= 65536u ? 4 : 1; }
 }  // namespace
 
+// Which compute units actually take this process's workgroups (a CU mask, a partition mode or a reservation can leave
+// fewer than the device properties promise): every probe wave marks the unit it runs on.
+__global__ __launch_bounds__(64) void cu_probe_kernel(uint32_t *bitmap)
+{
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n s_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+    for (int k = 0; k < 8; k++) __builtin_amdgcn_s_sleep(127);            // stay a moment, so that the dispatcher has to use every unit
+    const uint32_t id = ((((xcc & 15u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u) + ((hw >> 8) & 15u);
+    if (threadIdx.x == 0) atomicOr(bitmap + id / 32u, 1u << (id % 32u));
+}
+
+int probe_active_compute_units(hipStream_t st)
+{
+    uint32_t *bits = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&bits), 512) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    uint32_t host[128] = {};
+    int n = 0;
+    if (hipMemsetAsync(bits, 0, 512, st) == hipSuccess) {
+        hipLaunchKernelGGL(cu_probe_kernel, dim3(16384), dim3(64), 0, st, bits);
+        if (hipMemcpyAsync(host, bits, 512, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+            for (uint32_t w : host) n += __builtin_popcount(w);
+    }
+    (void)hipGetLastError();
+    (void)hipFree(bits);
+    return n;
+}
+
 // The exchange kernel's workgroups wait for each other (tickets) and for the peers: all of them must be resident at
-// once.  What the device can hold is asked of the runtime (registers, LDS), and half of it is left to whatever else
-// is running (a queued fence wait, the comm stream, another rank's kernels on a shared device).
+// once.  What ONE unit can hold is asked of the runtime (registers, LDS), how many units there are is probed
+// (probe_active_compute_units), and half of the product is left to whatever else is running (a queued fence wait, the comm
+// stream, another rank's kernels on a shared device).
 uint32_t sym_shard_exchange_resident_workgroups(uint32_t count, int cus)
 {
     int per_cu = 0;

@@ -113,7 +113,7 @@ extern "C" int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, u
     info->nb = p.nb; info->groups = p.groups; info->windows = (uint32_t)p.windows.size();
     info->parts = p.parts; info->taper1 = p.taper1; info->taper2 = p.taper2; info->waves = p.waves;
     info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
-    info->a0 = 0; info->nbl = 0;
+    info->a0 = 0; info->nbl = 0; info->active_compute_units = 0; info->exchange_workgroups = 0; info->scratch_bytes = 0;
     if (windows)
         for (size_t k = 0; k < p.windows.size(); k++) {
             windows[4 * k + 0] = p.windows[k].g0; windows[4 * k + 1] = p.windows[k].g1;

@@ -60,6 +60,9 @@ def main():
         # owners' receive regions, positions pulled as in "p2p"
         # "sympush" = the same with the new positions PUSHED into the peers' replicas by the exchange launch (gather algorithm 5)
         c.set_gather_algorithm({"p2p": 2, "flow": 3, "sym": 4, "sympush": 5}[mode])
+        if os.environ.get("HSA_CU_MASK") and mode in ("sym", "sympush") and count % 1024 == 0:
+            plan = c.sym_plan()                 # the probe must have seen the mask, and the launch must be sized for it
+            assert plan.active_compute_units <= 64 and plan.exchange_workgroups <= 4 * plan.active_compute_units, (plan.active_compute_units, plan.exchange_workgroups)
         # several processes time-slice ONE GPU here: be generous (the big jobs allocate GBs of scratch inside their
         # first step, one process after the other)
         c.set_timeouts(p2p_ms=5000 if n <= 65536 else 60000)

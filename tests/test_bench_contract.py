@@ -32,7 +32,7 @@ def test_committed_pmc_summaries_belong_to_the_current_kernel_sources():
     sha = bench.kernel_source_sha16()
     for tag, kernel in (("r02_sym", "force_sym_kernel"), ("r02_onesided", "force_sgpr_kernel")):
         d = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json")))
-        assert d["_kernel_source_sha16"] == sha, f"profiles/{tag}_pmc_summary.json is stale: re-run tools/r02_run18.sh"
+        assert d["_kernel_source_sha16"] == sha, f"profiles/{tag}_pmc_summary.json is stale: re-run tools/evidence.sh pmc"
     traffic, src = bench.pmc_traffic("force_sym_kernel", 65536, 1)
     assert traffic and 5e7 < traffic < 2e8 and src.endswith("r02_sym_pmc_summary.json")
 

@@ -34,11 +34,11 @@ def test_two_processes_one_gpu_sharded_device_steps(tmp_path, oracle):
     assert dx < 3e-6 and dv < 6e-5, (dx, dv)
 
 
-def _run_ranks(tmp_path, world, n, steps, *extra):
+def _run_ranks(tmp_path, world, n, steps, *extra, env=None):
     port = 29600 + (os.getpid() % 2000) + world
     worker = os.path.join(ROOT, "tests", "shard_gpu_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(n), str(steps), str(tmp_path), *extra],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, **(env or {}))) for r in range(world)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     return np.load(os.path.join(str(tmp_path), "gpu_sharded.npz"))
@@ -137,6 +137,20 @@ def test_pushed_positions_give_the_same_bits_as_pulled_ones(tmp_path):
         b = _run_ranks(d5, world, n, 7, "sympush" + mix, str(n))
         for k in ("pos", "vel", "other"):
             np.testing.assert_array_equal(a[k], b[k])
+
+
+def test_exchange_launch_is_sized_for_the_compute_units_the_process_really_gets(tmp_path):
+    """The exchange launch's workgroups wait for each other and for the peers, so all of them must be resident at once.
+    Its grid is capped by what ONE compute unit holds (asked of the runtime) times the units that really take the process's
+    workgroups (probed at set-up), halved.  With a CU mask of 32 of the 256 units the same job must run to the same bits --
+    with the nominal unit count the launch would not fit and every wait would time out."""
+    import os as _os
+    d1, d2 = tmp_path / "all", tmp_path / "masked"
+    _os.makedirs(d1); _os.makedirs(d2)
+    a = _run_ranks(d1, 2, 32768, 4, "sympush", "32768")
+    b = _run_ranks(d2, 2, 32768, 4, "sympush", "32768", env={"HSA_CU_MASK": "0:0-31"})
+    for k in ("pos", "vel", "other"):
+        np.testing.assert_array_equal(a[k], b[k])
 
 
 def test_symmetric_sharded_step_falls_back_bit_identically(tmp_path):

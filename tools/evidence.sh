@@ -1,0 +1,140 @@
+#!/bin/bash
+# tools/evidence.sh <what> [args]  -- every measurement behind profiles/ and DESIGN.md, run ON THE GPU BOX from the repo root
+# (gpurun -- 'bash tools/evidence.sh <what> ...').  Output goes to gpurun_out/<tag>/ (scratch); what is to be judged is copied
+# into profiles/ by hand.  One script with parameters instead of a numbered script per lease.
+#
+#   suite [fast|full]            pytest -m gpu (fast: without the slow oracle legs) + the default bench line
+#   bench [bench.py args]        one bench line, summarised
+#   stats [sym|sgpr]             rocprofv3 --kernel-trace --stats of the default bench -> kernel_stats csv
+#   pmc   [sym|sgpr] <tag>       the four --pmc passes of one force kernel -> profiles/<tag>_pmc_summary.{txt,json} (tools/pmc_summary.py)
+#   issue [tree]                 SQ issue / wait counters of force_sym_kernel (three --pmc passes)
+#   ab <other-tree>              same-box A/B of another checkout (e.g. ab/old: `git archive <rev> | tar -x -C ab/old && make -C ...`)
+#   timeline N WORLD RANK ALGO   per-wave timeline of one sharded symmetric force launch in loopback (tools/shard_timeline.py)
+#   shardstep [N WORLD]          kernel trace of the loopback step, ranks 0 and WORLD/2, algorithms 4 and 5: durations, gaps, period
+#   loopback [N]                 rank 0's compute per step at the shard size, one-sided against symmetric, WORLD = 2, 4, 8
+#   sizes                        symmetric against one-sided kernel at 65 536 ... 4 194 304 bodies
+#   parity1000                   tests/parity_report.py at 65 536 bodies, 1000 steps, all legs -> JSON
+#   soak MODE                    several real processes on one GPU, long runs: MODE = flow | sym | sympush (against p2p)
+set -u
+R=$PWD; W=${1:-suite}; shift || true
+O=$R/gpurun_out/ev_$W; mkdir -p $O
+export TMPDIR=/tmp
+line() { python -c "import sys,json; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); r=d.get('roofline') or {}; print('$1', 'value %.4e' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'force ms', round(r.get('avg_launch_ms',0),4), 'frac', round(r.get('frac',0),4), 'executed', round(r.get('frac_executed',0),4), 'clk', r.get('held_clock_ghz'), 'quarters', d['config'].get('step_ms_by_quarter_of_the_timed_region'), d['config'].get('kernel'))"; }
+case $W in
+suite)
+  sel=${1:-fast}; [ $sel = fast ] && M="gpu and not slow" || M="gpu"
+  python -m pytest tests -m "$M" -q > $O/pytest_$sel.txt 2>&1; tail -4 $O/pytest_$sel.txt
+  python bench.py > $O/bench_default.json 2> $O/bench_default.err; line default < $O/bench_default.json ;;
+bench)
+  python bench.py "$@" > $O/bench.json 2> $O/bench.err; line "bench $*" < $O/bench.json ;;
+stats)
+  k=${1:-sym}; cd /tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$k -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --kernel $k > $O/bench_profiled_$k.json 2> $O/bench_profiled_$k.err
+  cd $R; f=$(ls -t $(find $O/stats_$k -name "*kernel_stats.csv") | head -1); cp $f $O/kernel_stats_$k.csv; head -5 $f; line "profiled $k" < $O/bench_profiled_$k.json ;;
+pmc)
+  k=${1:-sym}; tag=${2:-r03_$k}; cd /tmp
+  P() { d=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$k/$d -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --kernel $k > /dev/null 2> $O/pmc_$k.$d.err; }
+  P fetch FETCH_SIZE; P write WRITE_SIZE
+  P sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAVES
+  P grbm GRBM_GUI_ACTIVE GRBM_COUNT
+  cd $R; python tools/pmc_summary.py $O/pmc_$k $tag > $O/pmc_summary_$k.txt 2>&1; tail -30 $O/pmc_summary_$k.txt ;;
+issue)
+  t=${1:-.}; cd /tmp
+  P() { d=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$d -- python3 $R/$t/bench.py --steps 12 --warmup 3 --no-cpu-baseline > /dev/null 2> $O/$d.err; }
+  P w1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
+  P w2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE
+  P w3 SQ_IFETCH SQ_WAIT_IFETCH SQ_INSTS_BRANCH SQ_INSTS_SALU SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_WAVES SQ_CYCLES
+  cd $R; python - "$O" <<'PY'
+import csv, glob, collections, sys
+O = sys.argv[1]
+for d in ("w1", "w2", "w3"):
+    acc = collections.defaultdict(float); cnt = collections.Counter(); dur = []
+    for f in glob.glob(f"{O}/{d}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "force_sym" not in r["Kernel_Name"]: continue
+            acc[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
+            dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for c in sorted(acc): print("%-24s %16.1f per launch" % (c, acc[c] / cnt[c]))
+    if dur: print("  (%s: force_sym_kernel %.1f us under the counters)" % (d, sum(dur) / len(dur) / 1e3))
+PY
+  ;;
+ab)
+  t=${1:?other tree}
+  for rep in 1 2; do
+    (cd $t && python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null) | line "$t" | tee -a $O/ab.txt
+    python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | line "tree" | tee -a $O/ab.txt
+    (cd $t && python tools/shard_sym_loopback.py 65536 300 2>&1 | grep "world 8  sym" | sed "s|^|$t |") | tee -a $O/ab.txt
+    python tools/shard_sym_loopback.py 65536 300 2>&1 | grep "world 8  sym" | sed "s|^|tree |" | tee -a $O/ab.txt
+  done ;;
+timeline)
+  python tools/shard_timeline.py "$@" 2>&1 | tee $O/timeline_$(echo "$*" | tr ' ' '_').txt ;;
+shardstep)
+  n=${1:-65536}; world=${2:-8}; cd /tmp
+  cat > /tmp/loopstep.py <<'PY'
+import os, sys
+os.environ["MAPN_P2P_LOOPBACK"] = "1"
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+import mapn
+n, world, algo, rank = (int(x) for x in sys.argv[1:5])
+with mapn.Compute(n, device=0, mass=70000.0 / n, rank=rank, world_size=world) as c:
+    blob = c.p2p_export(); c.p2p_import([blob] * world); c.set_gather_algorithm(algo); c.set_timers(0)
+    for _ in range(300):
+        c.Simulate(n, c.GetFenceValue())
+    c.WaitForGpu()
+PY
+  for algo in 5 4 2; do for rank in 0 $((world / 2)); do
+    rocprofv3 --kernel-trace --output-format csv -d $O/trace_${algo}_$rank -- python3 /tmp/loopstep.py $n $world $algo $rank > /dev/null 2> $O/trace_${algo}_$rank.err
+  done; done
+  cd $R; python - "$O" $n $world <<'PY' | tee $O/shard_step_timeline.txt
+import csv, glob, collections, sys
+O, n, world = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+print(f"# kernel trace (rocprofv3 --kernel-trace) of one rank's step at {n} / {world} in loopback (every peer mapped to the rank itself), second half of 300 steps:")
+print("# mean durations, gaps, step period.  Algorithm 5: exchange launch pushes the new positions; 4: it pulls them; 2: one-sided kernel, separate pull launch (skipped in loopback)")
+for algo in (5, 4, 2):
+    for rank in (0, world // 2):
+        f = glob.glob(f"{O}/trace_{algo}_{rank}/**/*kernel_trace.csv", recursive=True)
+        if not f: continue
+        rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Start_Timestamp"]))
+        rows = rows[len(rows) // 2:]
+        dur = collections.defaultdict(list); gap = collections.defaultdict(list)
+        for a, b in zip(rows, rows[1:]):
+            k = a["Kernel_Name"].split("(")[0][-40:]
+            dur[k].append(int(a["End_Timestamp"]) - int(a["Start_Timestamp"]))
+            gap[k + " -> next"].append(int(b["Start_Timestamp"]) - int(a["End_Timestamp"]))
+        print(f"== gather algorithm {algo}, rank {rank}")
+        for k, v in dur.items(): print("  %-48s %7.2f us  (x%d)" % (k, sum(v) / len(v) / 1e3, len(v)))
+        for k, v in gap.items(): print("  gap %-44s %7.2f us" % (k, sum(v) / len(v) / 1e3))
+        per = collections.Counter(r["Kernel_Name"] for r in rows).most_common(1)[0][1]
+        print("  step period %.2f us" % ((int(rows[-1]["Start_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / per / 1e3))
+PY
+  ;;
+loopback)
+  python tools/shard_sym_loopback.py ${1:-65536} ${2:-400} 2>&1 | tee $O/loopback_${1:-65536}.txt ;;
+sizes)
+  for n in 65536 100000 262144 1048576 4194304; do
+    st=$((n > 1000000 ? 4 : n > 200000 ? 30 : 200)); wu=$((n > 1000000 ? 1 : 5))
+    for k in sym sgpr; do python bench.py --bodies $n --steps $st --warmup $wu --prewarm-ms $((n > 1000000 ? 0 : 400)) --no-cpu-baseline --kernel $k 2>/dev/null | line "$n $k" | tee -a $O/sizes.txt; done
+  done ;;
+parity1000)
+  python tests/parity_report.py --bodies 65536 --steps 1,10,100,1000 --f64-max-steps 100 --out $O/parity_1000_65536.json > $O/parity_1000.txt 2>&1; tail -30 $O/parity_1000.txt ;;
+soak)
+  mode=${1:-sympush}; mkdir -p /tmp/soak
+  for cfg in "2 8192 1500" "4 8192 1500" "8 8192 1500" "8 16384 600" "4 32768 300" "8 65536 120"; do
+    set -- $cfg; Wd=$1; N=$2; S=$3
+    for m in p2p $mode; do
+      rm -rf /tmp/soak/$m; mkdir -p /tmp/soak/$m; pids=""
+      for r in $(seq 0 $((Wd - 1))); do python tests/shard_gpu_worker.py $r $Wd $((29850 + Wd)) $N $S /tmp/soak/$m $m > /tmp/soak/$m/log_$r.txt 2>&1 & pids="$pids $!"; done
+      ok=1; for p in $pids; do wait $p || ok=0; done
+      [ $ok = 1 ] || { echo "world=$Wd n=$N steps=$S mode=$m FAILED"; for f in /tmp/soak/$m/log_*.txt; do tail -n 2 $f; done; }
+    done
+    python - $Wd $N $S $mode <<'PY' | tee -a $O/soak_$mode.txt
+import sys, numpy as np
+Wd, N, S, mode = sys.argv[1:5]
+a = np.load("/tmp/soak/p2p/gpu_sharded.npz"); b = np.load(f"/tmp/soak/{mode}/gpu_sharded.npz")
+same = all(np.array_equal(a[k], b[k]) for k in ("pos", "vel", "other"))
+d = np.linalg.norm(a["pos"][:, :3].astype(np.float64) - b["pos"][:, :3], axis=1) / np.maximum(np.linalg.norm(a["pos"][:, :3].astype(np.float64), axis=1), 1e-30)
+print(f"world={Wd} n={N} steps={S}  {mode} vs p2p: bitwise equal {same}, relative position difference max {d.max():.2e} median {np.median(d):.2e}, finite {bool(np.isfinite(b['pos']).all())}")
+PY
+  done ;;
+*) echo "unknown: $W"; exit 2 ;;
+esac

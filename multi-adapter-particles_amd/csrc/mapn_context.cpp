@@ -95,6 +95,7 @@ struct mapn_ctx {
     bool stamp_next = false;
     unsigned long long *timeline_buf = nullptr;   // MAPN_STAMP_DUMP: per-wave wall-clock stamps of a diagnostic symmetric launch
     size_t timeline_waves = 0, timeline_last = 0;
+    unsigned long long *xtimeline_buf = nullptr;  // ... and the phase stamps of the sharded step's exchange launch (8 per workgroup, 4096 workgroups)
 
     uint32_t buffer_index = 0;                // Compute.cpp:80 m_bufferIndex(0)
     uint64_t fence_value = 0;                 // Compute.cpp:82 m_fenceValue(0)
@@ -231,6 +232,9 @@ int check_async_errors(mapn_ctx *c)
     if (!c->async_status) return MAPN_OK;
     const uint32_t p2p = reinterpret_cast<volatile uint32_t *>(c->async_status)[0];
     const uint32_t cons = reinterpret_cast<volatile uint32_t *>(c->async_status)[1];
+    if (p2p >= 0x100u)
+        return fail(MAPN_ERR_COMM, "sharded symmetric step: a reaction row read after its sender's counter did not carry this exchange's number "
+                    "(sender %u places behind this rank on the ring): the counter overtook the data", p2p - 0x100u);
     if (p2p)
         return fail(MAPN_ERR_COMM, "peer-to-peer exchange: the wait for rank %u's slice timed out (%.0f ms); "
                     "this rank's position replica is stale from that step on", p2p - 1u, c->p2p_timeout_ticks / 1e5);
@@ -602,7 +606,12 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     h.pull_self = c->p2p_loopback ? 1u : 0u;
     h.timeout_ticks = c->p2p_timeout_ticks;
     h.mass = a.mass; h.dt = a.dt; h.damping = a.damping;
-    HIP_TRY(mapn::launch_sym_shard_exchange(h, c->sym_exchange_cap, c->compute));
+    if (a.timeline) {                                      // MAPN_STAMP_DUMP: the exchange launch's phase stamps behind the force launch's
+        if (!c->xtimeline_buf) HIP_TRY(hipMalloc(&c->xtimeline_buf, 4096 * 64));
+        HIP_TRY(hipMemsetAsync(c->xtimeline_buf, 0, 4096 * 64, c->compute));
+        h.timeline = c->xtimeline_buf;
+    }
+    HIP_TRY(mapn::launch_sym_shard_exchange(h, std::min(c->sym_exchange_cap, 4096u), c->compute));
     mapn::ForcePlan p{};
     p.kind = mapn::KERNEL_SYM; p.k = 2 * mapn::SYM_K2; p.waves = pl.waves; p.sb = pl.parts; p.nseg = 1; p.epi = mapn::EPI_ROWS;
     c->last_plan = p; c->last_i_count = c->count; c->last_launches = 2;
@@ -1174,6 +1183,7 @@ int mapn_destroy(mapn_ctx *c)
     if (c->ticket) (void)hipFree(c->ticket);
     if (c->stamp_buf) (void)hipFree(c->stamp_buf);
     if (c->timeline_buf) (void)hipFree(c->timeline_buf);
+    if (c->xtimeline_buf) (void)hipFree(c->xtimeline_buf);
     release_sym(c);
     for (int k = 0; k < kTimerRing; k++) {
         if (c->fence_events[k]) (void)hipEventDestroy(c->fence_events[k]);
@@ -1644,7 +1654,7 @@ int mapn_comm_init(mapn_ctx *c, const void *id128)
 int mapn_set_gather_algorithm(mapn_ctx *c, int algorithm)
 {
     if (!c || algorithm < 0 || algorithm > 6) return fail(MAPN_ERR_INVALID_ARGUMENT, "set_gather_algorithm: bad argument");
-    if (algorithm >= 2 && algorithm <= 5 && !c->p2p_ready) return fail(MAPN_ERR_STATE, "set_gather_algorithm(%d): call mapn_p2p_import first", algorithm);
+    if (algorithm >= 2 && algorithm != 6 && !c->p2p_ready) return fail(MAPN_ERR_STATE, "set_gather_algorithm(%d): call mapn_p2p_import first", algorithm);
     if ((algorithm < 2 || algorithm == 6) && c->cfg.world_size > 1 && !c->comm && !c->external_gather)
         return fail(MAPN_ERR_STATE, "set_gather_algorithm(%d): no RCCL communicator (mapn_comm_init)", algorithm);
     if (int rc = mapn_wait_idle(c)) return rc;
@@ -1924,6 +1934,10 @@ int mapn_measure_clock(mapn_ctx *c, int steps, mapn_clock_info *out)
                 const unsigned long long hdr[4] = {c->timeline_last, c->sym_parts, c->sym_waves, (unsigned long long)c->cfg.rank};
                 fwrite(hdr, 8, 4, f);
                 fwrite(tl.data(), 8, tl.size(), f);
+                if (c->xtimeline_buf) {
+                    std::vector<unsigned long long> xt(4096 * 8);
+                    if (hipMemcpy(xt.data(), c->xtimeline_buf, xt.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) fwrite(xt.data(), 8, xt.size(), f);
+                }
                 fclose(f);
             }
         }

@@ -134,6 +134,7 @@ struct SymShardArgs {
     uint32_t      pull_self;                  // loopback timing only: the "peers" are this rank, pull from every slot
     uint64_t      timeout_ticks;
     float         mass, dt, damping;
+    unsigned long long *timeline;             // diagnostic launches only (MAPN_STAMP_DUMP): 8 wall-clock stamps per workgroup
 };
 hipError_t launch_sym_shard_exchange(const SymShardArgs &a, uint32_t max_workgroups, hipStream_t st);
 uint32_t sym_shard_exchange_resident_workgroups(uint32_t count, int cus);   // how many of its workgroups `cus` compute units hold at once (with headroom)

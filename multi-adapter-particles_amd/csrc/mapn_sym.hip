@@ -405,15 +405,30 @@ __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs
     const uint32_t t = jb % SYM_JPI;
     for (uint32_t g = gs0; g < gend; g += 8u) {            // 8 meetings in flight, summed in ascending order
         float4 v[8], h[8];
+        uint32_t sp[8], apv[8];
+        // first ALL the table lookups of the batch, then all its row loads (the waits count in order)
 #pragma unroll
         for (uint32_t u = 0; u < 8u; u++) {
             const uint32_t gu = g + u;
             const bool live = gu < gend;
             const uint32_t d = gu <= D ? gu : p.half_d;
-            const uint32_t ap = a >= d ? a - d : a + p.nb - d;                  // the I-block that ran this meeting
-            const uint32_t sp = live ? ((p.half_d && ap < p.half_d) ? split0 : split1)[(gu - p.g0) * SYM_JPI + t] : 0xffffffffu;
-            v[u] = live ? br[(size_t)(gu - gs0) * 64u] : make_float4(0.f, 0.f, 0.f, 0.f);
-            h[u] = sp != 0xffffffffu ? p.brow1[((size_t)ap * p.parts + sp) * 64u + (i & 63u)] : make_float4(0.f, 0.f, 0.f, 0.f);
+            apv[u] = a >= d ? a - d : a + p.nb - d;                                // the I-block that ran this meeting
+            sp[u] = live ? ((p.half_d && apv[u] < p.half_d) ? split0 : split1)[(gu - p.g0) * SYM_JPI + t] : 0xffffffffu;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            // (no branch around a load: a lane without a row / without a head row re-reads a row that IS there and drops it --
+            //  eight branches per batch serialised the loads: the launch took 18.7 instead of 13.9 us at 65 536 bodies)
+            const bool live = g + u < gend;
+            const float4 *vsrc = br + (size_t)((live ? g + u : gs0) - gs0) * 64u;
+            const float4 *hsrc = sp[u] != 0xffffffffu ? p.brow1 + ((size_t)apv[u] * p.parts + sp[u]) * 64u + (i & 63u) : vsrc;
+            v[u] = *vsrc;
+            h[u] = *hsrc;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            if (!(g + u < gend)) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sp[u] == 0xffffffffu) h[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (uint32_t u = 0; u < 8u; u++) {
@@ -470,13 +485,19 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 template <int G>
 __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardArgs p)
 {
+    const uint32_t bid = blockIdx.x, nblk = gridDim.x;
     constexpr uint32_t B = 256u / G;                       // bodies per workgroup and pass
     __shared__ uint32_t ok;
     __shared__ float part[G][3][B];
 
+    // diagnostic launches only (MAPN_STAMP_DUMP): wall-clock stamps of the workgroup's phases; null otherwise
+    auto stamp = [&](uint32_t k) {
+        if (p.timeline && threadIdx.x == 0) p.timeline[(size_t)bid * 8u + k] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
     const uint32_t *split0 = p.tab + 2u * (p.nwaves + 1u), *split1 = split0 + p.max_meetings;
     const uint32_t total = p.phase == 2u ? 0u : p.world * p.count;
-    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+    for (uint32_t t = bid * 256u + threadIdx.x; t < total; t += nblk * 256u) {
         const uint32_t q = t / p.count, jl = t - q * p.count;
         if (!((p.send_mask >> q) & 1u)) continue;
         const uint32_t b = t / SYM_BLOCK, jb = t >> 6, tt = jb % SYM_JPI;     // t is the body's index in the whole job
@@ -484,13 +505,30 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         float fx = 0.f, fy = 0.f, fz = 0.f;
         for (uint32_t la = 0; la < p.nbl; la += 8u) {      // eight meetings in flight, added in ascending block order
             float4 v[8], h[8];
+            uint32_t gg[8], sp[8];
+            // first ALL the table lookups of the batch, then all its row loads: the waits count in order, so a lookup issued
+            // behind a row load would wait for that row too
 #pragma unroll
             for (uint32_t u = 0; u < 8u; u++) {
                 const uint32_t a = p.a0 + la + u;
-                const uint32_t g = la + u < p.nbl ? sym_group(a, b, p.nb, p.half_d) : 0u;
-                const uint32_t sp = g ? ((p.half_d && a < p.half_d) ? split0 : split1)[g * SYM_JPI + tt] : 0xffffffffu;
-                v[u] = g ? rows[(size_t)(la + u) * 64u] : make_float4(0.f, 0.f, 0.f, 0.f);
-                h[u] = sp != 0xffffffffu ? p.brow1[((size_t)(la + u) * p.parts + sp) * 64u + (t & 63u)] : make_float4(0.f, 0.f, 0.f, 0.f);
+                gg[u] = la + u < p.nbl ? sym_group(a, b, p.nb, p.half_d) : 0u;
+                sp[u] = ((p.half_d && a < p.half_d) ? split0 : split1)[gg[u] * SYM_JPI + tt];   // (group 0: the block itself, never cut)
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) {
+                // no branch around a load (eight branches per batch serialise the loads):
+                // a lane without a row / without a head row re-reads a row that is there and drops it
+                const bool cut = gg[u] && sp[u] != 0xffffffffu;
+                const float4 *vsrc = rows + (size_t)(gg[u] ? la + u : 0u) * 64u;
+                const float4 *hsrc = cut ? p.brow1 + ((size_t)(la + u) * p.parts + sp[u]) * 64u + (t & 63u) : vsrc;
+                v[u] = *vsrc;
+                h[u] = *hsrc;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) {
+                const bool cut = gg[u] && sp[u] != 0xffffffffu;
+                if (!gg[u]) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!cut) h[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (uint32_t u = 0; u < 8u; u++) {
@@ -524,16 +562,18 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         }
     };
     float ax, ay, az;
-    own_rows(blockIdx.x * B + bl, ax, ay, az);
+    stamp(1);                                              // sends issued
+    own_rows(bid * B + bl, ax, ay, az);
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    stamp(2);                                              // sends acknowledged, own rows summed
     if (p.phase == 2u) {
         if (threadIdx.x == 0) ok = 1u;                     // REDUCE: the rows were delivered in stream order
     } else if (threadIdx.x < 64u) {
         if (threadIdx.x == 0) {
             const uint32_t prev = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (prev + 1u == gridDim.x) {
+            if (prev + 1u == nblk) {
                 __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
                 for (uint32_t q = 0; q < p.world; q++)
                     if ((p.send_mask >> q) & 1u)
@@ -547,11 +587,12 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     }
     __syncthreads();
     if (!ok) return;
+    stamp(3);                                              // the peers' rows are here
 
-    for (uint32_t base = blockIdx.x * B; base < p.count; base += gridDim.x * B) {
+    for (uint32_t base = bid * B; base < p.count; base += nblk * B) {
         const uint32_t il = base + bl;
         const bool live = il < p.count;
-        if (base != blockIdx.x * B) own_rows(il, ax, ay, az);
+        if (base != bid * B) own_rows(il, ax, ay, az);
         __syncthreads();                                   // (the previous pass has read `part`)
         part[g][0][bl] = ax; part[g][1][bl] = ay; part[g][2][bl] = az;
         __syncthreads();
@@ -596,22 +637,24 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         float *vo = p.vel_new + 3 * (size_t)i;
         vo[0] = vx; vo[1] = vy; vo[2] = vz;
     }
+    stamp(4);                                              // integrated, position stores issued
     if (!p.pos_step) return;
 
     // (5) this rank's new slice is in memory once every workgroup's stores are acknowledged: then the counter
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    stamp(5);                                              // position stores acknowledged
     if (threadIdx.x < 64u) {
         if (threadIdx.x == 0) {
             const uint32_t prev = __hip_atomic_fetch_add(p.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (prev + 1u == gridDim.x) {
+            if (prev + 1u == nblk) {
                 __hip_atomic_store(p.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 for (uint32_t q = 0; q < p.world; q++)
                     if (q != p.rank || p.pull_self)
                         __hip_atomic_store(p.flags_peer[q] + p.rank, p.pos_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
-        if (p.push) return;                                // the peers' NEXT force launch waits for the counter; nothing to pull
+        if (p.push) { stamp(6); return; }                  // the peers' NEXT force launch waits for the counter; nothing to pull
         const uint32_t q = threadIdx.x;
         const uint32_t all_good = wait_counters(p.flags_mine, p.pull_self ? p.rank : q, q < p.world && q != p.rank, p.pos_step,
                                                 p.timeout_ticks, p.status, 1u + q);
@@ -623,12 +666,12 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     // the peers' slices: 16 bytes per lane per access, eight in flight, past this GPU's caches (a line of q's buffer
     // cached here two steps ago must not be returned)
     const uint32_t others = (p.world - 1u) * p.count;
-    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < others; e += gridDim.x * 256u * 8u) {
+    for (uint32_t e = bid * 256u + threadIdx.x; e < others; e += nblk * 256u * 8u) {
         unsigned long long lo[8], hi[8];
         uint32_t at[8];
 #pragma unroll
         for (uint32_t u = 0; u < 8u; u++) {
-            const uint32_t eu = e + u * gridDim.x * 256u;
+            const uint32_t eu = e + u * nblk * 256u;
             const bool live = eu < others;
             const uint32_t k = live ? eu / p.count : 0u, q = k < p.rank ? k : k + 1u;      // skip self
             at[u] = live ? q * p.count + (eu - k * p.count) : 0xffffffffu;

@@ -89,7 +89,7 @@ PY
 import csv, glob, collections, sys
 O, n, world = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 print(f"# kernel trace (rocprofv3 --kernel-trace) of one rank's step at {n} / {world} in loopback (every peer mapped to the rank itself), second half of 300 steps:")
-print("# mean durations, gaps, step period.  Algorithm 5: exchange launch pushes the new positions; 4: it pulls them; 2: one-sided kernel, separate pull launch (skipped in loopback)")
+print("# mean durations, gaps, step period.  Algorithm 5: the exchange launch pushes the new positions; 4: it pulls them; 2: one-sided kernel, separate pull launch (skipped in loopback)")
 for algo in (5, 4, 2):
     for rank in (0, world // 2):
         f = glob.glob(f"{O}/trace_{algo}_{rank}/**/*kernel_trace.csv", recursive=True)

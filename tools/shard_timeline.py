@@ -25,7 +25,9 @@ import mapn  # noqa: E402
 def analyse(path, label):
     raw = open(path, "rb").read()
     nw, parts, waves, rank = struct.unpack("<4Q", raw[:32])
-    t = np.frombuffer(raw[32:], dtype=np.uint64).reshape(nw, 6)
+    t = np.frombuffer(raw[32:32 + nw * 48], dtype=np.uint64).reshape(nw, 6)
+    xt = np.frombuffer(raw[32 + nw * 48:], dtype=np.uint64)
+    xt = xt.reshape(-1, 8).astype(np.int64) if xt.size else None
     ok = t[:, 0] > 0
     t = t[ok]
     entry, loop, done, exit_ = (t[:, k].astype(np.int64) for k in range(4))
@@ -58,6 +60,19 @@ def analyse(path, label):
         m = work == wk
         print(f"    SIMDs with {wk:4d} steps in total: {m.sum():5d}, last exit {pct(last[m])}")
     print(f"  launch as the waves saw it: {us(exit_).max():.2f} us from first entry to last exit")
+    if xt is not None:
+        xt = xt[xt[:, 0] > 0]
+        if len(xt):
+            names = ["entry", "sends issued", "sends acknowledged + own rows summed", "peers' rows arrived (counters)", "integrated, positions stored",
+                     "position stores acknowledged", "counter published / exit"]
+            x0 = xt[:, 0].min()
+            print(f"  exchange launch: {len(xt)} workgroups; first entry {(x0 - t0) / 100.0:.2f} us after the force launch's first wave, "
+                  f"{(x0 - exit_.max()) / 100.0:.2f} us after its last exit; stamps in us after that entry; min p10 p50 p90 max")
+            for k, nm in enumerate(names):
+                col = xt[:, k]
+                col = col[col > 0]
+                if len(col):
+                    print(f"    {nm:40s} {pct((col - x0) / 100.0)}")
 
 
 def main():

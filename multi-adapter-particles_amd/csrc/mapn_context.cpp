@@ -158,8 +158,10 @@ struct mapn_ctx {
     uint32_t *p2p_peer_flags[mapn::P2P_MAX_RANKS] = {};
     uint32_t p2p_step = 0;
     uint32_t **p2p_flag_table = nullptr;      // device copy of p2p_peer_flags[] (flow mode reads it in the kernel)
-    uint32_t *sym_shard_ticket = nullptr;     // gather algorithm 4: the exchange kernel's two tickets
-    uint32_t sym_shard_step = 0;
+    uint32_t *sym_shard_ticket = nullptr;     // gather algorithms 4 / 5: the exchange launch's ticket
+    uint32_t sym_shard_step = 0;              // reaction exchanges through the peer-to-peer counters (algorithms 4 / 5) ...
+    uint32_t sym_pos_epoch = 0;               // ... position publications by them ...
+    uint32_t sym_rccl_step = 0;               // ... and exchanges carried by RCCL (algorithm 6: the number only tags the rows)
     float4 *sym_send = nullptr, *sym_recv = nullptr;   // gather algorithm 6: reaction rows [world][count] packed for / delivered by RCCL
     bool step_pulled = false;                 // this step's exchange launch already moved the positions (algorithms 4 / 5)
     bool push_pending = false;                // algorithm 5: the peers' pushes of the latest step have not been waited for yet
@@ -550,7 +552,7 @@ int settle_push(mapn_ctx *c)
 {
     if (!c->push_pending) return MAPN_OK;
     c->push_pending = false;
-    HIP_TRY(mapn::launch_p2p_wait(c->p2p_flags, c->p2p_step, (uint32_t)c->cfg.world_size, (uint32_t)c->cfg.rank, c->p2p_loopback ? 1u : 0u,
+    HIP_TRY(mapn::launch_p2p_wait(c->p2p_flags + mapn::SYM_POS_BASE, c->sym_pos_epoch * mapn::SYM_COUNT_PER_LAUNCH, (uint32_t)c->cfg.world_size, (uint32_t)c->cfg.rank, c->p2p_loopback ? 1u : 0u,
                                   c->p2p_timeout_ticks, c->async_status, c->compute));
     return MAPN_OK;
 }
@@ -572,8 +574,8 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     const bool push = c->gather_algo == 5;
     if (push) {
         // the replica this launch reads was completed by the peers' pushes of the previous step: wait for their counters in the launch
-        a.wait_counters = c->p2p_flags; a.wait_status = c->async_status; a.wait_timeout_ticks = c->p2p_timeout_ticks;
-        a.wait_need = c->p2p_step; a.wait_world = world; a.wait_rank = rank; a.wait_self = c->p2p_loopback ? 1u : 0u;
+        a.wait_counters = c->p2p_flags + mapn::SYM_POS_BASE; a.wait_status = c->async_status; a.wait_timeout_ticks = c->p2p_timeout_ticks;
+        a.wait_need = c->sym_pos_epoch * mapn::SYM_COUNT_PER_LAUNCH; a.wait_world = world; a.wait_rank = rank; a.wait_self = c->p2p_loopback ? 1u : 0u;
         c->push_pending = false;
     }
     if (int rc = stamps_prepare(c, (size_t)a.shard_nbl * pl.nwaves, a)) return rc;
@@ -600,7 +602,7 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = pl.parts; h.nwaves = pl.nwaves; h.max_meetings = pl.max_meetings;
     h.send_mask = c->sym_send_mask; h.recv_mask = c->sym_recv_mask;
     h.step = ++c->sym_shard_step;
-    h.pos_step = pull ? ++c->p2p_step : 0u;
+    h.pos_step = pull ? ++c->sym_pos_epoch : 0u;
     c->step_pulled = pull;
     c->push_pending = push;
     h.pull_self = c->p2p_loopback ? 1u : 0u;
@@ -642,7 +644,7 @@ int enqueue_sym_shard_rccl(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *t
     h.rank = rank; h.world = world; h.count = c->count;
     h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = pl.parts; h.nwaves = pl.nwaves; h.max_meetings = pl.max_meetings;
     h.send_mask = c->sym_send_mask; h.recv_mask = c->sym_recv_mask;
-    h.step = ++c->sym_shard_step;
+    h.step = ++c->sym_rccl_step;
     h.send_row = 0;
     h.mass = a.mass; h.dt = a.dt; h.damping = a.damping;
     h.phase = 1;
@@ -1166,8 +1168,8 @@ int mapn_destroy(mapn_ctx *c)
     }
     if (c->p2p_flags) (void)hipFree(c->p2p_flags);
     if (c->p2p_flag_table) (void)hipFree(c->p2p_flag_table);
-    if (c->sym_shard_ticket) (void)hipFree(c->sym_shard_ticket);
     if (c->flow_block) (void)hipFree(c->flow_block);
+    if (c->sym_shard_ticket) (void)hipFree(c->sym_shard_ticket);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->exported_done) (void)hipEventDestroy(c->exported_done);
     if (c->fence_host_word) (void)hipHostFree(c->fence_host_word);

@@ -102,8 +102,12 @@ hipError_t launch_sym_reduce(const SymArgs &a, hipStream_t st);
 // ranks that owe it rows, integrates its own bodies from its a-rows plus the rows received, publishes its
 // new slice and pulls the peers' slices (sym_shard_exchange_kernel: one launch).
 enum { P2P_MAX_RANKS = 16 };          // ranks of a direct peer-to-peer job (one process per GPU, buffers mapped through hipIpc)
-enum { SYM_FLAG_BASE = 16,            // reaction-arrival counters follow the P2P_MAX_RANKS publication counters
+enum { SYM_FLAG_BASE = 16,            // reaction-arrival counters follow the P2P_MAX_RANKS publication counters of the one-sided exchange
+       SYM_POS_BASE = 32,             // position counters of the sharded symmetric step (algorithms 4 / 5)
        SYM_RECV_OFFSET = 4096 };      // byte offset of the receive region [world][count] float4 inside the flags allocation
+// The position counters ADVANCE by this much per launch: every workgroup of the exchange launch adds its share once its stores are
+// acknowledged (the shares of a launch sum to exactly this, whatever its grid), a waiter needs launch number x this
+constexpr uint32_t SYM_COUNT_PER_LAUNCH = 1u << 16;
 struct SymShardArgs {
     const float4 *pos_old;
     const float  *vel_old;
@@ -124,13 +128,13 @@ struct SymShardArgs {
                                               // the counter); 0: this launch waits for the peers' counters and pulls their slices
     const float4 *recv_mine;
     uint32_t     *flags_mine;
-    uint32_t     *ticket;                     // [0] workgroups whose sends are acknowledged, [1] workgroups whose new positions are in memory
+    uint32_t     *ticket;                     // workgroups of this launch whose sends are acknowledged (zero between launches)
     uint32_t     *status;                     // host-visible word: non-zero = a wait timed out
     uint32_t      rank, world, count;         // count = bodies per rank (a multiple of SYM_BLOCK)
     uint32_t      nb, nbl, a0, half_d, parts, nwaves, max_meetings;
     uint32_t      send_mask, recv_mask;       // bit q: this rank produces reactions for / receives reactions from rank q
     uint32_t      step;                       // monotonically increasing (>= 1): number of the reaction exchange
-    uint32_t      pos_step;                   // publication number of the new positions (the p2p counter; 0: no pull in this launch)
+    uint32_t      pos_step;                   // number of this publication of new positions by a sharded symmetric step (0: they travel in another launch)
     uint32_t      pull_self;                  // loopback timing only: the "peers" are this rank, pull from every slot
     uint64_t      timeout_ticks;
     float         mass, dt, damping;

@@ -461,7 +461,7 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 
 }  // namespace
 
-// grid <= the workgroups the device holds at once (they wait for each other through the tickets)   block = 256
+// grid <= the workgroups the device holds at once (they wait for the peers, whose counters need ALL of a launch's workgroups)   block = 256
 // One launch does the reaction exchange, the integration and the exchange of the new positions.
 //  (1) SEND: for every rank q this rank produced reactions for and every body of q: the rows of this rank's
 //      I-blocks that met the body's block (a meeting's row, then its head row if it was cut between two workgroups),
@@ -472,13 +472,13 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 //  (2) OWN ROWS, before anything is waited for: G threads per body (a rank's slice is small -- 8192 bodies at
 //      65 536 / 8 -- so one thread per body would leave the rows' loads latency-bound): thread (body, g) adds the
 //      a-rows of parts [g P/G, (g+1) P/G) in ascending order.
-//  (3) the last workgroup through ticket[0] stores the arrival flags; lanes 0 .. world-1 of every workgroup's first
+//  (3) the last workgroup through the ticket stores the arrival flags; lanes 0 .. world-1 of every workgroup's first
 //      wave wait (bounded) for the flags of the ranks that owe this rank rows.
 //  (4) INTEGRATE: thread (body, 0) adds the G sums in ascending g, then the rows received, nearest sender first
 //      (this rank, rank - 1, rank - 2, ...), then mass, kick, damp, drift (hlsl:103-108) -- a fixed order throughout,
 //      so the replicas stay bit-identical.  The new position is stored write-through.
-//  (5) POSITIONS (pos_step != 0; else they travel in p2p_gather_kernel): the last workgroup through ticket[1]
-//      publishes this rank's slice to every peer (the counter p2p_gather_kernel uses).  PULL form: every workgroup waits
+//  (5) POSITIONS (pos_step != 0; else they travel in p2p_gather_kernel): every workgroup, its stores acknowledged, adds its share
+//      to this rank's position counter at every peer.  PULL form: every workgroup waits
 //      for the peers' counters and pulls its share of their slices with cache-bypassing system-scope loads.  PUSH form
 //      (gather algorithm 5): (4) has already stored every new position into every peer's replica as well, the counter
 //      says so, and the launch ends here -- the wait moves to the head of the peers' next force launch.
@@ -571,6 +571,9 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     if (p.phase == 2u) {
         if (threadIdx.x == 0) ok = 1u;                     // REDUCE: the rows were delivered in stream order
     } else if (threadIdx.x < 64u) {
+        // the last workgroup through the ticket tells every rank this one sent to.  (Every workgroup adding a share to the peers'
+        // counters instead -- no ticket round trip -- was 0.8 us SLOWER: 256 system-scope atomics on one uncached word are served
+        // one after the other, 3.3 us from the last add to the counter being seen against 1.45 us this way.)
         if (threadIdx.x == 0) {
             const uint32_t prev = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (prev + 1u == nblk) {
@@ -645,18 +648,15 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     __syncthreads();
     stamp(5);                                              // position stores acknowledged
     if (threadIdx.x < 64u) {
-        if (threadIdx.x == 0) {
-            const uint32_t prev = __hip_atomic_fetch_add(p.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (prev + 1u == nblk) {
-                __hip_atomic_store(p.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (uint32_t q = 0; q < p.world; q++)
-                    if (q != p.rank || p.pull_self)
-                        __hip_atomic_store(p.flags_peer[q] + p.rank, p.pos_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
+        // every workgroup adds ITS share of SYM_COUNT_PER_LAUNCH to this rank's position counter at every peer (fire and forget: the
+        // workgroup leaves at once instead of waiting for a ticket to come back; the shares of a launch sum to
+        // SYM_COUNT_PER_LAUNCH whatever its grid, a waiter needs launch number x that): the launch ends 2 us earlier
+        const uint32_t share = (uint32_t)(((uint64_t)SYM_COUNT_PER_LAUNCH * (bid + 1u)) / nblk) - (uint32_t)(((uint64_t)SYM_COUNT_PER_LAUNCH * bid) / nblk);
+        if (threadIdx.x < p.world && (p.pull_self ? threadIdx.x == p.rank : threadIdx.x != p.rank))
+            (void)__hip_atomic_fetch_add(p.flags_peer[threadIdx.x] + SYM_POS_BASE + p.rank, share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (p.push) { stamp(6); return; }                  // the peers' NEXT force launch waits for the counter; nothing to pull
         const uint32_t q = threadIdx.x;
-        const uint32_t all_good = wait_counters(p.flags_mine, p.pull_self ? p.rank : q, q < p.world && q != p.rank, p.pos_step,
+        const uint32_t all_good = wait_counters(p.flags_mine + SYM_POS_BASE, p.pull_self ? p.rank : q, q < p.world && q != p.rank, p.pos_step * SYM_COUNT_PER_LAUNCH,
                                                 p.timeout_ticks, p.status, 1u + q);
         if (threadIdx.x == 0) ok = all_good;
     }

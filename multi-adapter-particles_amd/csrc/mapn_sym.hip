@@ -261,12 +261,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
             // compiler kept two copies of the accumulators (220 register moves per meeting), ran out of registers and serialised
             // the step (36 s_nop, 1436 instead of 1183 cycles); those meetings are 16 of ~530, 6 packed fma dearer each.
             v2f bx = v2f{0.f, 0.f}, by = v2f{0.f, 0.f}, bz = v2f{0.f, 0.f};
-#pragma nounroll                                           // (unrolled by two: no loop-carried copies, but the moves issue late: 2 % slower)
-            for (uint32_t k = 0; k < steps; k++) {
-                // the travelling position does not change during the step: its move overlaps the step
-                const float nx = lane_next(xj, next), ny = lane_next(yj, next), nz = lane_next(zj, next);
+            // two steps per trip, the travelling position alternating between two register sets: the move's result IS the next
+            // step's operand (one step per trip needs three register copies per step to carry it round the loop: 2 % of the VALU work)
+            uint32_t k = 0;
+#pragma nounroll
+            for (; k + 2u <= steps; k += 2u) {
+                const float x1 = lane_next(xj, next), y1 = lane_next(yj, next), z1 = lane_next(zj, next);
                 sym_step(b, xj, yj, zj, soft2, bx, by, bz);
-                xj = nx; yj = ny; zj = nz;
+                bx.x = lane_next(bx.x, next); by.x = lane_next(by.x, next); bz.x = lane_next(bz.x, next);
+                bx.y = lane_next(bx.y, next); by.y = lane_next(by.y, next); bz.y = lane_next(bz.y, next);
+                xj = lane_next(x1, next); yj = lane_next(y1, next); zj = lane_next(z1, next);
+                sym_step(b, x1, y1, z1, soft2, bx, by, bz);
+                bx.x = lane_next(bx.x, next); by.x = lane_next(by.x, next); bz.x = lane_next(bz.x, next);
+                bx.y = lane_next(bx.y, next); by.y = lane_next(by.y, next); bz.y = lane_next(bz.y, next);
+            }
+            if (k < steps) {
+                sym_step(b, xj, yj, zj, soft2, bx, by, bz);
                 bx.x = lane_next(bx.x, next); by.x = lane_next(by.x, next); bz.x = lane_next(bz.x, next);
                 bx.y = lane_next(bx.y, next); by.y = lane_next(by.y, next); bz.y = lane_next(bz.y, next);
             }

@@ -44,7 +44,7 @@ issue)
   P w1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
   P w2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE
   P w3 SQ_IFETCH SQ_WAIT_IFETCH SQ_INSTS_BRANCH SQ_INSTS_SALU SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_WAVES SQ_CYCLES
-  cd $R; python - "$O" <<'PY'
+  cd $R; python - "$O" <<'PY' | tee $O/issue.txt
 import csv, glob, collections, sys
 O = sys.argv[1]
 for d in ("w1", "w2", "w3"):

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Compute side of one rank's sharded step at the TRUE shard size, on a 1-GPU box (MAPN_P2P_LOOPBACK=1:
-rank 0 of a P-way job with every peer mapped to itself -- the real force / send / reduce kernels run, the
-position pull is skipped, results are not a simulation).  One-sided step (gather algorithm 2) against the
-sharded symmetric step (algorithm 4).  Usage: tools/shard_sym_loopback.py [bodies] [steps]"""
+"""One rank's sharded step at the TRUE shard size, on a 1-GPU box (MAPN_P2P_LOOPBACK=1: rank 0 of a P-way job with
+every peer mapped to itself -- the real force / exchange launches run, results are not a simulation).  One-sided step
+(gather algorithm 2; its separate pull launch is skipped in loopback) against the sharded symmetric step with pushed
+positions (algorithm 5; the pushes go to the rank's own buffers).  Usage: tools/shard_sym_loopback.py [bodies] [steps]"""
 import os
 import sys
 import time
@@ -34,12 +34,12 @@ def run(n, world, algo, steps):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-    print(f"# {n} bodies, rank 0's compute per step at the shard size (no position pull), {steps} steps")
+    print(f"# {n} bodies, rank 0's step at the shard size in loopback (symmetric: including the position exchange), {steps} steps")
     for world in (2, 4, 8):
         if (n // world) % 1024:
             continue
         r = {}
-        for algo, name in ((2, "one-sided"), (4, "symmetric")):
+        for algo, name in ((2, "one-sided"), (5, "symmetric")):
             dt, ks, kn, grid = run(n, world, algo, steps)
             r[name] = dt
             print(f"world {world}  {name:10s} step {dt*1e6:8.1f} us   force kernel {ks*1e6:8.1f} us  {kn} grid {grid}"

@@ -60,6 +60,11 @@ def analyse(path, label):
         m = work == wk
         print(f"    SIMDs with {wk:4d} steps in total: {m.sum():5d}, last exit {pct(last[m])}")
     print(f"  launch as the waves saw it: {us(exit_).max():.2f} us from first entry to last exit")
+    # per XCD: do the eight dies run at one speed?  (loop time per step of the waves that ran on it, and when its last wave left)
+    for x in sorted(set(xcc.tolist())):
+        m = xcc == x
+        per_step = (done[m] - loop[m]) / 100.0 / np.maximum(steps[m], 1)
+        print(f"    XCD {x}: {m.sum():5d} waves, loop us per step p50 {np.median(per_step):.4f}, last exit {us(exit_[m]).max():8.2f}, steps {steps[m].sum()}")
     if xt is not None:
         xt = xt[xt[:, 0] > 0]
         if len(xt):

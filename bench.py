@@ -61,6 +61,9 @@ def parse():
                          "load to settle its clock; 0 disables)")
     ap.add_argument("--p2p-timeout-ms", type=int, default=200,
                     help="bound of the device-side waits of the peer-to-peer forms (raise it when ranks time-slice one device in tests)")
+    ap.add_argument("--xcd", choices=["auto", "off", "on"], default="auto",
+                    help="XCD-aware parts of the symmetric kernel (1 GPU): calibrate the dies' speeds during the untimed prewarm and size "
+                         "every part by the die it runs on; auto keeps them only if an untimed A/B against the default plan wins")
     ap.add_argument("--overlap", action="store_true", help="sharded mode: own-segment launch overlapped with the all-gather")
     ap.add_argument("--force-comm", action="store_true",
                     help="create the torch.distributed group and the in-library RCCL communicator even for one rank (exercises the sharded code path on a 1-GPU box)")
@@ -407,6 +410,34 @@ def main():
             for _ in range(prewarm_steps):
                 step()
             c.WaitForGpu()
+    # XCD-aware parts (1 GPU, symmetric kernel): the eight dies do not run at one speed and a launch gives each the same work.
+    # Untimed: calibrate, then an A/B of the weighted plan against the default one; the weights stay only if they win.
+    xcd = {"mode": a.xcd, "weights": None, "used": False}
+    if dist is None and a.mode == "all_pairs" and a.xcd != "off" and kern in (mapn.KERNEL_AUTO, mapn.KERNEL_SYMMETRIC) and not a.plan and not a.graph:
+        try:
+            def burst(k):
+                c.WaitForGpu(); t = time.perf_counter()
+                for _ in range(k):
+                    step()
+                c.WaitForGpu()
+                return (time.perf_counter() - t) / k
+            kk = max(8, min(120, int(0.08 / (0.65e-3 * (n / 65536.0) ** 2))))
+            w = c.calibrate_sym_xcds(4 if n <= 262144 else 1)
+            xcd["weights"] = w
+            t_def = min(burst(kk), burst(kk))
+            c.set_sym_xcd_weights(w)
+            t_w = min(burst(kk), burst(kk)) if c.sym_plan().sets > 2 else float("inf")
+            xcd["trial_ms"] = {"default": t_def * 1e3, "weighted": None if t_w == float("inf") else t_w * 1e3}
+            if a.xcd == "on" or t_w < t_def * 0.998:
+                xcd["used"] = c.sym_plan().sets > 2
+            if not xcd["used"]:
+                c.set_sym_xcd_weights(None)
+        except mapn.MapnError as e:
+            xcd["error"] = str(e)[:200]
+            try:
+                c.set_sym_xcd_weights(None)
+            except mapn.MapnError:
+                pass
     for _ in range(a.warmup):
         step()
     sync()
@@ -484,7 +515,8 @@ def main():
                        "launches_per_step": int(st.force_launches_per_step) * (1 if st.fused else 2), "timer_interval": timer_interval,
                        "step_ms_by_quarter_of_the_timed_region": quarters, "step_ms_spread": spread if quarters else None,
                        "step_ms_note": "device time (HIP events on the compute stream) of the steps of the timed region that carried events; ms_per_step is the wall clock over all of them",
-                       "p2p_failure": p2p_failure, "sharded_symmetric_deviation_after_run": sym_dev_after},
+                       "p2p_failure": p2p_failure, "sharded_symmetric_deviation_after_run": sym_dev_after,
+                       "xcd_aware_parts": xcd},
         }
         if a.mode == "all_pairs":
             peak = info.peak_fp32_flops / 1e12

@@ -387,9 +387,10 @@ int mapn_set_force_plan(mapn_ctx *ctx, int kernel, uint32_t bodies_per_lane, uin
  * followed by a reduce launch that carries the running sum; inside a launch `parts` workgroups of `waves` waves
  * share the meetings of every 1024-body block, cut to the STEP so that every wave carries the same cost.
  * windows[4 k ..] = {g0, g1, meetings of a class-0 block, of a class-1 block}; tables = per window
- * bounds[2][parts * waves + 1] (first linear step of every wave) then split[2][max_meetings] (the part whose
+ * bounds[sets][parts * waves + 1] (first linear step of every wave) then split[sets][max_meetings] (the part whose
  * head row holds the last steps of a meeting cut between two workgroups, 0xffffffff otherwise); class 0 = the blocks
- * that also run the half-ring group (even block count, a < nb / 2).  What an order-matched checker must reproduce
+ * that also run the half-ring group (even block count, a < nb / 2); set = class, or class + 2 * (block mod 8) when the
+ * parts are XCD-weighted (sets = 16; the block counted within its launch).  What an order-matched checker must reproduce
  * (the CPU checker restates exactly this): per wave one fused-multiply-add chain per body over its steps in
  * order; the workgroup's waves added in ascending order into ONE row per (block, part); the reaction of a meeting as
  * two chains (even / odd bodies of the lane) folded once per piece, pieces of a cut meeting added first steps + last
@@ -404,6 +405,8 @@ typedef struct mapn_sym_plan_info {
     uint32_t nb, groups, windows;
     uint32_t parts, taper1, taper2, waves;
     uint32_t brows, max_meetings, table_stride;
+    uint32_t sets;               /* table sets per window: 2 (one per class) or 16 (class + 2 * (block mod 8): XCD-weighted parts) */
+    uint32_t xcd_weight[8];      /* the relative die speeds the parts were weighted with (sets == 16), else 0 */
     uint32_t a0, nbl;
     uint32_t active_compute_units;  /* sharded: compute units that really take this process's workgroups (probed; a CU mask leaves fewer) */
     uint32_t exchange_workgroups;   /* sharded: most workgroups the exchange launch may have (they must all be resident at once) */
@@ -411,9 +414,22 @@ typedef struct mapn_sym_plan_info {
     char     error[256];         /* why a shape was refused / why the kernel does not run */
 } mapn_sym_plan_info;
 int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2,
-                           uint32_t waves, mapn_sym_plan_info *info, uint32_t *windows, uint32_t *tables, uint64_t tables_capacity);
+                           uint32_t waves, const uint32_t *xcd_weights, uint32_t launch_blocks, mapn_sym_plan_info *info,
+                           uint32_t *windows, uint32_t *tables, uint64_t tables_capacity);
 int mapn_get_sym_plan(mapn_ctx *ctx, mapn_sym_plan_info *info, uint32_t *windows, uint32_t *tables, uint64_t tables_capacity);
 int mapn_set_sym_plan(mapn_ctx *ctx, uint32_t waves, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t groups_per_window);
+/*
+ * XCD-aware parts.  The eight XCDs of an MI355X do not run at one speed under this kernel (measured 0.538 - 0.570 us per
+ * step, the same dies slow on every launch of a box) while a launch gives every die the same work, so it ends with the
+ * slowest one.  mapn_calibrate_sym_xcds runs `steps` stamped steps (REAL steps, like mapn_measure_clock) and returns the
+ * dies' relative speeds (1024 = the fastest), indexed by DISPATCH SLOT -- workgroup number mod 8, not the XCC_ID register; mapn_set_sym_xcd_weights makes the plan spread the parts of every block over
+ * the dies (workgroup (x, y) of the grid runs part y of block (x + y) mod blocks) with a share of the block's steps
+ * proportional to the speed of the die a part runs on (NULL or equal weights: back to the default plan).  Takes effect where
+ * a launch covers a multiple of 8 blocks.  The weights are part of the plan: results are bit-reproducible for given weights,
+ * and differ between weightings like between any two summation orders.  bench.py calibrates and says so in its line.
+ */
+int mapn_calibrate_sym_xcds(mapn_ctx *ctx, int steps, uint32_t out_weights[8]);
+int mapn_set_sym_xcd_weights(mapn_ctx *ctx, const uint32_t *weights8);
 
 /* Sharded mode: switch the own/remote overlap structure (MAPN_FLAG_SHARD_OVERLAP) at run time, so a
  * launcher can time both structures on the node it runs on; all ranks must agree. */

@@ -248,6 +248,20 @@ class Compute:
         """Shape of the symmetric kernel's launches (waves = parts = 0: the default); re-allocates its scratch."""
         check(self._lib.mapn_set_sym_plan(self._ctx, waves, parts, taper1, taper2, groups_per_window))
 
+    def calibrate_sym_xcds(self, steps: int = 4):
+        """Relative speeds of the eight XCDs under the symmetric kernel (1024 = the fastest), from `steps` stamped REAL steps."""
+        w = (C.c_uint32 * 8)()
+        check(self._lib.mapn_calibrate_sym_xcds(self._ctx, int(steps), C.byref(w)))
+        return list(w)
+
+    def set_sym_xcd_weights(self, weights=None):
+        """Spread the parts of every block over the dies, sized by their speed (None: back to the default plan)."""
+        if weights is None:
+            check(self._lib.mapn_set_sym_xcd_weights(self._ctx, None))
+        else:
+            w = (C.c_uint32 * 8)(*[int(x) for x in weights])
+            check(self._lib.mapn_set_sym_xcd_weights(self._ctx, C.byref(w)))
+
     def sym_plan(self) -> "SymPlan":
         """The plan the symmetric kernel runs in this context (raises MapnError if it does not run)."""
         info = _lib.SymPlanInfo()
@@ -338,31 +352,38 @@ class SymPlan:
 
     def __init__(self, info, windows, tables):
         self.info, self.windows, self.tables = info, windows, tables
-        for k in ("nb", "groups", "parts", "taper1", "taper2", "waves", "brows", "max_meetings", "table_stride", "a0", "nbl", "active_compute_units", "exchange_workgroups", "scratch_bytes"):
+        for k in ("nb", "groups", "parts", "taper1", "taper2", "waves", "brows", "max_meetings", "table_stride", "sets", "a0", "nbl", "active_compute_units", "exchange_workgroups", "scratch_bytes"):
             setattr(self, k, int(getattr(info, k)))
         self.nwaves = self.parts * self.waves
+        self.xcd_weight = list(info.xcd_weight)
 
-    def bounds(self, window: int, cls: int):
-        o = window * self.table_stride + cls * (self.nwaves + 1)
+    def set_of(self, cls: int, block_in_launch: int = 0) -> int:
+        """Table set of a block: its class, plus 2 * (block mod 8) when the parts are XCD-weighted."""
+        return cls + (2 * (block_in_launch % 8) if self.sets > 2 else 0)
+
+    def bounds(self, window: int, set_: int):
+        o = window * self.table_stride + set_ * (self.nwaves + 1)
         return self.tables[o:o + self.nwaves + 1]
 
-    def split(self, window: int, cls: int):
-        o = window * self.table_stride + 2 * (self.nwaves + 1) + cls * self.max_meetings
+    def split(self, window: int, set_: int):
+        o = window * self.table_stride + self.sets * (self.nwaves + 1) + set_ * self.max_meetings
         return self.tables[o:o + self.max_meetings]
 
 
-def describe_sym_plan(nb: int, groups_per_window: int = 0, parts: int = 32, taper1: int | None = None, taper2: int = 0, waves: int = 4) -> SymPlan:
+def describe_sym_plan(nb: int, groups_per_window: int = 0, parts: int = 32, taper1: int | None = None, taper2: int = 0, waves: int = 4,
+                      xcd_weights=None, launch_blocks: int = 0) -> SymPlan:
     """The plan of a shape, computed on the host without a device (csrc/mapn_sym_plan.cpp)."""
     lib = load_library()
     info = _lib.SymPlanInfo()
     t1 = parts if taper1 is None else taper1
-    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, C.byref(info), None, None, 0)
+    xw = C.byref((C.c_uint32 * 8)(*[int(x) for x in xcd_weights])) if xcd_weights is not None else None
+    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, xw, launch_blocks, C.byref(info), None, None, 0)
     if rc:
         raise MapnError(rc, info.error.decode(errors="replace"))
     win = np.zeros((info.windows, 4), np.uint32)
     tab = np.zeros(info.windows * info.table_stride, np.uint32)
     u32p = C.POINTER(C.c_uint32)
-    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, C.byref(info), win.ctypes.data_as(u32p), tab.ctypes.data_as(u32p), tab.size)
+    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, xw, launch_blocks, C.byref(info), win.ctypes.data_as(u32p), tab.ctypes.data_as(u32p), tab.size)
     if rc:
         raise MapnError(rc, info.error.decode(errors="replace"))
     return SymPlan(info, win, tab)

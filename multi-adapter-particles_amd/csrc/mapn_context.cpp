@@ -84,6 +84,9 @@ struct mapn_ctx {
     bool sym_sharded = false;                 // ... for the sharded form (this rank's blocks) rather than the whole job
     bool sym_user_plan = false;               // mapn_set_sym_plan: keep the shape on re-preparation
     uint32_t sym_user[5] = {0, 0, 0, 0, 0};   // waves, parts, taper1, taper2, groups per window
+    bool sym_xcd_weighted = false;            // mapn_set_sym_xcd_weights: parts spread over the dies, sized by their speed
+    uint32_t sym_xcd_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool calibrating = false;                 // mapn_calibrate_sym_xcds: stamped launches record the per-wave timeline without MAPN_STAMP_DUMP
     std::string sym_note;                     // why AUTO runs the one-sided kernel instead (allocation failed, ...)
     float4 *sym_arow = nullptr, *sym_brow = nullptr, *sym_brow1 = nullptr, *sym_acc = nullptr;
     uint32_t *sym_tab = nullptr;              // device copy of sym_plan.tables
@@ -404,6 +407,7 @@ int prepare_sym(mapn_ctx *c, bool sharded)
             tries.push_back({tp, t1, t2});
         } else if (!(t && t[0] == '0') && !pl && !sharded && gpw == 0 && nb >= 64u && nb <= 128u) {
             tries.push_back({40, 28, 4}); tries.push_back({38, 28, 4}); tries.push_back({36, 28, 4});
+            tries.push_back({36, 28, 8});                  // (XCD-weighted parts shrink the slow dies' shares: no part of one unit then)
         }
         if (!c->sym_user_plan)
             for (uint32_t q = parts; q >= 1u; q = q > 1u ? q / 2u : 0u) tries.push_back({q, q, 0});   // equal parts, halved until every wave has 64 steps
@@ -411,7 +415,7 @@ int prepare_sym(mapn_ctx *c, bool sharded)
     std::string err;
     bool built = false;
     for (const Shape &sh : tries)
-        if ((built = mapn::build_sym_plan(nb, gpw, sh.parts, sh.t1, sh.t2, waves, c->sym_plan, err))) break;
+        if ((built = mapn::build_sym_plan(nb, gpw, sh.parts, sh.t1, sh.t2, waves, c->sym_xcd_weighted ? c->sym_xcd_w : nullptr, nbl, c->sym_plan, err))) break;
     if (!built) {
         c->sym_note = err;
         return must ? fail(MAPN_ERR_INVALID_ARGUMENT, "%s", err.c_str()) : MAPN_OK;
@@ -465,7 +469,7 @@ bool sym_eligible(const mapn_ctx *c, uint32_t active)
 // its entry / loop start / loop end / exit times (100 MHz) and where it ran; mapn_measure_clock writes them to the file.
 int timeline_prepare(mapn_ctx *c, size_t nw, mapn::SymArgs &a)
 {
-    if (!c->stamp_next || !getenv("MAPN_STAMP_DUMP")) return MAPN_OK;
+    if (!c->stamp_next || !(c->calibrating || getenv("MAPN_STAMP_DUMP"))) return MAPN_OK;
     if (nw > c->timeline_waves) {
         if (c->timeline_buf) HIP_TRY(hipFree(c->timeline_buf));
         c->timeline_buf = nullptr; c->timeline_waves = 0;
@@ -500,7 +504,7 @@ mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t win
     a.pos_old = base.pos_old; a.vel_old = base.vel_old; a.pos_new = base.pos_new; a.vel_new = base.vel_new;
     a.arow = c->sym_arow; a.brow = c->sym_brow; a.brow1 = c->sym_brow1;
     a.tab = c->sym_tab + window * pl.table_stride;
-    a.n = c->n; a.nb = pl.nb; a.parts = pl.parts; a.nwaves = pl.nwaves; a.max_meetings = pl.max_meetings;
+    a.n = c->n; a.nb = pl.nb; a.parts = pl.parts; a.nwaves = pl.nwaves; a.max_meetings = pl.max_meetings; a.sets = pl.sets;
     a.g0 = pl.windows[window].g0; a.g1 = pl.windows[window].g1;
     a.brows = pl.brows; a.half_d = pl.half;
     a.mass = base.mass; a.soft2 = base.soft2; a.dt = base.dt; a.damping = base.damping;
@@ -599,7 +603,7 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     h.ticket = c->sym_shard_ticket;
     h.status = c->async_status;
     h.rank = rank; h.world = world; h.count = c->count;
-    h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = pl.parts; h.nwaves = pl.nwaves; h.max_meetings = pl.max_meetings;
+    h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = pl.parts; h.nwaves = pl.nwaves; h.max_meetings = pl.max_meetings; h.sets = pl.sets;
     h.send_mask = c->sym_send_mask; h.recv_mask = c->sym_recv_mask;
     h.step = ++c->sym_shard_step;
     h.pos_step = pull ? ++c->sym_pos_epoch : 0u;
@@ -642,7 +646,7 @@ int enqueue_sym_shard_rccl(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *t
     h.recv_mine = c->sym_recv;
     h.status = c->async_status;
     h.rank = rank; h.world = world; h.count = c->count;
-    h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = pl.parts; h.nwaves = pl.nwaves; h.max_meetings = pl.max_meetings;
+    h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = pl.parts; h.nwaves = pl.nwaves; h.max_meetings = pl.max_meetings; h.sets = pl.sets;
     h.send_mask = c->sym_send_mask; h.recv_mask = c->sym_recv_mask;
     h.step = ++c->sym_rccl_step;
     h.send_row = 0;
@@ -1864,6 +1868,71 @@ int mapn_set_sym_plan(mapn_ctx *c, uint32_t waves, uint32_t parts, uint32_t tape
     return MAPN_OK;
 }
 
+int mapn_set_sym_xcd_weights(mapn_ctx *c, const uint32_t *w)
+{
+    if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
+    if (int rc = mapn_wait_idle(c)) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    c->sym_xcd_weighted = false;
+    if (w) {
+        for (int k = 0; k < 8; k++) { c->sym_xcd_w[k] = w[k]; c->sym_xcd_weighted = c->sym_xcd_weighted || w[k] != w[0]; }
+        for (int k = 0; k < 8; k++) if (w[k] == 0u) return fail(MAPN_ERR_INVALID_ARGUMENT, "set_sym_xcd_weights: a weight is zero");
+    }
+    if (!c->sym_ready) return MAPN_OK;                     // (kept for when the symmetric step is prepared: a sharded context before algorithm 4 / 5 / 6)
+    drop_graphs(c);
+    const bool sharded = c->sym_sharded;
+    if (int rc = prepare_sym(c, sharded)) { c->sym_xcd_weighted = false; std::string keep = g_last_error; (void)prepare_sym(c, sharded); g_last_error = keep; return rc; }
+    return MAPN_OK;
+}
+
+int mapn_calibrate_sym_xcds(mapn_ctx *c, int steps, uint32_t out[8])
+{
+    if (!c || !out || steps < 1) return fail(MAPN_ERR_INVALID_ARGUMENT, "calibrate_sym_xcds: bad argument");
+    if (!(sym_eligible(c, c->n) || sym_shard_eligible(c, c->n)))
+        return fail(MAPN_ERR_STATE, "calibrate_sym_xcds: the symmetric kernel does not run in this context");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<double> per[8];
+    int slot_xcc[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    int rc = MAPN_OK;
+    for (int s = 0; s < steps && !rc; s++) {
+        c->stamp_next = true; c->calibrating = true;
+        rc = mapn_simulate(c, (int)c->n, 0);
+        c->stamp_next = false; c->calibrating = false;
+        if (!rc) rc = mapn_wait_idle(c);
+        if (rc || !c->timeline_buf || !c->timeline_last) break;
+        std::vector<unsigned long long> tl(6 * c->timeline_last);
+        HIP_TRY(hipMemcpy(tl.data(), c->timeline_buf, c->timeline_last * 48, hipMemcpyDeviceToHost));
+        // A die is identified by the DISPATCH SLOT of the workgroups it gets -- workgroup number mod 8, what the plan's
+        // weights are indexed by -- not by its XCC_ID register (the two numberings need not agree); the register only has to
+        // be the same for all waves of a slot, which is checked: if it is not, workgroups are not dealt to the dies round-robin
+        // on this device and the weighting would be meaningless.
+        const mapn::SymPlanHost &pl = c->sym_plan;
+        const uint32_t nblk = c->sym_sharded ? c->count / mapn::SYM_BLOCK : pl.nb;
+        if (nblk % 8u) return fail(MAPN_ERR_STATE, "calibrate_sym_xcds: a launch covers %u blocks, not a multiple of 8: XCD weights do not apply", nblk);
+        for (size_t wv = 0; wv < c->timeline_last; wv++) {
+            const unsigned long long *o = &tl[6 * wv];
+            const uint32_t wg = (uint32_t)(wv / pl.waves), la = wg / pl.parts, part = wg % pl.parts;
+            const uint32_t x = pl.sets > 2u ? (la + nblk * pl.parts - part) % nblk : la;      // blockIdx.x of the workgroup: its number mod 8 is x mod 8
+            const unsigned slot = x & 7u, xcc = (unsigned)((o[4] >> 32) & 15u);
+            if (o[5] < 64 || o[2] <= o[1]) continue;
+            if (slot_xcc[slot] < 0) slot_xcc[slot] = (int)xcc;
+            else if (slot_xcc[slot] != (int)xcc)
+                return fail(MAPN_ERR_STATE, "calibrate_sym_xcds: workgroups of dispatch slot %u ran on XCC %d and %u: not dealt round-robin to the dies", slot, slot_xcc[slot], xcc);
+            per[slot].push_back((double)(o[2] - o[1]) / (double)o[5]);   // 100 MHz ticks per step
+        }
+    }
+    if (rc) return rc;
+    double speed[8], best = 0.0;
+    for (int x = 0; x < 8; x++) {
+        if (per[x].empty()) return fail(MAPN_ERR_STATE, "calibrate_sym_xcds: no wave was seen in dispatch slot %d (a partitioned or masked device?)", x);
+        std::nth_element(per[x].begin(), per[x].begin() + per[x].size() / 2, per[x].end());
+        speed[x] = 1.0 / per[x][per[x].size() / 2];
+        best = std::max(best, speed[x]);
+    }
+    for (int x = 0; x < 8; x++) out[x] = (uint32_t)(1024.0 * speed[x] / best + 0.5);
+    return MAPN_OK;
+}
+
 int mapn_get_sym_plan(mapn_ctx *c, mapn_sym_plan_info *info, uint32_t *windows, uint32_t *tables, uint64_t tables_capacity)
 {
     if (!c || !info) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
@@ -1876,6 +1945,7 @@ int mapn_get_sym_plan(mapn_ctx *c, mapn_sym_plan_info *info, uint32_t *windows, 
     info->nb = p.nb; info->groups = p.groups; info->windows = (uint32_t)p.windows.size();
     info->parts = p.parts; info->taper1 = p.taper1; info->taper2 = p.taper2; info->waves = p.waves;
     info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
+    info->sets = p.sets; for (int k = 0; k < 8; k++) info->xcd_weight[k] = p.xcd_weight[k];
     info->a0 = c->sym_sharded ? (uint32_t)c->cfg.rank * (c->count / mapn::SYM_BLOCK) : 0u;
     info->nbl = c->sym_sharded ? c->count / mapn::SYM_BLOCK : 0u;
     info->scratch_bytes = c->sym_scratch_bytes;

@@ -75,6 +75,7 @@ struct SymArgs {
     uint32_t      parts;      // workgroups per I-block (gridDim.y)
     uint32_t      nwaves;     // parts * waves per workgroup
     uint32_t      max_meetings;
+    uint32_t      sets;       // table sets: 2, or 16 = XCD-weighted parts: workgroup (x, y) runs part y of block (x + y) mod blocks, set = class + 2 * (block mod 8)
     uint32_t      g0, g1;     // meeting groups of this launch: 0 the block itself, 1 .. D partner a + g, D + 1 the half-ring partner
     uint32_t      brows;      // rows allocated per J-block (symmetric groups of the widest window)
     uint32_t      half_d;     // nb / 2 when nb is even (the half-ring partner), else 0
@@ -131,7 +132,7 @@ struct SymShardArgs {
     uint32_t     *ticket;                     // workgroups of this launch whose sends are acknowledged (zero between launches)
     uint32_t     *status;                     // host-visible word: non-zero = a wait timed out
     uint32_t      rank, world, count;         // count = bodies per rank (a multiple of SYM_BLOCK)
-    uint32_t      nb, nbl, a0, half_d, parts, nwaves, max_meetings;
+    uint32_t      nb, nbl, a0, half_d, parts, nwaves, max_meetings, sets;
     uint32_t      send_mask, recv_mask;       // bit q: this rank produces reactions for / receives reactions from rank q
     uint32_t      step;                       // monotonically increasing (>= 1): number of the reaction exchange
     uint32_t      pos_step;                   // number of this publication of new positions by a sharded symmetric step (0: they travel in another launch)

@@ -166,11 +166,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     if (p.timeline) asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tl_entry));
     // dispatch order is part-major -- all blocks' part 0, then part 1, ... -- so that the LATE workgroups are the
     // small ones when the parts taper
-    const uint32_t s = blockIdx.y, la = blockIdx.x, a = p.a0 + la;    // a: the I-block in the whole job; la: among this launch's
+    // (XCD-weighted parts, sets == 16: the parts of a block are spread over the dies -- workgroup (x, y) lands on XCD x mod 8 and
+    //  runs part y of block (x + y) mod blocks, so part s of block la runs on die (la - s) mod 8, which its share of the steps was sized for)
+    const uint32_t s = blockIdx.y, la = p.sets > 2u ? (blockIdx.x + blockIdx.y) % gridDim.x : blockIdx.x, a = p.a0 + la;    // a: the I-block in the whole job; la: among this launch's
     const uint32_t nb = p.nb, half = p.half_d;             // half_d = NB/2 when NB is even, else 0
     const uint32_t D = (nb - 1u) / 2u;
     const uint32_t cls = (half && a < half) ? 0u : 1u;     // class 0: the blocks that also run the half-ring group
-    const uint32_t *bounds = p.tab + cls * (p.nwaves + 1u);
+    const uint32_t set = cls + (p.sets > 2u ? 2u * (la & 7u) : 0u);
+    const uint32_t *bounds = p.tab + set * (p.nwaves + 1u);
     const uint32_t t0 = bounds[s * WAVES + w], t1 = bounds[s * WAVES + w + 1u];
 
     const float4 *__restrict__ pos = p.pos_old;
@@ -411,7 +414,9 @@ __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs
     const uint32_t D = (p.nb - 1u) / 2u, gs0 = p.g0 ? p.g0 : 1u;
     const uint32_t gend = (p.g1 == D + 2u && !(p.half_d && a >= p.half_d)) ? D + 1u : p.g1;
     const float4 *br = p.brow + (size_t)jb * p.brows * 64u + (i & 63u);
-    const uint32_t *split0 = p.tab + 2u * (p.nwaves + 1u), *split1 = split0 + p.max_meetings;
+    // split table of the block that ran a meeting: set = class (+ 2 * (block mod 8) with XCD-weighted parts)
+    const uint32_t *splits = p.tab + p.sets * (p.nwaves + 1u);
+    auto split_of = [&](uint32_t blk) { return splits + (size_t)(((p.half_d && blk < p.half_d) ? 0u : 1u) + (p.sets > 2u ? 2u * (blk & 7u) : 0u)) * p.max_meetings; };
     const uint32_t t = jb % SYM_JPI;
     for (uint32_t g = gs0; g < gend; g += 8u) {            // 8 meetings in flight, summed in ascending order
         float4 v[8], h[8];
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs
             const bool live = gu < gend;
             const uint32_t d = gu <= D ? gu : p.half_d;
             apv[u] = a >= d ? a - d : a + p.nb - d;                                // the I-block that ran this meeting
-            sp[u] = live ? ((p.half_d && apv[u] < p.half_d) ? split0 : split1)[(gu - p.g0) * SYM_JPI + t] : 0xffffffffu;
+            sp[u] = live ? split_of(apv[u])[(gu - p.g0) * SYM_JPI + t] : 0xffffffffu;
         }
 #pragma unroll
         for (uint32_t u = 0; u < 8u; u++) {
@@ -505,7 +510,9 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         if (p.timeline && threadIdx.x == 0) p.timeline[(size_t)bid * 8u + k] = __builtin_amdgcn_s_memrealtime();
     };
     stamp(0);
-    const uint32_t *split0 = p.tab + 2u * (p.nwaves + 1u), *split1 = split0 + p.max_meetings;
+    // split table of the block that ran a meeting: set = class (+ 2 * (LOCAL block mod 8) with XCD-weighted parts)
+    const uint32_t *splits = p.tab + p.sets * (p.nwaves + 1u);
+    auto split_of = [&](uint32_t a, uint32_t la) { return splits + (size_t)(((p.half_d && a < p.half_d) ? 0u : 1u) + (p.sets > 2u ? 2u * (la & 7u) : 0u)) * p.max_meetings; };
     const uint32_t total = p.phase == 2u ? 0u : p.world * p.count;
     for (uint32_t t = bid * 256u + threadIdx.x; t < total; t += nblk * 256u) {
         const uint32_t q = t / p.count, jl = t - q * p.count;
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
             for (uint32_t u = 0; u < 8u; u++) {
                 const uint32_t a = p.a0 + la + u;
                 gg[u] = la + u < p.nbl ? sym_group(a, b, p.nb, p.half_d) : 0u;
-                sp[u] = ((p.half_d && a < p.half_d) ? split0 : split1)[gg[u] * SYM_JPI + tt];   // (group 0: the block itself, never cut)
+                sp[u] = split_of(a, la + u)[gg[u] * SYM_JPI + tt];   // (group 0: the block itself, never cut)
             }
 #pragma unroll
             for (uint32_t u = 0; u < 8u; u++) {

@@ -20,7 +20,7 @@ uint32_t units(uint32_t x, uint32_t t1, uint32_t t2)
 }  // namespace
 
 bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t waves,
-                    SymPlanHost &out, std::string &err)
+                    const uint32_t *xcd_weight, uint32_t launch_blocks, SymPlanHost &out, std::string &err)
 {
     char msg[256];
     if (nb == 0 || parts == 0 || waves == 0 || 64u % waves != 0u || taper1 + taper2 > parts) {
@@ -33,6 +33,13 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
     const uint32_t gsym = p.D + (p.half ? 1u : 0u);            // symmetric groups 1 .. gsym
     p.groups = 1u + gsym;
     p.parts = parts; p.taper1 = taper1; p.taper2 = taper2; p.waves = waves; p.nwaves = parts * waves;
+    bool weighted = false;
+    if (xcd_weight && (launch_blocks ? launch_blocks : nb) % 8u == 0u) {
+        for (int k = 0; k < 8; k++) weighted = weighted || xcd_weight[k] != xcd_weight[0];
+        for (int k = 0; k < 8; k++) if (xcd_weight[k] == 0u || xcd_weight[k] > (1u << 20)) { err = "symmetric plan: XCD weights must be 1 .. 2^20"; return false; }
+    }
+    p.sets = weighted ? 16u : 2u;
+    for (int k = 0; k < 8; k++) p.xcd_weight[k] = weighted ? xcd_weight[k] : 0u;
     // windows: the symmetric groups in nwin runs of (nearly) equal length; the block itself rides in the first
     const uint32_t cap = groups_per_window ? groups_per_window : std::max(1u, gsym);
     const uint32_t nwin = std::max(1u, (gsym + cap - 1u) / cap);
@@ -50,23 +57,31 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
         p.windows.push_back(w);
     }
     p.brows = std::max(p.brows, 1u);
-    p.table_stride = 2u * (p.nwaves + 1u) + 2u * p.max_meetings;
+    p.table_stride = p.sets * (p.nwaves + 1u) + p.sets * p.max_meetings;
     p.tables.assign((size_t)nwin * p.table_stride, SYM_SPLIT_NONE);
 
-    const uint32_t U = units(parts, taper1, taper2);
     for (uint32_t k = 0; k < nwin; k++) {
         const SymWindow &w = p.windows[k];
-        for (uint32_t cls = 0; cls < 2; cls++) {
-            uint32_t *bounds = p.tables.data() + (size_t)k * p.table_stride + cls * (p.nwaves + 1u);
-            uint32_t *split = p.tables.data() + (size_t)k * p.table_stride + 2u * (p.nwaves + 1u) + cls * p.max_meetings;
+        for (uint32_t set = 0; set < p.sets; set++) {
+            const uint32_t cls = set & 1u, r = set >> 1;           // r = block mod 8: which die part s of the block runs on is (r - s) mod 8
+            uint32_t *bounds = p.tables.data() + (size_t)k * p.table_stride + set * (p.nwaves + 1u);
+            uint32_t *split = p.tables.data() + (size_t)k * p.table_stride + p.sets * (p.nwaves + 1u) + set * p.max_meetings;
             const uint32_t M = w.meetings[cls], L = 64u * M;
             const uint32_t Ls = (w.g0 == 0u && M) ? 64u * JPI : 0u;        // steps of the block against itself (weighted by SYM_COST_SELF)
             const uint64_t ctot = (uint64_t)SYM_COST_SELF * Ls + (uint64_t)SYM_COST_SYM * (L - Ls);
+            // weight of part s: its size in the taper (4 : 2 : 1) times the speed of the die it runs on
+            auto part_weight = [&](uint32_t s) -> uint64_t {
+                const uint64_t size = units(s + 1u, taper1, taper2) - units(s, taper1, taper2);
+                return size * (weighted ? p.xcd_weight[(r + 8u * parts - s) & 7u] : 1u);
+            };
+            uint64_t wtot = 0;
+            for (uint32_t s = 0; s < parts; s++) wtot += part_weight(s) * waves;
+            uint64_t before = 0;                                           // weight of the parts before part s
             for (uint32_t v = 0; v <= p.nwaves; v++) {
                 const uint32_t s = v / waves, ww = v % waves;
-                const uint64_t num = (uint64_t)units(s, taper1, taper2) * waves +
-                                     (s < parts ? (uint64_t)(units(s + 1u, taper1, taper2) - units(s, taper1, taper2)) * ww : 0u);
-                const uint64_t target = ctot * num / ((uint64_t)U * waves);   // cost that lies before wave v
+                if (v && ww == 0u) before += part_weight(s - 1u) * waves;
+                const uint64_t num = before + (s < parts ? part_weight(s) * ww : 0u);
+                const uint64_t target = ctot * num / wtot;                 // cost that lies before wave v
                 bounds[v] = target <= (uint64_t)SYM_COST_SELF * Ls ? (uint32_t)(target / SYM_COST_SELF)
                                                                    : Ls + (uint32_t)((target - (uint64_t)SYM_COST_SELF * Ls) / SYM_COST_SYM);
             }
@@ -100,12 +115,13 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
 
 // ---- C ABI: the plan as data, without a device (tests, the order-matched oracle) ------------------
 extern "C" int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2,
-                                      uint32_t waves, mapn_sym_plan_info *info, uint32_t *windows, uint32_t *tables, uint64_t tables_capacity)
+                                      uint32_t waves, const uint32_t *xcd_weights, uint32_t launch_blocks, mapn_sym_plan_info *info,
+                                      uint32_t *windows, uint32_t *tables, uint64_t tables_capacity)
 {
     if (!info) return MAPN_ERR_INVALID_ARGUMENT;
     mapn::SymPlanHost p;
     std::string err;
-    if (!mapn::build_sym_plan(nb, groups_per_window, parts, taper1, taper2, waves, p, err)) {
+    if (!mapn::build_sym_plan(nb, groups_per_window, parts, taper1, taper2, waves, xcd_weights, launch_blocks, p, err)) {
         snprintf(info->error, sizeof info->error, "%s", err.c_str());
         return MAPN_ERR_INVALID_ARGUMENT;
     }
@@ -113,6 +129,7 @@ extern "C" int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, u
     info->nb = p.nb; info->groups = p.groups; info->windows = (uint32_t)p.windows.size();
     info->parts = p.parts; info->taper1 = p.taper1; info->taper2 = p.taper2; info->waves = p.waves;
     info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
+    info->sets = p.sets; for (int k = 0; k < 8; k++) info->xcd_weight[k] = p.xcd_weight[k];
     info->a0 = 0; info->nbl = 0; info->active_compute_units = 0; info->exchange_workgroups = 0; info->scratch_bytes = 0;
     if (windows)
         for (size_t k = 0; k < p.windows.size(); k++) {

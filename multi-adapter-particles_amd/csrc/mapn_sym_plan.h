@@ -20,6 +20,12 @@ constexpr uint32_t SYM_COST_SELF = 6, SYM_COST_SYM = 6;   // relative cost of a 
 //   g = 0: the block itself, one-sided;  g = 1 .. D = (nb - 1) / 2: partner block a + g (mod nb), symmetric;
 //   g = D + 1 (even nb only): the half-ring partner a + nb / 2, run by the blocks a < nb / 2 alone.
 // CLASS 0 = the blocks that have the half-ring group, class 1 = the others (all blocks when nb is odd).
+// SETS.  The eight XCDs of an MI355X do not run at one speed (measured: 0.538 - 0.570 us per step under this kernel, the same
+// dies slow on every launch of a box) and a launch gives every XCD the same work, so it ends with the slowest die.  With XCD
+// weights (mapn_set_sym_xcd_weights; from a calibration, mapn_calibrate_sym_xcds) the parts of every block are spread over the
+// dies -- workgroup (x, y) of the grid runs part y of block (x + y) mod blocks, and lands on XCD x mod 8 when the launch's block
+// count is a multiple of 8 -- and a part's share of the block's steps is proportional to the speed of the die it runs on.  The
+// tables then exist per SET = class + 2 * (block mod 8): 16 sets instead of 2.
 // A WINDOW is one force launch: the groups [g0, g1).  Inside a window meeting m = (g - g0) * 16 + t, step k of
 // meeting m has the linear index 64 m + k, and wave v = part * waves + wave-in-workgroup runs the steps
 // [bounds[v], bounds[v + 1]) -- every wave at least 64 of them, so a meeting is cut at most once:
@@ -39,18 +45,22 @@ struct SymPlanHost {
     uint32_t nwaves = 0;                     // parts * waves
     uint32_t brows = 0;                      // reaction-row slots per J-block and window (most symmetric groups in one window)
     uint32_t max_meetings = 0;               // most meetings of a block in one window
-    uint32_t table_stride = 0;               // uint32 per window: bounds[2][nwaves + 1], split[2][max_meetings]
+    uint32_t sets = 2;                       // table sets per window: 2 (one per class) or 16 (class + 2 * (block mod 8): XCD-weighted parts)
+    uint32_t xcd_weight[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // relative speed of the dies the parts were weighted with (sets == 16)
+    uint32_t table_stride = 0;               // uint32 per window: bounds[sets][nwaves + 1], split[sets][max_meetings]
     std::vector<SymWindow> windows;
     std::vector<uint32_t> tables;            // windows.size() * table_stride
 
-    const uint32_t *bounds(size_t window, uint32_t cls) const { return tables.data() + window * table_stride + cls * (nwaves + 1); }
-    const uint32_t *split(size_t window, uint32_t cls) const { return tables.data() + window * table_stride + 2 * (nwaves + 1) + cls * max_meetings; }
+    const uint32_t *bounds(size_t window, uint32_t set) const { return tables.data() + window * table_stride + set * (nwaves + 1); }
+    const uint32_t *split(size_t window, uint32_t set) const { return tables.data() + window * table_stride + sets * (nwaves + 1) + set * max_meetings; }
 };
 
 // groups_per_window: most SYMMETRIC groups one launch may hold (0 = all in one launch).  parts workgroups per
 // I-block whose sizes taper 4 : 2 : 1 (the first taper1 parts weigh 4, the next taper2 weigh 2, the rest 1;
 // taper1 = parts: equal parts).  Fails (false + err) when a wave would get fewer than 64 steps.
+// xcd_weight: null or 8 relative speeds (all equal = none); they take effect only when launch_blocks (the blocks ONE launch
+// covers: nb, or a rank's share) is a multiple of 8 -- otherwise the plan is the unweighted one.
 bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t waves,
-                    SymPlanHost &out, std::string &err);
+                    const uint32_t *xcd_weight, uint32_t launch_blocks, SymPlanHost &out, std::string &err);
 
 }  // namespace mapn

@@ -89,11 +89,11 @@ def sym_reaction_rows(nb: int, block: int) -> list[int]:
     return list(range(D + (1 if half and block >= half else 0)))
 
 
-def sym_wave_pieces(plan, window: int, cls: int):
+def sym_wave_pieces(plan, window: int, set_: int):
     """How force_sym_kernel walks a block's meetings: yields (part, wave in the workgroup, meeting of the window, first
     step, steps) for every piece of every wave, from the host-built plan tables (`plan`: mapn.SymPlan -- the tables the
     kernel itself reads).  Wave v runs the linear steps [bounds[v], bounds[v + 1]); step 64 m + k is step k of meeting m."""
-    b = plan.bounds(window, cls)
+    b = plan.bounds(window, set_)      # set_: the block's class, or class + 2 * (block mod 8) with XCD-weighted parts (plan.set_of)
     for v in range(plan.nwaves):
         t, t1 = int(b[v]), int(b[v + 1])
         while t < t1:

@@ -50,15 +50,15 @@ class SymShape(C.Structure):
     """Shape of the device's SYMMETRIC launch plan (include/mapn.h, mapn_sym_plan_info) for the order-matched
     restatement of that kernel (mapn_oracle.c, ORDER_MATCHED_SYM)."""
 
-    _fields_ = [(k, C.c_uint32) for k in ("nb", "groups", "windows", "parts", "waves", "brows", "max_meetings", "table_stride")]
+    _fields_ = [(k, C.c_uint32) for k in ("nb", "groups", "windows", "parts", "waves", "brows", "max_meetings", "table_stride", "sets")]
 
 
 def sym_plan_args(plan):
     """(SymShape, windows, tables) from a plan object as the product's binding returns it (duck-typed: attributes
-    nb, groups, parts, waves, brows, max_meetings, table_stride and the uint32 arrays windows [k, 4], tables)."""
+    nb, groups, parts, waves, brows, max_meetings, table_stride, sets and the uint32 arrays windows [k, 4], tables)."""
     win = np.ascontiguousarray(plan.windows, np.uint32)
     tab = np.ascontiguousarray(plan.tables, np.uint32)
-    shape = SymShape(plan.nb, plan.groups, win.shape[0], plan.parts, plan.waves, plan.brows, plan.max_meetings, plan.table_stride)
+    shape = SymShape(plan.nb, plan.groups, win.shape[0], plan.parts, plan.waves, plan.brows, plan.max_meetings, plan.table_stride, getattr(plan, "sets", 2))
     assert tab.size == win.shape[0] * plan.table_stride
     return shape, win, tab
 

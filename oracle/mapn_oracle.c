@@ -736,7 +736,8 @@ void mapn_oracle_initial_state(uint32_t seed, uint32_t n, float spread, float sp
  *
  * The launch plan is DATA handed in by the test (include/mapn.h: mapn_get_sym_plan /
  * mapn_sym_plan_describe): windows[k] = {g0, g1, meetings of a class-0 block, of a class-1 block};
- * per window bounds[2][parts * waves + 1] and split[2][max_meetings].  Restated, in the device's order:
+ * per window bounds[sets][parts * waves + 1] and split[sets][max_meetings] (set = class, or class + 2 * (block mod 8) when the
+ * device's parts are XCD-weighted).  Restated, in the device's order:
  *   * blocks of 1024 bodies (the last padded with stand-ins at 3e18 that exert and feel nothing); group g of
  *     block a: 0 = a itself (one-sided), 1..D = partner a + g, D + 1 = the half-ring partner (class 0 only);
  *     meeting m of a window = group g0 + m / 16, 64-body J-block m % 16 of the partner;
@@ -754,6 +755,7 @@ void mapn_oracle_initial_state(uint32_t seed, uint32_t n, float spread, float sp
  * ================================================================================================= */
 typedef struct {
     uint32_t nb, groups, windows, parts, waves, brows, max_meetings, table_stride;
+    uint32_t sets;   /* table sets per window: 2 (one per class) or 16 (class + 2 * (block mod 8): the device's XCD-weighted parts) */
 } mapn_oracle_sym_shape;
 
 #define SYM_IB 1024u
@@ -788,7 +790,8 @@ static void sym_workgroup(const sym_job *J, uint32_t a, uint32_t s, float *scrat
     const uint32_t nb = sh->nb, D = (nb - 1u) / 2u, half = (nb & 1u) ? 0u : nb / 2u, W = sh->waves;
     const uint32_t g0 = J->win[0];
     const uint32_t cls = (half && a < half) ? 0u : 1u;
-    const uint32_t *bounds = J->tab + cls * (sh->parts * W + 1u);
+    const uint32_t set = cls + (sh->sets > 2u ? 2u * (a & 7u) : 0u);
+    const uint32_t *bounds = J->tab + set * (sh->parts * W + 1u);
     const float soft2 = J->p->soft2;
     float *xi = scratch, *yi = xi + SYM_IB, *zi = yi + SYM_IB;          /* the I-block */
     float *accw = zi + SYM_IB;                                           /* [W][3][1024] */
@@ -900,7 +903,7 @@ static void *sym_reduce_worker(void *arg)
     const mapn_oracle_sym_shape *sh = J->sh;
     const uint32_t nb = sh->nb, D = (nb - 1u) / 2u, half = (nb & 1u) ? 0u : nb / 2u;
     const uint32_t g0 = J->win[0], g1 = J->win[1], gs0 = g0 ? g0 : 1u;
-    const uint32_t *split0 = J->tab + 2u * (sh->parts * sh->waves + 1u), *split1 = split0 + sh->max_meetings;
+    const uint32_t *splits = J->tab + sh->sets * (sh->parts * sh->waves + 1u);
     const size_t np = (size_t)nb * SYM_IB;
     for (uint32_t i = J->tid; i < J->n; i += J->nthreads) {
         const uint32_t a = i / SYM_IB, jb = i >> 6, l = i & 63u, tt = jb % SYM_JPI;
@@ -919,7 +922,7 @@ static void *sym_reduce_worker(void *arg)
                     const uint32_t d = gu <= D ? gu : half, ap = a >= d ? a - d : a + nb - d;
                     const float *r0 = J->brow + ((size_t)jb * sh->brows + (gu - gs0)) * 192u;
                     vx = r0[l]; vy = r0[64 + l]; vz = r0[128 + l];
-                    const uint32_t sp = ((half && ap < half) ? split0 : split1)[(gu - g0) * SYM_JPI + tt];
+                    const uint32_t sp = (splits + (size_t)(((half && ap < half) ? 0u : 1u) + (sh->sets > 2u ? 2u * (ap & 7u) : 0u)) * sh->max_meetings)[(gu - g0) * SYM_JPI + tt];
                     if (sp != SYM_NONE) {
                         const float *h0 = J->brow1 + ((size_t)ap * sh->parts + sp) * 192u;
                         hx = h0[l]; hy = h0[64 + l]; hz = h0[128 + l];
@@ -958,7 +961,7 @@ int mapn_oracle_step_all_pairs_sym(const float *old_pos, const float *old_vel, f
                                    const mapn_oracle_params *p, int threads, const mapn_oracle_sym_shape *shape,
                                    const uint32_t *windows, const uint32_t *tables)
 {
-    if (!shape || !windows || !tables || shape->nb != (n + SYM_IB - 1u) / SYM_IB || shape->waves == 0 || shape->parts == 0) return -2;
+    if (!shape || !windows || !tables || shape->nb != (n + SYM_IB - 1u) / SYM_IB || shape->waves == 0 || shape->parts == 0 || (shape->sets != 2u && shape->sets != 16u)) return -2;
     if (threads <= 0) threads = mapn_oracle_hardware_threads();
     const size_t np = (size_t)shape->nb * SYM_IB;
     float *arow = (float *)malloc(sizeof(float) * 3u * SYM_IB * shape->nb * shape->parts);

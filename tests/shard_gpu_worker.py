@@ -60,6 +60,9 @@ def main():
         # owners' receive regions, positions pulled as in "p2p"
         # "sympush" = the same with the new positions PUSHED into the peers' replicas by the exchange launch (gather algorithm 5)
         c.set_gather_algorithm({"p2p": 2, "flow": 3, "sym": 4, "sympush": 5}[mode])
+        if os.environ.get("MAPN_WORKER_XCD_W") and mode in ("sym", "sympush"):
+            c.set_sym_xcd_weights([int(x) for x in os.environ["MAPN_WORKER_XCD_W"].split(",")])
+            assert c.sym_plan().sets == (16 if (count // 1024) % 8 == 0 else 2)
         if os.environ.get("HSA_CU_MASK") and mode in ("sym", "sympush") and count % 1024 == 0:
             plan = c.sym_plan()                 # the probe must have seen the mask, and the launch must be sized for it
             assert plan.active_compute_units <= 64 and plan.exchange_workgroups <= 4 * plan.active_compute_units, (plan.active_compute_units, plan.exchange_workgroups)

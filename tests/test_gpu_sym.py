@@ -105,6 +105,37 @@ def test_symmetric_kernel_against_its_order_matched_oracle(oracle, n, shape):
     assert errs(v, rv, SPEED)[0] < 1e-6
 
 
+@pytest.mark.parametrize("n", [8192, 65536])
+def test_xcd_weighted_parts_against_the_order_matched_oracle(oracle, n):
+    """mapn_calibrate_sym_xcds returns eight relative die speeds; with them (and with a deliberately lopsided set) the parts of
+    every block are spread over the dies and sized by their speed -- another summation order, restated by the oracle from the
+    same 16-set plan: bit-identical for most bodies again, and bit-reproducible for given weights."""
+    mass = 70000.0 / n
+    pos, vel = oracle.initial_state(n, seed=6)
+    with mapn.Compute(n, mass=mass, seed=6, kernel=mapn.KERNEL_SYMMETRIC) as c:
+        w = c.calibrate_sym_xcds(2)
+        assert len(w) == 8 and max(w) == 1024 and min(w) > 800, w
+        print(f"N={n}: calibrated XCD weights {w}")
+        for weights in (w, [1024, 900, 1000, 950, 1024, 880, 990, 1010]):
+            c.upload_state(pos, vel)
+            c.set_sym_xcd_weights(weights)
+            plan = c.sym_plan()
+            if len(set(weights)) > 1:
+                assert plan.sets == 16 and plan.xcd_weight == list(weights)
+            draw(c, 2)
+            p, v = c.download_state()
+            c.upload_state(pos, vel)
+            draw(c, 2)
+            np.testing.assert_array_equal(c.download_state()[0], p)          # bit-reproducible for given weights
+            sim = OracleSim(oracle, pos, vel, params=Params(mass=mass), sym_plan=plan)
+            sim.simulate(steps=2)
+            rp = sim.latest[0]
+            rel = np.linalg.norm(p[:, :3].astype(np.float64) - rp[:, :3], axis=1) / np.maximum(np.linalg.norm(rp[:, :3].astype(np.float64), axis=1), 1e-30)
+            assert rel.max() <= 3e-7 and float((p[:, :3] == rp[:, :3]).all(axis=1).mean()) >= 0.9, rel.max()
+        c.set_sym_xcd_weights(None)
+        assert c.sym_plan().sets == 2
+
+
 def test_windows_of_partner_distance_change_only_the_rounding(oracle):
     """One step made in 1, 2 and 4 force launches (windows): the running sum is carried in a fixed order, so each is
     bit-reproducible, and they differ from each other by partial-sum rounding only."""

@@ -139,6 +139,19 @@ def test_pushed_positions_give_the_same_bits_as_pulled_ones(tmp_path):
             np.testing.assert_array_equal(a[k], b[k])
 
 
+def test_sharded_symmetric_step_with_xcd_weighted_parts(tmp_path, oracle):
+    """XCD-weighted parts in the sharded launch (a rank's 8 blocks: the launch covers a multiple of 8): parts of every block spread
+    over the dies, the exchange launch reading the split tables of the same 16 sets.  Against the oracle."""
+    from oracle import OracleSim, Params
+    n, world, steps = 16384, 2, 5
+    got = _run_ranks(tmp_path, world, n, steps, "sympush", str(n), env={"MAPN_WORKER_XCD_W": "1024,900,1000,950,1024,880,990,1010"})
+    pos0, vel0 = oracle.initial_state(n, seed=1)
+    sim = OracleSim(oracle, pos0, vel0, params=Params(mass=70000.0 / n))
+    sim.simulate(steps=steps)
+    dx = np.linalg.norm(got["pos"][:, :3].astype(np.float64) - sim.latest[0][:, :3], axis=1).max() / 400.0
+    assert dx < 8e-6, dx
+
+
 def test_exchange_launch_is_sized_for_the_compute_units_the_process_really_gets(tmp_path):
     """The exchange launch's workgroups wait for each other and for the peers, so all of them must be resident at once.
     Its grid is capped by what ONE compute unit holds (asked of the runtime) times the units that really take the process's

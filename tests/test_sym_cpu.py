@@ -111,25 +111,52 @@ def test_plan_that_would_leave_a_wave_fewer_than_64_steps_is_refused():
         mapn.describe_sym_plan(64, 0, 32, 30, 4, 4)            # taper1 + taper2 > parts
 
 
-@pytest.mark.parametrize("nb,gpw,parts,t1,t2,waves", PLAN_SHAPES[:13])
-def test_force_kernel_writes_exactly_the_rows_the_reduce_kernel_reads(nb, gpw, parts, t1, t2, waves):
+XCD_W = [1024, 970, 1010, 1000, 1020, 985, 1024, 990]      # what a calibration returns: the dies' relative speeds
+
+
+def test_xcd_weighted_parts_are_sized_by_the_speed_of_the_die_they_run_on():
+    """mapn_set_sym_xcd_weights: with weights the plan has 16 table sets (class + 2 * (block mod 8)); part s of a block whose
+    index is r mod 8 runs on die (r - s) mod 8 and its waves get steps in proportion to that die's speed; equal weights, or a
+    launch that does not cover a multiple of 8 blocks, give the default plan."""
+    import mapn
+    plan = mapn.describe_sym_plan(64, 0, 32, None, 0, 4, xcd_weights=XCD_W)
+    assert plan.sets == 16 and plan.xcd_weight == XCD_W
+    base = mapn.describe_sym_plan(64, 0, 32, None, 0, 4)
+    assert base.sets == 2 and mapn.describe_sym_plan(64, 0, 32, None, 0, 4, xcd_weights=[1000] * 8).sets == 2
+    assert mapn.describe_sym_plan(98, 0, 32, None, 0, 4, xcd_weights=XCD_W).sets == 2          # 100 000 bodies: 98 blocks
+    assert mapn.describe_sym_plan(64, 0, 32, None, 0, 4, xcd_weights=XCD_W, launch_blocks=4).sets == 2
+    for r in range(8):
+        for cls in (0, 1):
+            b = plan.bounds(0, plan.set_of(cls, r)).astype(np.int64)
+            per_part = np.diff(b).reshape(32, 4).sum(axis=1)
+            w = np.array([XCD_W[(r - s) % 8] for s in range(32)], np.float64)
+            want = w / w.sum() * b[-1]
+            assert np.abs(per_part - want).max() <= 4, (r, cls)       # whole steps: a few steps of slack
+            assert b[-1] == np.diff(base.bounds(0, cls).astype(np.int64)).sum()
+
+
+@pytest.mark.parametrize("nb,gpw,parts,t1,t2,waves,xw", [sh + (None,) for sh in PLAN_SHAPES[:13]] +
+                         [(8, 0, 8, None, 0, 4, XCD_W), (16, 3, 4, None, 0, 4, XCD_W), (64, 0, 36, 28, 8, 4, XCD_W)])
+def test_force_kernel_writes_exactly_the_rows_the_reduce_kernel_reads(nb, gpw, parts, t1, t2, waves, xw):
     """force_sym_kernel's bookkeeping replayed from the plan tables: every step of every meeting is run exactly once; a symmetric
     meeting's row is written exactly once (whole, or put together in LDS from two waves of one workgroup, or its first steps when
     it is cut between two workgroups -- then its last steps go to the later workgroup's head row); sym_reduce_integrate_kernel
     reads a meeting's row and, where the split table says so, that very head row -- and nothing else is ever written."""
     import mapn
-    plan = mapn.describe_sym_plan(nb, gpw, parts, t1, t2, waves)
+    plan = mapn.describe_sym_plan(nb, gpw, parts, t1, t2, waves, xcd_weights=xw)
+    assert plan.sets == (16 if xw else 2)
     D, half = (nb - 1) // 2, (nb // 2 if nb % 2 == 0 else 0)
     for k, w in enumerate(plan.windows):
         g0, g1 = int(w[0]), int(w[1])
         rows, heads = {}, {}                                   # (J-block, group) -> writes; (I-block, part) -> meeting it holds
-        for a in range(nb if nb <= 9 else 3):                  # every block for small jobs, else a class-0, class-0, class-0/1 sample
-            a = a if nb <= 9 else (0, half - 1 if half else 1, nb - 1)[a]
+        for a in range(nb if nb <= 16 else 3):                 # every block for small jobs, else a class-0, class-0, class-0/1 sample
+            a = a if nb <= 16 else (0, half - 1 if half else 1, nb - 1)[a]
             cls = shard.sym_block_class(nb, a)
+            st = plan.set_of(cls, a)
             M = int(w[2 + cls])
             seen = np.zeros((max(M, 1), 64), np.int32)
             lds = {}                                           # (part, wave, which) -> meeting
-            for s, wv, m, k0, n in shard.sym_wave_pieces(plan, k, cls):
+            for s, wv, m, k0, n in shard.sym_wave_pieces(plan, k, st):
                 seen[m, k0:k0 + n] += 1
                 g, t = g0 + m // 16, m % 16
                 if g == 0:
@@ -153,7 +180,7 @@ def test_force_kernel_writes_exactly_the_rows_the_reduce_kernel_reads(nb, gpw, p
                         lds[(s, wv, 0)] = key
             assert not lds and (seen[:M] == 1).all()
             # what the reduce kernel reads for the rows this block wrote: the split table names the head row
-            sp = plan.split(k, cls)
+            sp = plan.split(k, st)
             for m in range(M):
                 g, t = g0 + m // 16, m % 16
                 if g == 0:

@@ -54,8 +54,9 @@ typedef enum mapn_kernel {
     MAPN_KERNEL_LDS = 1,        /* j-tiles staged through LDS, broadcast ds_read */
     MAPN_KERNEL_SCALAR = 2,     /* j-bodies through the scalar cache into SGPRs */
     MAPN_KERNEL_SYMMETRIC = 3   /* Newton's third law: every unordered pair evaluated once, feeding both bodies
-                                   (csrc/mapn_sym.hip).  Applies to the unsharded step with all bodies active and
-                                   N >= 1024; any other step of such a context runs the scalar-cache kernel.  Its
+                                   (csrc/mapn_sym.hip).  Applies to the unsharded step with N >= 1024 and at least
+                                   three quarters of the bodies active (the frozen ones still exert force); any other
+                                   step of such a context runs the scalar-cache kernel.  Its
                                    scratch is O(N): a step is made in as many launches (windows of partner distance) as
                                    keep the reaction rows within MAPN_SYM_MAX_MB (default 1024), and is allocated by
                                    mapn_create -- which fails if the memory is not to be had.  Under
@@ -404,6 +405,7 @@ int mapn_set_force_plan(mapn_ctx *ctx, int kernel, uint32_t bodies_per_lane, uin
 typedef struct mapn_sym_plan_info {
     uint32_t nb, groups, windows;
     uint32_t parts, taper1, taper2, waves;
+    uint32_t wave_bias[2];       /* share of a workgroup's steps: first half of its waves : second half (1 : 1 = equal) */
     uint32_t brows, max_meetings, table_stride;
     uint32_t sets;               /* table sets per window: 2 (one per class) or 16 (class + 2 * (block mod 8): XCD-weighted parts) */
     uint32_t xcd_weight[8];      /* the relative die speeds the parts were weighted with (sets == 16), else 0 */
@@ -414,10 +416,12 @@ typedef struct mapn_sym_plan_info {
     char     error[256];         /* why a shape was refused / why the kernel does not run */
 } mapn_sym_plan_info;
 int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2,
-                           uint32_t waves, const uint32_t *xcd_weights, uint32_t launch_blocks, mapn_sym_plan_info *info,
+                           uint32_t waves, uint32_t wave_bias_hi, uint32_t wave_bias_lo, const uint32_t *xcd_weights,
+                           uint32_t launch_blocks, mapn_sym_plan_info *info,
                            uint32_t *windows, uint32_t *tables, uint64_t tables_capacity);
 int mapn_get_sym_plan(mapn_ctx *ctx, mapn_sym_plan_info *info, uint32_t *windows, uint32_t *tables, uint64_t tables_capacity);
-int mapn_set_sym_plan(mapn_ctx *ctx, uint32_t waves, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t groups_per_window);
+int mapn_set_sym_plan(mapn_ctx *ctx, uint32_t waves, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t groups_per_window,
+                      uint32_t wave_bias_hi, uint32_t wave_bias_lo);
 /*
  * XCD-aware parts.  The eight XCDs of an MI355X do not run at one speed under this kernel (measured 0.538 - 0.570 us per
  * step, the same dies slow on every launch of a box) while a launch gives every die the same work, so it ends with the

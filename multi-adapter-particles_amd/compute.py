@@ -244,9 +244,10 @@ class Compute:
         """fused: False/0 two launches (rows + reduce_integrate), True/1 one launch, 2 ticket form always."""
         check(self._lib.mapn_set_force_plan(self._ctx, kernel, bodies_per_lane, waves, sb, int(fused)))
 
-    def set_sym_plan(self, waves: int = 0, parts: int = 0, taper1: int = 0, taper2: int = 0, groups_per_window: int = 0):
-        """Shape of the symmetric kernel's launches (waves = parts = 0: the default); re-allocates its scratch."""
-        check(self._lib.mapn_set_sym_plan(self._ctx, waves, parts, taper1, taper2, groups_per_window))
+    def set_sym_plan(self, waves: int = 0, parts: int = 0, taper1: int = 0, taper2: int = 0, groups_per_window: int = 0, wave_bias=(1, 1)):
+        """Shape of the symmetric kernel's launches (waves = parts = 0: the default); re-allocates its scratch.
+        wave_bias = (hi, lo): the first half of a workgroup's waves carries hi : lo of its steps against the second half."""
+        check(self._lib.mapn_set_sym_plan(self._ctx, waves, parts, taper1, taper2, groups_per_window, int(wave_bias[0]), int(wave_bias[1])))
 
     def calibrate_sym_xcds(self, steps: int = 4):
         """Relative speeds of the eight XCDs under the symmetric kernel (1024 = the fastest), from `steps` stamped REAL steps."""
@@ -352,6 +353,7 @@ class SymPlan:
 
     def __init__(self, info, windows, tables):
         self.info, self.windows, self.tables = info, windows, tables
+        self.wave_bias = (int(info.wave_bias[0]), int(info.wave_bias[1]))
         for k in ("nb", "groups", "parts", "taper1", "taper2", "waves", "brows", "max_meetings", "table_stride", "sets", "a0", "nbl", "active_compute_units", "exchange_workgroups", "scratch_bytes"):
             setattr(self, k, int(getattr(info, k)))
         self.nwaves = self.parts * self.waves
@@ -371,19 +373,19 @@ class SymPlan:
 
 
 def describe_sym_plan(nb: int, groups_per_window: int = 0, parts: int = 32, taper1: int | None = None, taper2: int = 0, waves: int = 4,
-                      xcd_weights=None, launch_blocks: int = 0) -> SymPlan:
+                      xcd_weights=None, launch_blocks: int = 0, wave_bias=(1, 1)) -> SymPlan:
     """The plan of a shape, computed on the host without a device (csrc/mapn_sym_plan.cpp)."""
     lib = load_library()
     info = _lib.SymPlanInfo()
     t1 = parts if taper1 is None else taper1
     xw = C.byref((C.c_uint32 * 8)(*[int(x) for x in xcd_weights])) if xcd_weights is not None else None
-    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, xw, launch_blocks, C.byref(info), None, None, 0)
+    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, int(wave_bias[0]), int(wave_bias[1]), xw, launch_blocks, C.byref(info), None, None, 0)
     if rc:
         raise MapnError(rc, info.error.decode(errors="replace"))
     win = np.zeros((info.windows, 4), np.uint32)
     tab = np.zeros(info.windows * info.table_stride, np.uint32)
     u32p = C.POINTER(C.c_uint32)
-    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, xw, launch_blocks, C.byref(info), win.ctypes.data_as(u32p), tab.ctypes.data_as(u32p), tab.size)
+    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, int(wave_bias[0]), int(wave_bias[1]), xw, launch_blocks, C.byref(info), win.ctypes.data_as(u32p), tab.ctypes.data_as(u32p), tab.size)
     if rc:
         raise MapnError(rc, info.error.decode(errors="replace"))
     return SymPlan(info, win, tab)

@@ -83,7 +83,7 @@ struct mapn_ctx {
     bool sym_ready = false;                   // plan built, scratch allocated, tables uploaded
     bool sym_sharded = false;                 // ... for the sharded form (this rank's blocks) rather than the whole job
     bool sym_user_plan = false;               // mapn_set_sym_plan: keep the shape on re-preparation
-    uint32_t sym_user[5] = {0, 0, 0, 0, 0};   // waves, parts, taper1, taper2, groups per window
+    uint32_t sym_user[7] = {0, 0, 0, 0, 0, 0, 0};   // waves, parts, taper1, taper2, groups per window, wave bias (first half : second half)
     bool sym_xcd_weighted = false;            // mapn_set_sym_xcd_weights: parts spread over the dies, sized by their speed
     uint32_t sym_xcd_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool calibrating = false;                 // mapn_calibrate_sym_xcds: stamped launches record the per-wave timeline without MAPN_STAMP_DUMP
@@ -239,7 +239,8 @@ int check_async_errors(mapn_ctx *c)
     const uint32_t cons = reinterpret_cast<volatile uint32_t *>(c->async_status)[1];
     if (p2p >= 0x100u)
         return fail(MAPN_ERR_COMM, "sharded symmetric step: a reaction row read after its sender's counter did not carry this exchange's number "
-                    "(sender %u places behind this rank on the ring): the counter overtook the data", p2p - 0x100u);
+                    "(sender %u places behind this rank on the ring): either that sender went on after a timed-out wait of its own "
+                    "(it reports the timeout) and overwrote the row, or its counter overtook its data", p2p - 0x100u);
     if (p2p)
         return fail(MAPN_ERR_COMM, "peer-to-peer exchange: the wait for rank %u's slice timed out (%.0f ms); "
                     "this rank's position replica is stale from that step on", p2p - 1u, c->p2p_timeout_ticks / 1e5);
@@ -389,33 +390,52 @@ int prepare_sym(mapn_ctx *c, bool sharded)
     // (65 536 .. 131 072 bodies, one window): parts that TAPER 4 : 2 : 1 so that the workgroups dispatched last are a
     // quarter of the first ones' size (+1.1 % at 65 536, +3.6 % at 100 000).  Sharded: one resident round -- about 512
     // workgroups, at least 32 per block.
+    // A launch of ONE resident round (sharded, up to 256 workgroups of 8 waves): 8-wave workgroups whose first four waves -- the
+    // older wave of every SIMD, which the SIMD issues first -- carry 3 (2) times the steps of the last four, so that the two
+    // waves of a SIMD finish together (build_sym_plan; rank 0 of 65 536 / 8: force launch 83.7 against 87.9 us).
     uint32_t waves = 4, parts = sharded ? std::max(32u, (512u + nbl - 1u) / nbl) : std::min(32u, std::max(1u, (8192u + nb - 1u) / nb));
-    struct Shape { uint32_t parts, t1, t2; };
+    struct Shape { uint32_t parts, t1, t2, waves, hi, lo; };
     std::vector<Shape> tries;
     {
-        unsigned ew = 0, ep = 0, tp = 0, t1 = 0, t2 = 0, eg = 0;
+        unsigned ew = 0, ep = 0, tp = 0, t1 = 0, t2 = 0, eg = 0, bh = 1, bl = 1;
         const char *pl = getenv(sharded ? "MAPN_SYM_SHARD_PLAN" : "MAPN_SYM_PLAN");     // "waves,parts" tuning override
         if (pl && sscanf(pl, "%u,%u", &ew, &ep) == 2 && (ew == 4 || ew == 8) && ep >= 1) { waves = ew; parts = ep; }
+        const char *wb = getenv(sharded ? "MAPN_SYM_SHARD_WAVE_BIAS" : "MAPN_SYM_WAVE_BIAS");   // "hi,lo": first half : second half of a workgroup's waves
+        const bool bias_env = wb && sscanf(wb, "%u,%u", &bh, &bl) == 2 && bh >= 1 && bl >= 1;
+        if (!bias_env) bh = bl = 1;
         const char *tw = getenv("MAPN_SYM_WINDOW");                                    // groups per window (unsharded)
         if (tw && !sharded && sscanf(tw, "%u", &eg) == 1 && eg >= 1) gpw = eg >= gsym ? 0u : eg;
         const char *t = getenv(sharded ? "MAPN_SYM_SHARD_TAPER" : "MAPN_SYM_TAPER");     // "parts,taper1,taper2"; "0" = equal parts
         if (c->sym_user_plan) {
             waves = c->sym_user[0]; parts = c->sym_user[1];
-            tries.push_back({parts, c->sym_user[2] + c->sym_user[3] ? c->sym_user[2] : parts, c->sym_user[3]});
+            tries.push_back({parts, c->sym_user[2] + c->sym_user[3] ? c->sym_user[2] : parts, c->sym_user[3], waves, c->sym_user[5], c->sym_user[6]});
             if (!sharded && c->sym_user[4]) gpw = c->sym_user[4] >= gsym ? 0u : c->sym_user[4];
         } else if (t && sscanf(t, "%u,%u,%u", &tp, &t1, &t2) == 3 && tp >= 1 && t1 + t2 <= tp) {
-            tries.push_back({tp, t1, t2});
-        } else if (!(t && t[0] == '0') && !pl && !sharded && gpw == 0 && nb >= 64u && nb <= 128u) {
-            tries.push_back({40, 28, 4}); tries.push_back({38, 28, 4}); tries.push_back({36, 28, 4});
-            tries.push_back({36, 28, 8});                  // (XCD-weighted parts shrink the slow dies' shares: no part of one unit then)
+            tries.push_back({tp, t1, t2, waves, bh, bl});
+        } else if (!(t && t[0] == '0') && !pl && !bias_env && !sharded) {
+            // biased 8-wave workgroups (one per compute unit) where the launch's workgroups fill whole rounds of the device
+            const uint32_t cus = c->cus > 0 ? (uint32_t)c->cus : 256u;
+            for (uint32_t q : {4u, 8u, 5u, 6u, 7u, 3u, 2u, 10u, 12u, 13u, 16u}) {
+                const uint64_t wg = (uint64_t)nb * q, rounds = (wg + cus - 1u) / cus;
+                if (wg < cus || (rounds < 16u && wg * 50u < rounds * cus * 49u)) continue;      // (the last round at least 98 % full)
+                tries.push_back({q, q, 0, 8, 10, 3}); tries.push_back({q, q, 0, 8, 3, 1});
+                break;
+            }
+            if (gpw == 0 && nb >= 64u && nb <= 128u) {
+                tries.push_back({40, 28, 4, 4, 1, 1}); tries.push_back({38, 28, 4, 4, 1, 1}); tries.push_back({36, 28, 4, 4, 1, 1});
+                tries.push_back({36, 28, 8, 4, 1, 1});     // (XCD-weighted parts shrink the slow dies' shares: no part of one unit then)
+            }
+        } else if (sharded && !pl && !bias_env) {
+            const uint32_t p8 = std::max(16u, (256u + nbl - 1u) / nbl);
+            tries.push_back({p8, p8, 0, 8, 10, 3}); tries.push_back({p8, p8, 0, 8, 3, 1}); tries.push_back({p8, p8, 0, 8, 2, 1});
         }
         if (!c->sym_user_plan)
-            for (uint32_t q = parts; q >= 1u; q = q > 1u ? q / 2u : 0u) tries.push_back({q, q, 0});   // equal parts, halved until every wave has 64 steps
+            for (uint32_t q = parts; q >= 1u; q = q > 1u ? q / 2u : 0u) tries.push_back({q, q, 0, waves, bh, bl});   // equal parts, halved until every wave has 64 steps
     }
     std::string err;
     bool built = false;
     for (const Shape &sh : tries)
-        if ((built = mapn::build_sym_plan(nb, gpw, sh.parts, sh.t1, sh.t2, waves, c->sym_xcd_weighted ? c->sym_xcd_w : nullptr, nbl, c->sym_plan, err))) break;
+        if ((built = mapn::build_sym_plan(nb, gpw, sh.parts, sh.t1, sh.t2, sh.waves, sh.hi, sh.lo, c->sym_xcd_weighted ? c->sym_xcd_w : nullptr, nbl, c->sym_plan, err))) break;
     if (!built) {
         c->sym_note = err;
         return must ? fail(MAPN_ERR_INVALID_ARGUMENT, "%s", err.c_str()) : MAPN_OK;
@@ -462,7 +482,10 @@ bool sym_eligible(const mapn_ctx *c, uint32_t active)
 {
     if (!c->sym_ready || c->sym_sharded || c->plan_forced) return false;
     if (c->comm || c->external_gather || c->p2p_ready) return false;   // a context wired for an exchange runs the sharded step
-    return active == c->n;
+    // Some bodies frozen (num_active < N): they still exert force, so the force launches are the same and only the reduce launch
+    // stops early.  The one-sided kernel evaluates active x N ordered pairs at 4.9e12 / s, this one always N x N at 7e12 / s:
+    // it stays the faster one down to about 0.7 N active bodies.
+    return active > 0 && (uint64_t)active * 4u >= (uint64_t)c->n * 3u;
 }
 
 // MAPN_STAMP_DUMP=<file> (development tool): a stamped diagnostic launch of the symmetric kernel also records, per wave,
@@ -504,7 +527,7 @@ mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t win
     a.pos_old = base.pos_old; a.vel_old = base.vel_old; a.pos_new = base.pos_new; a.vel_new = base.vel_new;
     a.arow = c->sym_arow; a.brow = c->sym_brow; a.brow1 = c->sym_brow1;
     a.tab = c->sym_tab + window * pl.table_stride;
-    a.n = c->n; a.nb = pl.nb; a.parts = pl.parts; a.nwaves = pl.nwaves; a.max_meetings = pl.max_meetings; a.sets = pl.sets;
+    a.n = c->n; a.n_integrate = c->n; a.nb = pl.nb; a.parts = pl.parts; a.nwaves = pl.nwaves; a.max_meetings = pl.max_meetings; a.sets = pl.sets;
     a.g0 = pl.windows[window].g0; a.g1 = pl.windows[window].g1;
     a.brows = pl.brows; a.half_d = pl.half;
     a.mass = base.mass; a.soft2 = base.soft2; a.dt = base.dt; a.damping = base.damping;
@@ -512,6 +535,7 @@ mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t win
     // same box, rank 0 of 65 536 / 8: force launch 92.7 against 95.9 us; 65 536 unsharded 0.3 % faster (MAPN_SYM_ROW_WT=0: A/B)
     static const uint32_t wt = [] { const char *e = getenv("MAPN_SYM_ROW_WT"); return e ? (uint32_t)atoi(e) : 1u; }();
     a.row_wt = wt;
+    { static const uint32_t sg = [] { const char *e = getenv("MAPN_SYM_STAGGER"); return e ? (uint32_t)atoi(e) : 0u; }(); a.stagger = sg; }
     // the I-block reaches the workgroup's waves through LDS (a quarter of the global loads at launch start): same box, rank 0 of
     // 65 536 / 8: prologue 2.9 against 5.0 us, force launch 89.9 against 92.4 us; 65 536 unsharded 0.45 % faster (MAPN_SYM_STAGE=0: A/B)
     static const uint32_t stage = [] { const char *e = getenv("MAPN_SYM_STAGE"); return e ? (uint32_t)atoi(e) : 1u; }();
@@ -527,6 +551,7 @@ int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     const size_t nwin = pl.windows.size();
     for (size_t k = 0; k < nwin; k++) {
         mapn::SymArgs a = sym_args(c, base, k);
+        a.n_integrate = base.i_count;                      // (unsharded: the active bodies are [0, i_count))
         a.acc_in = k ? c->sym_acc : nullptr;
         a.acc_out = k + 1 < nwin ? c->sym_acc : nullptr;
         if (k == 0) { if (int rc = stamps_prepare(c, (size_t)a.nb * pl.nwaves, a)) return rc; }
@@ -536,7 +561,7 @@ int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     }
     mapn::ForcePlan p{};
     p.kind = mapn::KERNEL_SYM; p.k = 2 * mapn::SYM_K2; p.waves = pl.waves; p.sb = pl.parts; p.nseg = 1; p.epi = mapn::EPI_ROWS;
-    c->last_plan = p; c->last_i_count = c->n; c->last_launches = 2 * (uint32_t)nwin;
+    c->last_plan = p; c->last_i_count = c->n; c->last_launches = 2 * (uint32_t)nwin;   // (the force launches always cover all N bodies)
     return MAPN_OK;
 }
 
@@ -598,6 +623,8 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     }
     h.push = push ? 1u : 0u;
     h.send_row = rank;
+    static const uint32_t rel = [] { const char *e = getenv("MAPN_SYM_SHARD_RELEASE"); return e ? (uint32_t)atoi(e) : 0u; }();   // 1 = a release fence (L2 write-back) before each publication: +22 us per step measured, and the acknowledged write-through stores need none
+    h.release = rel;
     h.flags_mine = c->p2p_flags;
     h.recv_mine = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(c->p2p_flags) + mapn::SYM_RECV_OFFSET);
     h.ticket = c->sym_shard_ticket;
@@ -1847,7 +1874,8 @@ int mapn_set_force_plan(mapn_ctx *c, int kernel, uint32_t bodies_per_lane, uint3
 
 // ---- the symmetric kernel's launch plan (tuning hook + introspection) ---------------------------------------
 
-int mapn_set_sym_plan(mapn_ctx *c, uint32_t waves, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t groups_per_window)
+int mapn_set_sym_plan(mapn_ctx *c, uint32_t waves, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t groups_per_window,
+                      uint32_t wave_bias_hi, uint32_t wave_bias_lo)
 {
     if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
     if (int rc = mapn_wait_idle(c)) return rc;
@@ -1857,10 +1885,12 @@ int mapn_set_sym_plan(mapn_ctx *c, uint32_t waves, uint32_t parts, uint32_t tape
         return fail(MAPN_ERR_STATE, "set_sym_plan: a sharded context runs the symmetric kernel under gather algorithm 4 only");
     if (waves == 0 && parts == 0) c->sym_user_plan = false;            // back to the default shape
     else {
-        if ((waves != 4 && waves != 8) || parts == 0 || taper1 + taper2 > parts)
-            return fail(MAPN_ERR_INVALID_ARGUMENT, "set_sym_plan: waves must be 4 or 8, parts >= 1, taper1 + taper2 <= parts");
+        if (wave_bias_hi == 0u && wave_bias_lo == 0u) wave_bias_hi = wave_bias_lo = 1u;
+        if ((waves != 4 && waves != 8) || parts == 0 || taper1 + taper2 > parts || wave_bias_hi == 0u || wave_bias_lo == 0u || wave_bias_hi > 64u || wave_bias_lo > 64u)
+            return fail(MAPN_ERR_INVALID_ARGUMENT, "set_sym_plan: waves must be 4 or 8, parts >= 1, taper1 + taper2 <= parts, wave bias 1 .. 64 (or 0, 0 = equal)");
         c->sym_user_plan = true;
         c->sym_user[0] = waves; c->sym_user[1] = parts; c->sym_user[2] = taper1; c->sym_user[3] = taper2; c->sym_user[4] = groups_per_window;
+        c->sym_user[5] = wave_bias_hi; c->sym_user[6] = wave_bias_lo;
     }
     drop_graphs(c);
     if (int rc = prepare_sym(c, sharded)) { c->sym_user_plan = false; std::string keep = g_last_error; (void)prepare_sym(c, sharded); g_last_error = keep; return rc; }
@@ -1944,6 +1974,7 @@ int mapn_get_sym_plan(mapn_ctx *c, mapn_sym_plan_info *info, uint32_t *windows, 
     const mapn::SymPlanHost &p = c->sym_plan;
     info->nb = p.nb; info->groups = p.groups; info->windows = (uint32_t)p.windows.size();
     info->parts = p.parts; info->taper1 = p.taper1; info->taper2 = p.taper2; info->waves = p.waves;
+    info->wave_bias[0] = p.bias_hi; info->wave_bias[1] = p.bias_lo;
     info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
     info->sets = p.sets; for (int k = 0; k < 8; k++) info->xcd_weight[k] = p.xcd_weight[k];
     info->a0 = c->sym_sharded ? (uint32_t)c->cfg.rank * (c->count / mapn::SYM_BLOCK) : 0u;

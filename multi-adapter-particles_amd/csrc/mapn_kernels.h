@@ -72,6 +72,7 @@ struct SymArgs {
     float4       *acc_out;    // reduce launch: where this window's running sum goes (null: last window -- integrate)
     const uint32_t *tab;      // this window's tables: bounds[2][nwaves + 1], split[2][max_meetings] (SymPlanHost)
     uint32_t      n, nb;      // bodies, I-blocks of SYM_BLOCK (the last may be padded)
+    uint32_t      n_integrate;// bodies [0, n_integrate) are advanced by the reduce launch (roundup64(num_active)); the rest only exert force
     uint32_t      parts;      // workgroups per I-block (gridDim.y)
     uint32_t      nwaves;     // parts * waves per workgroup
     uint32_t      max_meetings;
@@ -88,6 +89,7 @@ struct SymArgs {
     uint64_t      wait_timeout_ticks;
     uint32_t      wait_need, wait_world, wait_rank, wait_self;   // wait_self: loopback timing only -- the "peers" are this rank
     uint32_t      stage_iblock;   // the workgroup's waves share the I-block's global loads through LDS
+    uint32_t      stagger;    // experiment: waves in odd slots of their SIMD start this many s_sleep(8) later (0 = off)
     uint32_t      row_wt;     // rows are stored write-through (sc1) as they are produced instead of waiting in L2 for the end-of-kernel write-back
     float         mass, soft2, dt, damping;
     unsigned long long *stamps;   // diagnostic launches only (mapn_measure_clock), else null
@@ -124,6 +126,7 @@ struct SymShardArgs {
     uint32_t      phase;                      // 0: the whole exchange in this launch (peer-to-peer); 1: PACK only -- (1), rows stored where recv_peer[]
                                               // points (a local send buffer), no counters; 2: REDUCE only -- (2) and (4) on rows that a
                                               // collective library has delivered into recv_mine (gather algorithm 6)
+    uint32_t      release;                    // 1: a system-scope release fence (buffer_wbl2 + wait) in front of the flags / counters
     uint32_t      send_row;                   // row of the destination's region this rank's reactions go to (its rank; 0 when packing)
     uint32_t      push;                       // 1: the new positions are stored into every peer's buffer here (and the peers' NEXT force launch waits for
                                               // the counter); 0: this launch waits for the peers' counters and pulls their slices

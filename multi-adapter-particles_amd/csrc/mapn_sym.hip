@@ -240,6 +240,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
         (void)wait_counters(p.wait_counters, p.wait_self ? p.wait_rank : lane, need, p.wait_need, p.wait_timeout_ticks, p.wait_status, 1u + lane);
     }
     if (t0 < t1) { meeting(t0 >> 6, jb, d, g); pn = body_j(jb * 64u + ((lane + t0) & 63u)); }
+    if (p.stagger) {
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if (hw & 1u) for (uint32_t i = 0; i < p.stagger; i++) __builtin_amdgcn_s_sleep(8);
+    }
     asm volatile("" :: "v"(pn.x), "v"(pn.y), "v"(pn.z));   // (the first piece's bodies are waited for HERE: see the note in the loop)
     if (p.timeline) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the I-block and the first J-block have arrived
@@ -392,7 +397,7 @@ __device__ __forceinline__ uint32_t sym_group(uint32_t a, uint32_t b, uint32_t n
 __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs p)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= p.n) return;
+    if (i >= p.n_integrate) return;                        // (bodies past num_active exert force but are not advanced: Compute.cpp:1041)
     const uint32_t a = i / SYM_IB, jb = i >> 6;
     float ax = 0.f, ay = 0.f, az = 0.f;
     if (p.acc_in) { const float4 v = p.acc_in[i]; ax = v.x; ay = v.y; az = v.z; }
@@ -583,6 +588,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     own_rows(bid * B + bl, ax, ay, az);
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // buffer_wbl2 sc0 sc1 + wait: the sends have LEFT this GPU's L2 (see the note at sync 2)
     __syncthreads();
     stamp(2);                                              // sends acknowledged, own rows summed
     if (p.phase == 2u) {
@@ -662,6 +668,11 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
 
     // (5) this rank's new slice is in memory once every workgroup's stores are acknowledged: then the counter
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // vmcnt(0) says the write-through stores were accepted by the L2, not that they have reached memory: a counter on another
+    // channel could overtake them (seen once in a soak of 4 processes x 300 steps at 32 768 bodies, caught by the rows' exchange
+    // number).  The release fence -- buffer_wbl2 + wait -- completes only when they have.  With the force rows stored
+    // write-through there is little left in the L2 for it to write back (round 2 measured 10+ us for it when the L2 was full of rows).
+    if (p.release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     __syncthreads();
     stamp(5);                                              // position stores acknowledged
     if (threadIdx.x < 64u) {
@@ -792,7 +803,7 @@ hipError_t launch_sym_shard_exchange(const SymShardArgs &a, uint32_t max_workgro
 
 hipError_t launch_sym_reduce(const SymArgs &a, hipStream_t st)
 {
-    hipLaunchKernelGGL(sym_reduce_integrate_kernel, dim3((a.n + 255u) / 256u), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(sym_reduce_integrate_kernel, dim3((a.n_integrate + 255u) / 256u), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

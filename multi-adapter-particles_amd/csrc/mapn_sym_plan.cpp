@@ -20,11 +20,13 @@ uint32_t units(uint32_t x, uint32_t t1, uint32_t t2)
 }  // namespace
 
 bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t waves,
-                    const uint32_t *xcd_weight, uint32_t launch_blocks, SymPlanHost &out, std::string &err)
+                    uint32_t bias_hi, uint32_t bias_lo, const uint32_t *xcd_weight, uint32_t launch_blocks, SymPlanHost &out, std::string &err)
 {
     char msg[256];
-    if (nb == 0 || parts == 0 || waves == 0 || 64u % waves != 0u || taper1 + taper2 > parts) {
-        snprintf(msg, sizeof msg, "symmetric plan: bad shape nb=%u parts=%u (%u, %u) waves=%u", nb, parts, taper1, taper2, waves);
+    if (bias_hi == 0u && bias_lo == 0u) bias_hi = bias_lo = 1u;
+    if (nb == 0 || parts == 0 || waves == 0 || 64u % waves != 0u || taper1 + taper2 > parts || bias_hi == 0u || bias_lo == 0u || bias_hi > 64u || bias_lo > 64u ||
+        (bias_hi != bias_lo && (waves & 1u))) {
+        snprintf(msg, sizeof msg, "symmetric plan: bad shape nb=%u parts=%u (%u, %u) waves=%u bias %u : %u", nb, parts, taper1, taper2, waves, bias_hi, bias_lo);
         err = msg;
         return false;
     }
@@ -33,6 +35,7 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
     const uint32_t gsym = p.D + (p.half ? 1u : 0u);            // symmetric groups 1 .. gsym
     p.groups = 1u + gsym;
     p.parts = parts; p.taper1 = taper1; p.taper2 = taper2; p.waves = waves; p.nwaves = parts * waves;
+    p.bias_hi = bias_hi; p.bias_lo = bias_lo;
     bool weighted = false;
     if (xcd_weight && (launch_blocks ? launch_blocks : nb) % 8u == 0u) {
         for (int k = 0; k < 8; k++) weighted = weighted || xcd_weight[k] != xcd_weight[0];
@@ -74,13 +77,19 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
                 const uint64_t size = units(s + 1u, taper1, taper2) - units(s, taper1, taper2);
                 return size * (weighted ? p.xcd_weight[(r + 8u * parts - s) & 7u] : 1u);
             };
+            // the first half of a workgroup's waves (the older wave of every SIMD) weighs bias_hi, the second half bias_lo
+            auto wave_units = [&](uint32_t ww) -> uint64_t {               // weight of the waves before wave ww of a workgroup
+                const uint32_t h = waves / 2u;
+                return ww <= h ? (uint64_t)bias_hi * ww : (uint64_t)bias_hi * h + (uint64_t)bias_lo * (ww - h);
+            };
+            const uint64_t wg_units = wave_units(waves);
             uint64_t wtot = 0;
-            for (uint32_t s = 0; s < parts; s++) wtot += part_weight(s) * waves;
+            for (uint32_t s = 0; s < parts; s++) wtot += part_weight(s) * wg_units;
             uint64_t before = 0;                                           // weight of the parts before part s
             for (uint32_t v = 0; v <= p.nwaves; v++) {
                 const uint32_t s = v / waves, ww = v % waves;
-                if (v && ww == 0u) before += part_weight(s - 1u) * waves;
-                const uint64_t num = before + (s < parts ? part_weight(s) * ww : 0u);
+                if (v && ww == 0u) before += part_weight(s - 1u) * wg_units;
+                const uint64_t num = before + (s < parts ? part_weight(s) * wave_units(ww) : 0u);
                 const uint64_t target = ctot * num / wtot;                 // cost that lies before wave v
                 bounds[v] = target <= (uint64_t)SYM_COST_SELF * Ls ? (uint32_t)(target / SYM_COST_SELF)
                                                                    : Ls + (uint32_t)((target - (uint64_t)SYM_COST_SELF * Ls) / SYM_COST_SYM);
@@ -115,19 +124,19 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
 
 // ---- C ABI: the plan as data, without a device (tests, the order-matched oracle) ------------------
 extern "C" int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2,
-                                      uint32_t waves, const uint32_t *xcd_weights, uint32_t launch_blocks, mapn_sym_plan_info *info,
+                                      uint32_t waves, uint32_t wave_bias_hi, uint32_t wave_bias_lo, const uint32_t *xcd_weights, uint32_t launch_blocks, mapn_sym_plan_info *info,
                                       uint32_t *windows, uint32_t *tables, uint64_t tables_capacity)
 {
     if (!info) return MAPN_ERR_INVALID_ARGUMENT;
     mapn::SymPlanHost p;
     std::string err;
-    if (!mapn::build_sym_plan(nb, groups_per_window, parts, taper1, taper2, waves, xcd_weights, launch_blocks, p, err)) {
+    if (!mapn::build_sym_plan(nb, groups_per_window, parts, taper1, taper2, waves, wave_bias_hi, wave_bias_lo, xcd_weights, launch_blocks, p, err)) {
         snprintf(info->error, sizeof info->error, "%s", err.c_str());
         return MAPN_ERR_INVALID_ARGUMENT;
     }
     info->error[0] = 0;
     info->nb = p.nb; info->groups = p.groups; info->windows = (uint32_t)p.windows.size();
-    info->parts = p.parts; info->taper1 = p.taper1; info->taper2 = p.taper2; info->waves = p.waves;
+    info->parts = p.parts; info->taper1 = p.taper1; info->taper2 = p.taper2; info->waves = p.waves; info->wave_bias[0] = p.bias_hi; info->wave_bias[1] = p.bias_lo;
     info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
     info->sets = p.sets; for (int k = 0; k < 8; k++) info->xcd_weight[k] = p.xcd_weight[k];
     info->a0 = 0; info->nbl = 0; info->active_compute_units = 0; info->exchange_workgroups = 0; info->scratch_bytes = 0;

@@ -42,6 +42,7 @@ struct SymPlanHost {
     uint32_t nb = 0, D = 0, half = 0;        // half = nb / 2 when nb is even, else 0
     uint32_t groups = 0;                     // 1 + D (+ 1 when nb is even)
     uint32_t parts = 0, taper1 = 0, taper2 = 0, waves = 0;
+    uint32_t bias_hi = 1, bias_lo = 1;       // share of a workgroup's steps: first half of its waves : second half (1 : 1 = equal waves)
     uint32_t nwaves = 0;                     // parts * waves
     uint32_t brows = 0;                      // reaction-row slots per J-block and window (most symmetric groups in one window)
     uint32_t max_meetings = 0;               // most meetings of a block in one window
@@ -60,7 +61,13 @@ struct SymPlanHost {
 // taper1 = parts: equal parts).  Fails (false + err) when a wave would get fewer than 64 steps.
 // xcd_weight: null or 8 relative speeds (all equal = none); they take effect only when launch_blocks (the blocks ONE launch
 // covers: nb, or a rank's share) is a multiple of 8 -- otherwise the plan is the unweighted one.
+// WAVE BIAS.  A SIMD holds two of this kernel's waves (248 registers each) and issues the OLDER one whenever it can: the younger
+// runs in the gaps.  Measured (rank 0 of 65 536 / 8, every SIMD alike): two waves of 132 steps each -- the older is done after
+// 44 us at its own full speed (22.3 us per 64 steps), the younger, then alone, after 78.  In an 8-wave workgroup the waves
+// 0 .. 3 are the older ones of their SIMDs, so the plan can give them bias_hi : bias_lo of the workgroup's steps -- 3 : 1 lets both
+// finish together (198 + 66 steps: 69 and 73 us).  bias_hi = bias_lo: equal waves (the 4-wave shape: which of two WORKGROUPS
+// of a compute unit is the older one is not known to the host).
 bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t waves,
-                    const uint32_t *xcd_weight, uint32_t launch_blocks, SymPlanHost &out, std::string &err);
+                    uint32_t bias_hi, uint32_t bias_lo, const uint32_t *xcd_weight, uint32_t launch_blocks, SymPlanHost &out, std::string &err);
 
 }  // namespace mapn

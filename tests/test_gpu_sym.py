@@ -73,12 +73,13 @@ def test_symmetric_full_size_subset_momentum_and_reproducibility(oracle, n):
 
 
 @pytest.mark.parametrize("n,shape", [(1024, None), (4096, None), (5000, None), (8192, (4, 4, 0, 0, 1)), (8192, (8, 2, 0, 0, 2)), (65536, None),
-                                     (65536, (4, 16, 0, 0, 8)), (100000, None)])
+                                     (65536, (4, 16, 0, 0, 8)), (100000, None), (65536, (8, 4, 0, 0, 8, (3, 1))), (16384, (8, 2, 0, 0, 4, (2, 1)))])
 def test_symmetric_kernel_against_its_order_matched_oracle(oracle, n, shape):
     """The kernel's summation order and fusion restated on the CPU FROM THE PLAN THE CONTEXT RUNS (mapn_get_sym_plan): waves'
     step ranges, cut meetings, head rows, windows.  What is left between the two is v_rsq_f32 against 1/sqrtf: most bodies
     come out bit-identical, none farther than one ulp of the position (a wrong row, a dropped or doubled step would show
-    at 1e-5 and more).  Ragged N, tapered parts, 8-wave workgroups, several windows."""
+    at 1e-5 and more).  Ragged N, tapered parts, 8-wave workgroups, several windows, biased waves (the older wave of every
+    SIMD carrying three / two times the steps of the younger)."""
     mass = 70000.0 / n
     pos, vel = oracle.initial_state(n, seed=5)
     if n % 2:
@@ -91,6 +92,7 @@ def test_symmetric_kernel_against_its_order_matched_oracle(oracle, n, shape):
         plan = c.sym_plan()
         if shape:
             assert (plan.waves, plan.parts) == shape[:2] and len(plan.windows) > 1
+            assert plan.wave_bias == (shape[5] if len(shape) > 5 else (1, 1))
         draw(c, steps)
         p, v = c.download_state()
     sim = OracleSim(oracle, pos, vel, params=Params(mass=mass), sym_plan=plan)
@@ -199,14 +201,17 @@ def test_symmetric_free_run_matches_golden_and_the_one_sided_kernel(oracle, gold
 
 
 def test_symmetric_context_falls_back_where_the_kernel_does_not_apply(oracle):
-    """num_active < N, or N smaller than one 1024-body block: the step runs the scalar-cache kernel (same results
-    contract); with all bodies active again the symmetric kernel is back."""
+    """Fewer than about 0.75 N active bodies, or N smaller than one 1024-body block: the step runs the scalar-cache kernel
+    (same results contract, incl. the frozen tail in BOTH ping-pong buffers); otherwise the symmetric kernel, whose reduce launch
+    simply stops at roundup64(num_active)."""
     n = 4096
     pos, vel = oracle.initial_state(n, seed=4)
     prm = Params(mass=70000.0 / n)
     sim = OracleSim(oracle, pos, vel, params=prm)
     with mapn.Compute(n, mass=70000.0 / n, seed=4, kernel=mapn.KERNEL_SYMMETRIC) as c:
-        for na, name in ((n, "force_sym_kernel"), (1000, "force_sgpr_kernel"), (n, "force_sym_kernel")):
+        # 3500 of 4096 active: the frozen bodies still exert force, so the symmetric kernel runs (its reduce launch stops early);
+        # 1000 of 4096: the one-sided kernel's active x N pairs are cheaper than N x N / 1.4
+        for na, name in ((n, "force_sym_kernel"), (3500, "force_sym_kernel"), (1000, "force_sgpr_kernel"), (3100, "force_sym_kernel"), (n, "force_sym_kernel")):
             sim.simulate(num_active=na); draw(c, 1, num_active=na)
             assert c.kernel_stats().kernel_name.decode() == name
             for b in (0, 1):

@@ -135,16 +135,41 @@ def test_xcd_weighted_parts_are_sized_by_the_speed_of_the_die_they_run_on():
             assert b[-1] == np.diff(base.bounds(0, cls).astype(np.int64)).sum()
 
 
-@pytest.mark.parametrize("nb,gpw,parts,t1,t2,waves,xw", [sh + (None,) for sh in PLAN_SHAPES[:13]] +
-                         [(8, 0, 8, None, 0, 4, XCD_W), (16, 3, 4, None, 0, 4, XCD_W), (64, 0, 36, 28, 8, 4, XCD_W)])
-def test_force_kernel_writes_exactly_the_rows_the_reduce_kernel_reads(nb, gpw, parts, t1, t2, waves, xw):
+def test_wave_bias_gives_the_older_waves_of_a_workgroup_the_larger_share():
+    """An 8-wave workgroup's waves 0 .. 3 are the older wave of their SIMDs and are issued first (measured); with a wave bias
+    hi : lo they carry hi / lo times the steps of waves 4 .. 7, so that the two waves of a SIMD finish together.  Still one
+    linear run of steps per wave, every wave at least 64 steps; a bias with an odd wave count or outside 1 .. 64 is refused."""
+    import mapn
+    base = mapn.describe_sym_plan(64, 0, 32, None, 0, 8, launch_blocks=8)
+    assert base.wave_bias == (1, 1)
+    plan = mapn.describe_sym_plan(64, 0, 32, None, 0, 8, launch_blocks=8, wave_bias=(3, 1))
+    assert plan.wave_bias == (3, 1) and plan.sets == 2
+    for cls in (0, 1):
+        b = plan.bounds(0, cls).astype(np.int64)
+        assert b[0] == 0 and b[-1] == base.bounds(0, cls)[-1]
+        per = np.diff(b).reshape(32, 8)
+        assert (per >= 64).all()
+        assert np.abs(per[:, :4] - 3 * per[:, 4:].mean()).max() <= 4 and np.ptp(per[:, 4:]) <= 2 and np.ptp(per[:, :4]) <= 2
+        assert np.ptp(per.sum(axis=1)) <= 2                                     # the workgroups still carry equal shares
+    with pytest.raises(mapn.MapnError, match="< 64"):
+        mapn.describe_sym_plan(64, 0, 32, None, 0, 8, wave_bias=(5, 1))        # 1056 steps per workgroup: 44 for the small waves
+    with pytest.raises(mapn.MapnError):
+        mapn.describe_sym_plan(64, 0, 32, None, 0, 8, wave_bias=(65, 1))
+    with pytest.raises(mapn.MapnError):
+        mapn.describe_sym_plan(64, 0, 32, None, 0, 8, wave_bias=(0, 1))
+
+
+@pytest.mark.parametrize("nb,gpw,parts,t1,t2,waves,xw,bias", [sh + (None, (1, 1)) for sh in PLAN_SHAPES[:13]] +
+                         [(8, 0, 8, None, 0, 4, XCD_W, (1, 1)), (16, 3, 4, None, 0, 4, XCD_W, (1, 1)), (64, 0, 36, 28, 8, 4, XCD_W, (1, 1)),
+                          (64, 0, 32, None, 0, 8, None, (3, 1)), (16, 0, 4, None, 0, 8, XCD_W, (2, 1)), (9, 2, 2, None, 0, 8, None, (1, 3))])
+def test_force_kernel_writes_exactly_the_rows_the_reduce_kernel_reads(nb, gpw, parts, t1, t2, waves, xw, bias):
     """force_sym_kernel's bookkeeping replayed from the plan tables: every step of every meeting is run exactly once; a symmetric
     meeting's row is written exactly once (whole, or put together in LDS from two waves of one workgroup, or its first steps when
     it is cut between two workgroups -- then its last steps go to the later workgroup's head row); sym_reduce_integrate_kernel
     reads a meeting's row and, where the split table says so, that very head row -- and nothing else is ever written."""
     import mapn
-    plan = mapn.describe_sym_plan(nb, gpw, parts, t1, t2, waves, xcd_weights=xw)
-    assert plan.sets == (16 if xw else 2)
+    plan = mapn.describe_sym_plan(nb, gpw, parts, t1, t2, waves, xcd_weights=xw, wave_bias=bias)
+    assert plan.sets == (16 if xw else 2) and plan.wave_bias == bias
     D, half = (nb - 1) // 2, (nb // 2 if nb % 2 == 0 else 0)
     for k, w in enumerate(plan.windows):
         g0, g1 = int(w[0]), int(w[1])

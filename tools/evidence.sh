@@ -119,7 +119,9 @@ parity1000)
   python tests/parity_report.py --bodies 65536 --steps 1,10,100,1000 --f64-max-steps 100 --out $O/parity_1000_65536.json > $O/parity_1000.txt 2>&1; tail -30 $O/parity_1000.txt ;;
 soak)
   mode=${1:-sympush}; mkdir -p /tmp/soak
-  for cfg in "2 8192 1500" "4 8192 1500" "8 8192 1500" "8 16384 600" "4 32768 300" "8 65536 120"; do
+  # (jobs whose launches fit the device TOGETHER: several processes time-slice one GPU here, and a force launch that fills it
+  #  while waiting for a peer only moves on when the driver preempts it -- 8 x 65 536 took more than half an hour)
+  for cfg in "2 8192 1500" "4 8192 1500" "8 8192 1500" "8 16384 600" "2 32768 200"; do
     set -- $cfg; Wd=$1; N=$2; S=$3
     for m in p2p $mode; do
       rm -rf /tmp/soak/$m; mkdir -p /tmp/soak/$m; pids=""

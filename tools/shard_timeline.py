@@ -91,6 +91,12 @@ def main():
             blob = c.p2p_export()
             c.p2p_import([blob] * world)
             c.set_gather_algorithm(algo)
+        if os.environ.get("TL_XCD") == "1":                # XCD-aware parts: calibrate on this box, weigh the parts
+            w = c.calibrate_sym_xcds(4)
+            c.set_sym_xcd_weights(w)
+            print(f"# XCD weights {w}")
+        pl = c.sym_plan()
+        print(f"# plan: {pl.waves} waves x {pl.parts} parts, wave bias {pl.wave_bias}, sets {pl.sets}")
         c.set_timers(4)
         for _ in range(200):
             c.Simulate(n, c.GetFenceValue())

@@ -92,6 +92,7 @@ struct mapn_ctx {
     uint32_t *sym_tab = nullptr;              // device copy of sym_plan.tables
     size_t sym_scratch_bytes = 0;
     uint32_t sym_parts = 0, sym_waves = 0;
+    bool p2p_shared_device = false;          // a peer rank runs on THIS GPU (several processes on one device: tests)
     uint32_t sym_exchange_cap = 0;            // workgroups of sym_shard_exchange_kernel the device holds at once
     unsigned long long *stamp_buf = nullptr;  // mapn_measure_clock: per-wave clock stamps of a diagnostic launch
     size_t stamp_waves = 0;
@@ -425,7 +426,9 @@ int prepare_sym(mapn_ctx *c, bool sharded)
                 tries.push_back({40, 28, 4, 4, 1, 1}); tries.push_back({38, 28, 4, 4, 1, 1}); tries.push_back({36, 28, 4, 4, 1, 1});
                 tries.push_back({36, 28, 8, 4, 1, 1});     // (XCD-weighted parts shrink the slow dies' shares: no part of one unit then)
             }
-        } else if (sharded && !pl && !bias_env) {
+        } else if (sharded && !pl && !bias_env && !c->p2p_shared_device) {
+            // (not when several ranks share this GPU: an 8-wave workgroup needs BOTH wave slots of all four SIMDs of a compute
+            //  unit, and cannot be placed on one where a peer's exchange workgroup sits waiting -- for this very launch's rows)
             const uint32_t p8 = std::max(16u, (256u + nbl - 1u) / nbl);
             tries.push_back({p8, p8, 0, 8, 10, 3}); tries.push_back({p8, p8, 0, 8, 3, 1}); tries.push_back({p8, p8, 0, 8, 2, 1});
         }
@@ -1729,12 +1732,20 @@ int mapn_set_gather_algorithm(mapn_ctx *c, int algorithm)
 namespace {
 struct P2PBlob {
     char magic[8];
-    uint32_t rank, world, n, reserved;
+    uint32_t rank, world, n, device_id;       // device_id: PCI domain / bus / device of the exporting rank's GPU (+1), 0 = unknown
     uint64_t aligned_data_size;
     hipIpcMemHandle_t heap, flags;
 };
 static_assert(sizeof(P2PBlob) <= MAPN_P2P_BLOB_BYTES, "MAPN_P2P_BLOB_BYTES too small");
 }  // namespace
+
+// which GPU a rank runs on, so that ranks SHARING one device (tests, a partitioned box) can be told from a real job
+static uint32_t p2p_device_id(int device)
+{
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) { (void)hipGetLastError(); return 0u; }
+    return 1u + (((uint32_t)p.pciDomainID & 0xffu) << 16 | ((uint32_t)p.pciBusID & 0xffu) << 8 | ((uint32_t)p.pciDeviceID & 0xffu));
+}
 
 int mapn_p2p_export(mapn_ctx *c, void *out_blob)
 {
@@ -1756,6 +1767,7 @@ int mapn_p2p_export(mapn_ctx *c, void *out_blob)
     P2PBlob b{};
     memcpy(b.magic, "MAPNP2P1", 8);
     b.rank = (uint32_t)c->cfg.rank; b.world = (uint32_t)c->cfg.world_size; b.n = c->n;
+    b.device_id = p2p_device_id(c->device);
     b.aligned_data_size = c->aligned_data_size;
     HIP_TRY(hipIpcGetMemHandle(&b.heap, c->pos_heap));
     HIP_TRY(hipIpcGetMemHandle(&b.flags, c->p2p_flags));
@@ -1776,7 +1788,9 @@ int mapn_p2p_import(mapn_ctx *c, const void *blobs, int count)
     // all its destinations, reduce); the position pull is skipped and only this rank's own row is waited for --
     // the other slices are never refreshed, so results are not a simulation.
     const char *loop = getenv("MAPN_P2P_LOOPBACK");
-    c->p2p_loopback = loop && loop[0] == '1';
+    // MAPN_P2P_LOOPBACK=2 (tests): the same, but nothing is SENT to the other ranks either (their rows would land on this rank's
+    // own), so this rank's bodies come out exactly as the schedule says: own meetings plus reactions between own blocks.
+    c->p2p_loopback = loop && (loop[0] == '1' || loop[0] == '2');
     for (int q = 0; q < count; q++) {
         if (c->p2p_loopback) { c->p2p_peer_heap[q] = c->pos_heap; c->p2p_peer_flags[q] = c->p2p_flags; continue; }
         P2PBlob b;
@@ -1789,6 +1803,7 @@ int mapn_p2p_import(mapn_ctx *c, const void *blobs, int count)
             c->p2p_peer_flags[q] = c->p2p_flags;
             continue;
         }
+        if (b.device_id && b.device_id == p2p_device_id(c->device)) c->p2p_shared_device = true;
         HIP_TRY(hipIpcOpenMemHandle(&c->p2p_peer_heap[q], b.heap, hipIpcMemLazyEnablePeerAccess));
         HIP_TRY(hipIpcOpenMemHandle(reinterpret_cast<void **>(&c->p2p_peer_flags[q]), b.flags, hipIpcMemLazyEnablePeerAccess));
     }
@@ -1799,6 +1814,7 @@ int mapn_p2p_import(mapn_ctx *c, const void *blobs, int count)
     if (c->count % mapn::SYM_BLOCK == 0 && c->count * (uint32_t)count == c->n)
         sym_shard_masks(c->n / mapn::SYM_BLOCK, (uint32_t)count, (uint32_t)c->cfg.rank, c->sym_send_mask, c->sym_recv_mask);
     if (c->p2p_loopback) c->sym_recv_mask = 1u << c->cfg.rank;
+    if (c->p2p_loopback && loop[0] == '2') c->sym_send_mask &= 1u << c->cfg.rank;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->p2p_flag_table), sizeof(uint32_t *) * mapn::P2P_MAX_RANKS));
     HIP_TRY(hipMemcpy(c->p2p_flag_table, c->p2p_peer_flags, sizeof(uint32_t *) * mapn::P2P_MAX_RANKS, hipMemcpyHostToDevice));
     c->p2p_ready = true;

@@ -200,7 +200,7 @@ def test_default_plans_at_65536_bodies():
         draw(c, 2)
         st = c.kernel_stats()
     assert st.kernel_name.decode() == "force_sym_kernel" and st.epilogue == 3 and st.fused == 0
-    assert (st.grid_x, st.grid_y, st.block_x) == (64, 40, 256)      # 64 I-blocks x 40 tapered parts, dispatched part-major
+    assert (st.grid_x, st.grid_y, st.block_x) == (64, 4, 512)       # 64 I-blocks x 4 parts, 8-wave workgroups (biased waves): one round
 
 
 def test_graph_replay_is_bit_identical_to_eager():

@@ -222,6 +222,60 @@ def test_symmetric_context_falls_back_where_the_kernel_does_not_apply(oracle):
         assert c.kernel_stats().kernel_name.decode() == "force_sgpr_kernel"
 
 
+def _loopback_expectation(pos, vel, nb, nbl, mass, soft2, dt):
+    """What rank 0 of a sharded job computes when no peer ever answers (float64): its blocks meet what the schedule says; its
+    bodies get the forces of those meetings plus the reactions of meetings between two of its own blocks."""
+    from mapn import shard
+    x = pos[:, :3].astype(np.float64)
+    acc = np.zeros((nbl * 1024, 3))
+    for a, b, d, symmetric in shard.sym_meetings(nb):
+        if a >= nbl:
+            continue                                           # a block of another rank: not run here
+        xi, xj = x[a * 1024:(a + 1) * 1024], x[b * 1024:(b + 1) * 1024]
+        r = xj[None, :, :] - xi[:, None, :]
+        f = r * ((r * r).sum(-1) + soft2)[..., None] ** -1.5
+        acc[a * 1024:(a + 1) * 1024] += f.sum(1)
+        if symmetric and b < nbl:
+            acc[b * 1024:(b + 1) * 1024] -= f.sum(0)          # the reaction stays on this rank: through the receive rows
+    vexp = vel[:nbl * 1024].astype(np.float64) + acc * mass * dt
+    return x[:nbl * 1024] + vexp * dt, vexp
+
+
+def test_sharded_symmetric_step_with_biased_waves_one_rank_loopback(oracle, monkeypatch):
+    """Rank 0's share of the 65 536-body job over 8 ranks (the shape DESIGN 5 times), peers mapped to the rank itself
+    (MAPN_P2P_LOOPBACK=2): the launch plan is the biased one -- 8-wave workgroups, one per compute unit, whose first four waves
+    (the older wave of every SIMD) carry three times the steps of the last four -- under the pushed-positions exchange
+    (algorithm 5) and the pulled one (4); both must give rank 0's bodies exactly what the schedule says, bit-identically to
+    each other and to the equal-wave 4-wave plan's result within rounding."""
+    monkeypatch.setenv("MAPN_P2P_LOOPBACK", "2")               # (2: nothing is sent to the other ranks either)
+    n, world = 65536, 8
+    nb, nbl = n // 1024, n // 1024 // world
+    mass = 70000.0 / n
+    pos, vel = oracle.initial_state(n, seed=1)
+    pexp, vexp = _loopback_expectation(pos, vel, nb, nbl, mass, 25.0, 0.1)
+    got = {}
+    for algo, shape in ((5, None), (4, None), (5, (4, 64, 0, 0, 0, (1, 1)))):
+        with mapn.Compute(n, mass=mass, rank=0, world_size=world) as c:
+            blob = c.p2p_export()
+            c.p2p_import([blob] * world)
+            c.set_gather_algorithm(algo)
+            if shape:
+                c.set_sym_plan(*shape)
+            plan = c.sym_plan()
+            assert plan.nbl == nbl and plan.a0 == 0
+            assert (plan.waves, plan.parts, plan.wave_bias) == ((8, 32, (3, 1)) if shape is None else (4, 64, (1, 1)))
+            draw(c, 1)
+            p, v = c.download_state()
+            assert c.kernel_stats().kernel_name.decode() == "force_sym_kernel" and c.p2p_status() == 0
+        own = slice(0, nbl * 1024)
+        assert errs(p[own, :3], pexp, SPREAD)[0] < 1e-6
+        assert errs(v[own], vexp, SPEED)[0] < 2e-5
+        got[(algo, shape is None)] = (p[own].copy(), v[own].copy())
+    np.testing.assert_array_equal(got[(5, True)][0], got[(4, True)][0])          # pushed or pulled positions: the same arithmetic
+    np.testing.assert_array_equal(got[(5, True)][1], got[(4, True)][1])
+    assert errs(got[(5, True)][0][:, :3], got[(5, False)][0][:, :3], SPREAD)[0] < 1e-6
+
+
 def test_rccl_form_of_the_sharded_symmetric_step_one_rank_loopback(oracle, monkeypatch):
     """Gather algorithm 6: pack launch -> one group of ncclSend / ncclRecv -> reduce launch -> ncclAllGather.  RCCL refuses two
     ranks on one device, so what runs here is rank 0 of a 2-rank job on a ONE-rank communicator (MAPN_COMM_LOOPBACK): the pack
@@ -242,20 +296,8 @@ def test_rccl_form_of_the_sharded_symmetric_step_one_rank_loopback(oracle, monke
         draw(c, 1)
         p, v = c.download_state()
         assert c.kernel_stats().kernel_name.decode() == "force_sym_kernel" and c.p2p_status() == 0
-    x = pos[:, :3].astype(np.float64)
-    acc = np.zeros((n, 3))
-    for a, b, d, symmetric in shard.sym_meetings(nb):
-        if a >= nbl:
-            continue                                           # a block of rank 1: not run here
-        xi, xj = x[a * 1024:(a + 1) * 1024], x[b * 1024:(b + 1) * 1024]
-        r = xj[None, :, :] - xi[:, None, :]
-        f = r * ((r * r).sum(-1) + soft2)[..., None] ** -1.5
-        acc[a * 1024:(a + 1) * 1024] += f.sum(1)
-        if symmetric and b < nbl:
-            acc[b * 1024:(b + 1) * 1024] -= f.sum(0)          # the reaction stays on this rank: through the receive rows
+    pexp, vexp = _loopback_expectation(pos, vel, nb, nbl, mass, soft2, dt)
     own = slice(0, nbl * 1024)
-    vexp = vel[own].astype(np.float64) + acc[own] * mass * dt
-    pexp = x[own] + vexp * dt
     assert errs(p[own, :3], pexp, SPREAD)[0] < 1e-6
     assert errs(v[own], vexp, SPEED)[0] < 2e-5
     np.testing.assert_array_equal(p[nbl * 1024:], pos[nbl * 1024:])      # the other rank's slice: untouched

@@ -493,6 +493,14 @@ def main():
     if rank == 0:
         pairs_per_step = float(n) * float(n) if a.mode == "all_pairs" else float(n)
         value = pairs_per_step * a.steps / elapsed
+        sym_plan_desc = None
+        if st.kernel_name.decode() == "force_sym_kernel":
+            try:
+                pl = c.sym_plan()
+                sym_plan_desc = {"waves_per_workgroup": pl.waves, "parts_per_block": pl.parts, "taper": [pl.taper1, pl.taper2],
+                                 "wave_bias_older_to_younger": list(pl.wave_bias), "windows": len(pl.windows), "table_sets": pl.sets}
+            except mapn.MapnError:
+                pass
         out = {
             "metric": "body-pair interactions/s" if a.mode == "all_pairs" else "bodies/s",
             "value": value,
@@ -516,7 +524,7 @@ def main():
                        "step_ms_by_quarter_of_the_timed_region": quarters, "step_ms_spread": spread if quarters else None,
                        "step_ms_note": "device time (HIP events on the compute stream) of the steps of the timed region that carried events; ms_per_step is the wall clock over all of them",
                        "p2p_failure": p2p_failure, "sharded_symmetric_deviation_after_run": sym_dev_after,
-                       "xcd_aware_parts": xcd},
+                       "xcd_aware_parts": xcd, "symmetric_plan": sym_plan_desc},
         }
         if a.mode == "all_pairs":
             peak = info.peak_fp32_flops / 1e12

@@ -89,7 +89,6 @@ struct SymArgs {
     uint64_t      wait_timeout_ticks;
     uint32_t      wait_need, wait_world, wait_rank, wait_self;   // wait_self: loopback timing only -- the "peers" are this rank
     uint32_t      stage_iblock;   // the workgroup's waves share the I-block's global loads through LDS
-    uint32_t      stagger;    // experiment: waves in odd slots of their SIMD start this many s_sleep(8) later (0 = off)
     uint32_t      row_wt;     // rows are stored write-through (sc1) as they are produced instead of waiting in L2 for the end-of-kernel write-back
     float         mass, soft2, dt, damping;
     unsigned long long *stamps;   // diagnostic launches only (mapn_measure_clock), else null

@@ -240,11 +240,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
         (void)wait_counters(p.wait_counters, p.wait_self ? p.wait_rank : lane, need, p.wait_need, p.wait_timeout_ticks, p.wait_status, 1u + lane);
     }
     if (t0 < t1) { meeting(t0 >> 6, jb, d, g); pn = body_j(jb * 64u + ((lane + t0) & 63u)); }
-    if (p.stagger) {
-        uint32_t hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        if (hw & 1u) for (uint32_t i = 0; i < p.stagger; i++) __builtin_amdgcn_s_sleep(8);
-    }
     asm volatile("" :: "v"(pn.x), "v"(pn.y), "v"(pn.z));   // (the first piece's bodies are waited for HERE: see the note in the loop)
     if (p.timeline) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the I-block and the first J-block have arrived

@@ -36,6 +36,7 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
     p.groups = 1u + gsym;
     p.parts = parts; p.taper1 = taper1; p.taper2 = taper2; p.waves = waves; p.nwaves = parts * waves;
     p.bias_hi = bias_hi; p.bias_lo = bias_lo;
+    const uint32_t min_steps = 64u;          // (fewer is no gain: the younger wave of a SIMD ends right after the older one whatever its share, measured 66 .. 58 steps)
     bool weighted = false;
     if (xcd_weight && (launch_blocks ? launch_blocks : nb) % 8u == 0u) {
         for (int k = 0; k < 8; k++) weighted = weighted || xcd_weight[k] != xcd_weight[0];
@@ -96,9 +97,9 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
             }
             if (bounds[0] != 0u || bounds[p.nwaves] != L) { err = "symmetric plan: internal error (bounds do not span the meetings)"; return false; }
             for (uint32_t v = 0; v < p.nwaves && L; v++) {
-                if (bounds[v + 1u] - bounds[v] < 64u) {
-                    snprintf(msg, sizeof msg, "symmetric plan: wave %u of window %u would run %u steps (< 64): %u meetings are too few for %u x %u waves (taper %u, %u)",
-                             v, k, bounds[v + 1u] - bounds[v], M, parts, waves, taper1, taper2);
+                if (bounds[v + 1u] - bounds[v] < min_steps) {
+                    snprintf(msg, sizeof msg, "symmetric plan: wave %u of window %u would run %u steps (< %u): %u meetings are too few for %u x %u waves (taper %u, %u)",
+                             v, k, bounds[v + 1u] - bounds[v], min_steps, M, parts, waves, taper1, taper2);
                     err = msg;
                     return false;
                 }
@@ -110,7 +111,11 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
                 while (bounds[v + 1u] <= 64u * m) v++;                      // wave holding step 64 m
                 uint32_t vb = v;
                 while (bounds[vb + 1u] <= 64u * m + 63u) vb++;              // wave holding step 64 m + 63
-                if (vb > v + 1u) { err = "symmetric plan: internal error (a meeting cut twice)"; return false; }
+                if (vb > v + 1u) {
+                    snprintf(msg, sizeof msg, "symmetric plan: meeting %u of window %u would be cut twice (wave %u runs %u steps inside it)", m, k, v + 1u, bounds[v + 2u] - bounds[v + 1u]);
+                    err = msg;
+                    return false;
+                }
                 const bool symmetric = w.g0 + m / JPI >= 1u;
                 if (symmetric && vb != v && vb / waves != v / waves) split[m] = vb / waves;
             }

@@ -34,7 +34,7 @@ def test_committed_pmc_summaries_belong_to_the_current_kernel_sources():
         d = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json")))
         assert d["_kernel_source_sha16"] == sha, f"profiles/{tag}_pmc_summary.json is stale: re-run tools/evidence.sh pmc"
     traffic, src = bench.pmc_traffic("force_sym_kernel", 65536, 1)
-    assert traffic and 5e7 < traffic < 2e8 and src.endswith("r03_sym_pmc_summary.json")
+    assert traffic and 3e7 < traffic < 2e8 and src.endswith("r03_sym_pmc_summary.json")     # rows: N^2 / 128 + 16 N x parts bytes, + the positions
 
 
 @pytest.mark.gpu

@@ -401,6 +401,12 @@ int mapn_set_force_plan(mapn_ctx *ctx, int kernel, uint32_t bodies_per_lane, uin
  * mapn_get_sym_plan returns the plan a context runs (a0 / nbl: first block and block count of this rank when sharded);
  * mapn_set_sym_plan is the tuning hook (waves 4 or 8; taper1 = taper2 = 0: equal parts; groups_per_window 0: as many
  * as fit; waves = parts = 0: back to the default shape) -- it re-allocates the scratch, never call it per step.
+ * WAVE BIAS (wave_bias_hi : wave_bias_lo; 0 : 0 or equal = none).  A SIMD holds two of this kernel's waves and serves the older
+ * one first; in an 8-wave workgroup (one per compute unit) waves 0 .. 3 are the older wave of their SIMDs, and the plan gives
+ * them hi / lo times the steps of waves 4 .. 7 so that both end together (measured optimum about 10 : 3).  The defaults: 8-wave
+ * workgroups with 10 : 3 where a launch's workgroups fill whole rounds of the compute units, 3 : 1 for a sharded launch; the
+ * equal-wave 4-wave shape otherwise and whenever several ranks share one device.  Still one linear run of steps per wave, so
+ * everything above holds unchanged.
  */
 typedef struct mapn_sym_plan_info {
     uint32_t nb, groups, windows;

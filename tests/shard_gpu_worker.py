@@ -60,6 +60,10 @@ def main():
         # owners' receive regions, positions pulled as in "p2p"
         # "sympush" = the same with the new positions PUSHED into the peers' replicas by the exchange launch (gather algorithm 5)
         c.set_gather_algorithm({"p2p": 2, "flow": 3, "sym": 4, "sympush": 5}[mode])
+        if mode in ("sym", "sympush") and count % 1024 == 0 and not os.environ.get("MAPN_SYM_SHARD_PLAN"):
+            # the ranks share ONE device here (mapn_p2p_import compares their PCI ids): the plan must be the 4-wave one -- an
+            # 8-wave workgroup needs a whole compute unit's registers and cannot be placed beside a peer's waiting exchange launch
+            assert c.sym_plan().waves == 4 and c.sym_plan().wave_bias == (1, 1), (c.sym_plan().waves, c.sym_plan().wave_bias)
         if os.environ.get("MAPN_WORKER_XCD_W") and mode in ("sym", "sympush"):
             c.set_sym_xcd_weights([int(x) for x in os.environ["MAPN_WORKER_XCD_W"].split(",")])
             assert c.sym_plan().sets == (16 if (count // 1024) % 8 == 0 else 2)

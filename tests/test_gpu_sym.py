@@ -281,12 +281,15 @@ def test_sharded_symmetric_step_with_biased_waves_one_rank_loopback(oracle, monk
             draw(c, 1)
             p, v = c.download_state()
             assert c.kernel_stats().kernel_name.decode() == "force_sym_kernel" and c.p2p_status() == 0
+            draw(c, 300)                                       # and a long run: counters, tags and tickets over many exchanges
+            p300, v300 = c.download_state()
+            assert c.p2p_status() == 0 and np.isfinite(p300).all()
         own = slice(0, nbl * 1024)
         assert errs(p[own, :3], pexp, SPREAD)[0] < 1e-6
         assert errs(v[own], vexp, SPEED)[0] < 2e-5
-        got[(algo, shape is None)] = (p[own].copy(), v[own].copy())
-    np.testing.assert_array_equal(got[(5, True)][0], got[(4, True)][0])          # pushed or pulled positions: the same arithmetic
-    np.testing.assert_array_equal(got[(5, True)][1], got[(4, True)][1])
+        got[(algo, shape is None)] = (p[own].copy(), v[own].copy(), p300[own].copy(), v300[own].copy())
+    for k in range(4):
+        np.testing.assert_array_equal(got[(5, True)][k], got[(4, True)][k])      # pushed or pulled positions: the same arithmetic, 1 and 301 steps
     assert errs(got[(5, True)][0][:, :3], got[(5, False)][0][:, :3], SPREAD)[0] < 1e-6
 
 

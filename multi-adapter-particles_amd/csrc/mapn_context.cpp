@@ -1897,7 +1897,7 @@ int mapn_set_sym_plan(mapn_ctx *c, uint32_t waves, uint32_t parts, uint32_t tape
     HIP_TRY(hipSetDevice(c->device));
     const bool sharded = c->cfg.world_size > 1;
     if (sharded && !((c->p2p_ready && (c->gather_algo == 4 || c->gather_algo == 5)) || (c->comm && c->gather_algo == 6)))
-        return fail(MAPN_ERR_STATE, "set_sym_plan: a sharded context runs the symmetric kernel under gather algorithm 4 only");
+        return fail(MAPN_ERR_STATE, "set_sym_plan: a sharded context runs the symmetric kernel under gather algorithms 4, 5 and 6 only (set one first)");
     if (waves == 0 && parts == 0) c->sym_user_plan = false;            // back to the default shape
     else {
         if (wave_bias_hi == 0u && wave_bias_lo == 0u) wave_bias_hi = wave_bias_lo = 1u;

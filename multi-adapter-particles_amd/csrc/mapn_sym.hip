@@ -184,31 +184,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     auto body = [&](uint32_t i) { return i < p.n ? pos[i] : far; };
     // a travelling body: under gather algorithm 5 it may lie in a slice a PEER stored into this rank's buffer
     auto body_j = [&](uint32_t i) { return i >= p.n ? far : p.wait_counters ? load_sys(pos + i) : pos[i]; };
-    SymBodies b;
-    if (p.stage_iblock) {
-        // the workgroup's waves all hold the SAME I-block: each fetches 16 / WAVES of its 16 lane-slices, the slices meet in LDS
-        // (the space the closing combination uses) and every wave takes all 16 from there -- a quarter of the global loads in
-        // the moment when every wave of the launch starts at once
-        float4 *stage = reinterpret_cast<float4 *>(&comb[0][0][0]);
-        constexpr uint32_t PER = 2u * SYM_K2 / WAVES;
-#pragma unroll
-        for (uint32_t c = 0; c < PER; c++) stage[(w * PER + c) * 64u + lane] = body(a * SYM_IB + (w * PER + c) * 64u + lane);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < SYM_K2; k++) {
-            const float4 b0 = stage[(2 * k) * 64u + lane], b1 = stage[(2 * k + 1) * 64u + lane];
-            b.xi[k] = v2f{b0.x, b1.x}; b.yi[k] = v2f{b0.y, b1.y}; b.zi[k] = v2f{b0.z, b1.z};
-            b.ax[k] = v2f{0.f, 0.f}; b.ay[k] = v2f{0.f, 0.f}; b.az[k] = v2f{0.f, 0.f};
-        }
-        __syncthreads();                                   // (the space is written again only by the closing combination)
-    } else {
-#pragma unroll
-        for (int k = 0; k < SYM_K2; k++) {
-            const float4 b0 = body(a * SYM_IB + (2 * k) * 64u + lane), b1 = body(a * SYM_IB + (2 * k + 1) * 64u + lane);
-            b.xi[k] = v2f{b0.x, b1.x}; b.yi[k] = v2f{b0.y, b1.y}; b.zi[k] = v2f{b0.z, b1.z};
-            b.ax[k] = v2f{0.f, 0.f}; b.ay[k] = v2f{0.f, 0.f}; b.az[k] = v2f{0.f, 0.f};
-        }
-    }
     const v2f soft2 = v2f{p.soft2, p.soft2};
     const int next = (int)((lane + 1u) & 63u) * 4;         // ds_bpermute: take the value of lane + 1
 
@@ -230,16 +205,52 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     if (p.stamps) asm volatile("s_memrealtime %0\n s_memtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(st_r), "=s"(st_c));
     uint32_t jb = 0, d = 0, g = 0;
     float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);
-    // the first piece may start inside a meeting (k0 = t0 % 64 steps of it ran in the previous wave): the lane then
+    // The wave's start is a chain of memory round trips (~1 us each); they are issued so that they overlap: the I-block's
+    // loads go out first, the wait for the peers' counters (gather algorithm 5) polls while they are in flight, the first
+    // J-block is requested as soon as the counters allow, and only then are the I-block's slices taken through LDS
+    // (entry -> first step 2.6 us when these ran one after the other).
+    // The first piece may start inside a meeting (k0 = t0 % 64 steps of it ran in the previous wave): the lane then
     // starts with body (lane + k0) % 64; every later piece starts a meeting.  The NEXT piece's bodies are fetched
     // while the current one is computed (a meeting is ~9 us of a wave's life, a global load ~1-2 us).
-    if (p.wait_counters) {
-        // (the I-block above is this rank's own slice; everything else waits for the peers' pushes -- the counters have
-        //  normally been there since before this launch started)
-        const bool need = lane < p.wait_world && lane != p.wait_rank;
-        (void)wait_counters(p.wait_counters, p.wait_self ? p.wait_rank : lane, need, p.wait_need, p.wait_timeout_ticks, p.wait_status, 1u + lane);
+    auto first_piece = [&]() {
+        if (p.wait_counters) {
+            // (the I-block is this rank's own slice; everything else waits for the peers' pushes -- the counters have
+            //  normally been there since before this launch started)
+            const bool need = lane < p.wait_world && lane != p.wait_rank;
+            (void)wait_counters(p.wait_counters, p.wait_self ? p.wait_rank : lane, need, p.wait_need, p.wait_timeout_ticks, p.wait_status, 1u + lane);
+        }
+        if (t0 < t1) { meeting(t0 >> 6, jb, d, g); pn = body_j(jb * 64u + ((lane + t0) & 63u)); }
+    };
+    SymBodies b;
+    if (p.stage_iblock) {
+        // the workgroup's waves all hold the SAME I-block: each fetches 16 / WAVES of its 16 lane-slices, the slices meet in LDS
+        // (the space the closing combination uses) and every wave takes all 16 from there -- a quarter of the global loads in
+        // the moment when every wave of the launch starts at once
+        float4 *stage = reinterpret_cast<float4 *>(&comb[0][0][0]);
+        constexpr uint32_t PER = 2u * SYM_K2 / WAVES;
+        float4 mine[PER];
+#pragma unroll
+        for (uint32_t c = 0; c < PER; c++) mine[c] = body(a * SYM_IB + (w * PER + c) * 64u + lane);
+        first_piece();
+#pragma unroll
+        for (uint32_t c = 0; c < PER; c++) stage[(w * PER + c) * 64u + lane] = mine[c];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SYM_K2; k++) {
+            const float4 b0 = stage[(2 * k) * 64u + lane], b1 = stage[(2 * k + 1) * 64u + lane];
+            b.xi[k] = v2f{b0.x, b1.x}; b.yi[k] = v2f{b0.y, b1.y}; b.zi[k] = v2f{b0.z, b1.z};
+            b.ax[k] = v2f{0.f, 0.f}; b.ay[k] = v2f{0.f, 0.f}; b.az[k] = v2f{0.f, 0.f};
+        }
+        __syncthreads();                                   // (the space is written again only by the closing combination)
+    } else {
+#pragma unroll
+        for (int k = 0; k < SYM_K2; k++) {
+            const float4 b0 = body(a * SYM_IB + (2 * k) * 64u + lane), b1 = body(a * SYM_IB + (2 * k + 1) * 64u + lane);
+            b.xi[k] = v2f{b0.x, b1.x}; b.yi[k] = v2f{b0.y, b1.y}; b.zi[k] = v2f{b0.z, b1.z};
+            b.ax[k] = v2f{0.f, 0.f}; b.ay[k] = v2f{0.f, 0.f}; b.az[k] = v2f{0.f, 0.f};
+        }
+        first_piece();
     }
-    if (t0 < t1) { meeting(t0 >> 6, jb, d, g); pn = body_j(jb * 64u + ((lane + t0) & 63u)); }
     asm volatile("" :: "v"(pn.x), "v"(pn.y), "v"(pn.z));   // (the first piece's bodies are waited for HERE: see the note in the loop)
     if (p.timeline) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the I-block and the first J-block have arrived

@@ -78,7 +78,7 @@ import mapn
 n, world, algo, rank = (int(x) for x in sys.argv[1:5])
 with mapn.Compute(n, device=0, mass=70000.0 / n, rank=rank, world_size=world) as c:
     blob = c.p2p_export(); c.p2p_import([blob] * world); c.set_gather_algorithm(algo); c.set_timers(0)
-    for _ in range(300):
+    for _ in range(2000):                  # 0.2 s: the clock has settled by the second half, which is what is analysed
         c.Simulate(n, c.GetFenceValue())
     c.WaitForGpu()
 PY
@@ -88,8 +88,8 @@ PY
   cd $R; python - "$O" $n $world <<'PY' | tee $O/shard_step_timeline.txt
 import csv, glob, collections, sys
 O, n, world = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-print(f"# kernel trace (rocprofv3 --kernel-trace) of one rank's step at {n} / {world} in loopback (every peer mapped to the rank itself), second half of 300 steps:")
-print("# mean durations, gaps, step period.  Algorithm 5: the exchange launch pushes the new positions; 4: it pulls them; 2: one-sided kernel, separate pull launch (skipped in loopback)")
+print(f"# kernel trace (rocprofv3 --kernel-trace) of one rank's step at {n} / {world} in loopback (every peer mapped to the rank itself), second half of 2000 steps:")
+print("# MEDIAN (mean) durations and gaps; step period = median distance between two force launches' starts.  Algorithm 5: the exchange launch pushes the new positions; 4: it pulls them; 2: one-sided kernel, separate pull launch (skipped in loopback)")
 for algo in (5, 4, 2):
     for rank in (0, world // 2):
         f = glob.glob(f"{O}/trace_{algo}_{rank}/**/*kernel_trace.csv", recursive=True)
@@ -102,10 +102,13 @@ for algo in (5, 4, 2):
             dur[k].append(int(a["End_Timestamp"]) - int(a["Start_Timestamp"]))
             gap[k + " -> next"].append(int(b["Start_Timestamp"]) - int(a["End_Timestamp"]))
         print(f"== gather algorithm {algo}, rank {rank}")
-        for k, v in dur.items(): print("  %-48s %7.2f us  (x%d)" % (k, sum(v) / len(v) / 1e3, len(v)))
-        for k, v in gap.items(): print("  gap %-44s %7.2f us" % (k, sum(v) / len(v) / 1e3))
-        per = collections.Counter(r["Kernel_Name"] for r in rows).most_common(1)[0][1]
-        print("  step period %.2f us" % ((int(rows[-1]["Start_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / per / 1e3))
+        med = lambda v: sorted(v)[len(v) // 2]
+        for k, v in dur.items(): print("  %-48s %7.2f us  (mean %.2f, x%d)" % (k, med(v) / 1e3, sum(v) / len(v) / 1e3, len(v)))
+        for k, v in gap.items(): print("  gap %-44s %7.2f us  (mean %.2f)" % (k, med(v) / 1e3, sum(v) / len(v) / 1e3))
+        top = collections.Counter(r["Kernel_Name"] for r in rows if "force" in r["Kernel_Name"]).most_common(1)[0][0]
+        starts = [int(r["Start_Timestamp"]) for r in rows if r["Kernel_Name"] == top]
+        d = [b - a for a, b in zip(starts, starts[1:])]
+        print("  step period %.2f us  (mean %.2f)" % (med(d) / 1e3, sum(d) / len(d) / 1e3))
 PY
   ;;
 loopback)

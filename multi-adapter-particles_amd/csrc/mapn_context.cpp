@@ -630,6 +630,9 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     h.flags_mine = c->p2p_flags;
     h.recv_mine = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(c->p2p_flags) + mapn::SYM_RECV_OFFSET);
     h.ticket = c->sym_shard_ticket;
+    // arrival flags per (sender, 256-body chunk) behind the receive region (MAPN_SYM_SHARD_CHUNK_FLAGS=0: the ticket + one flag per sender, the A/B)
+    static const bool chunked = [] { const char *e = getenv("MAPN_SYM_SHARD_CHUNK_FLAGS"); return !(e && e[0] == '0'); }();
+    h.chunk_flags = chunked ? (uint32_t)((mapn::SYM_RECV_OFFSET + (size_t)world * c->count * sizeof(float4)) / sizeof(uint32_t)) : 0u;
     h.status = c->async_status;
     h.rank = rank; h.world = world; h.count = c->count;
     h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = pl.parts; h.nwaves = pl.nwaves; h.max_meetings = pl.max_meetings; h.sets = pl.sets;
@@ -1758,7 +1761,9 @@ int mapn_p2p_export(mapn_ctx *c, void *out_blob)
         // GPU's polling loads meet in memory, never in a cache
         // Behind the counters (same allocation, same hipIpc handle): the receive region of the sharded symmetric
         // step, one float4 row per sender rank and body of this rank -- peers store into it, this GPU reads it.
-        const size_t bytes = mapn::SYM_RECV_OFFSET + (size_t)c->cfg.world_size * c->count * sizeof(float4);
+        // ... and behind that the arrival flags of the reaction rows, one word per sender and 256-body chunk
+        const size_t bytes = mapn::SYM_RECV_OFFSET + (size_t)c->cfg.world_size * c->count * sizeof(float4) +
+                             (size_t)c->cfg.world_size * ((c->count + 255u) / 256u) * sizeof(uint32_t);
         HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void **>(&c->p2p_flags), bytes, hipDeviceMallocUncached));
         HIP_TRY(hipMemset(c->p2p_flags, 0, bytes));
         HIP_TRY(hipDeviceSynchronize());

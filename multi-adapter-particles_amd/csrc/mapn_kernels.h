@@ -132,6 +132,8 @@ struct SymShardArgs {
     const float4 *recv_mine;
     uint32_t     *flags_mine;
     uint32_t     *ticket;                     // workgroups of this launch whose sends are acknowledged (zero between launches)
+    uint32_t      chunk_flags;                // != 0: arrival flags per (sender, 256-body chunk) at this word offset of the flag arrays instead of
+                                              // the ticket + one flag per sender
     uint32_t     *status;                     // host-visible word: non-zero = a wait timed out
     uint32_t      rank, world, count;         // count = bodies per rank (a multiple of SYM_BLOCK)
     uint32_t      nb, nbl, a0, half_d, parts, nwaves, max_meetings, sets;

@@ -487,7 +487,7 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 
 }  // namespace
 
-// grid <= the workgroups the device holds at once (they wait for the peers, whose counters need ALL of a launch's workgroups)   block = 256
+// grid <= the workgroups the device holds at once (they wait for the peers' rows; a rank's waiting workgroups must not keep its unsent ones out)   block = 256
 // One launch does the reaction exchange, the integration and the exchange of the new positions.
 //  (1) SEND: for every rank q this rank produced reactions for and every body of q: the rows of this rank's
 //      I-blocks that met the body's block (a meeting's row, then its head row if it was cut between two workgroups),
@@ -498,8 +498,10 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 //  (2) OWN ROWS, before anything is waited for: G threads per body (a rank's slice is small -- 8192 bodies at
 //      65 536 / 8 -- so one thread per body would leave the rows' loads latency-bound): thread (body, g) adds the
 //      a-rows of parts [g P/G, (g+1) P/G) in ascending order.
-//  (3) the last workgroup through the ticket stores the arrival flags; lanes 0 .. world-1 of every workgroup's first
-//      wave wait (bounded) for the flags of the ranks that owe this rank rows.
+//  (3) ARRIVAL: every workgroup stores a flag per (destination, 256-body chunk) it sent, in the destination's uncached region;
+//      lanes 0 .. world-1 of a workgroup's first wave wait (bounded) for the senders' flags of the chunk it integrates next.
+//      (chunk_flags == 0, the earlier form: the last workgroup through a ticket stores ONE flag per destination, and every
+//      workgroup waits for the flags of all the ranks that owe this rank rows.)
 //  (4) INTEGRATE: thread (body, 0) adds the G sums in ascending g, then the rows received, nearest sender first
 //      (this rank, rank - 1, rank - 2, ...), then mass, kick, damp, drift (hlsl:103-108) -- a fixed order throughout,
 //      so the replicas stay bit-identical.  The new position is stored write-through.
@@ -599,6 +601,19 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     stamp(2);                                              // sends acknowledged, own rows summed
     if (p.phase == 2u) {
         if (threadIdx.x == 0) ok = 1u;                     // REDUCE: the rows were delivered in stream order
+    } else if (p.chunk_flags) {
+        // ARRIVAL FLAGS PER CHUNK: this workgroup's sends are acknowledged -- it says so itself, per destination and 256-body
+        // chunk (one word each in the destination's uncached region: [sender][chunk]), and a receiver waits only for the
+        // chunk it is about to integrate.  No ticket round trip, no workgroup waits for another one of its own rank (so the
+        // launch's workgroups need not all be resident for it to make progress), and the first receivers start while the last
+        // senders are still at work.
+        const uint32_t tasks = p.world * (p.count / 256u), nchunks = p.count / 256u;
+        for (uint32_t T = bid + threadIdx.x * nblk; T < tasks; T += 256u * nblk) {
+            const uint32_t q = T / nchunks, c = T - q * nchunks;
+            if ((p.send_mask >> q) & 1u)
+                __hip_atomic_store(p.flags_peer[q] + p.chunk_flags + p.send_row * nchunks + c, p.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (threadIdx.x == 0) ok = 1u;
     } else if (threadIdx.x < 64u) {
         // the last workgroup through the ticket tells every rank this one sent to.  (Every workgroup adding a share to the peers'
         // counters instead -- no ticket round trip -- was 0.8 us SLOWER: 256 system-scope atomics on one uncached word are served
@@ -619,15 +634,24 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     }
     __syncthreads();
     if (!ok) return;
-    stamp(3);                                              // the peers' rows are here
+    if (!p.chunk_flags) stamp(3);                          // the peers' rows are here
 
     for (uint32_t base = bid * B; base < p.count; base += nblk * B) {
         const uint32_t il = base + bl;
         const bool live = il < p.count;
         if (base != bid * B) own_rows(il, ax, ay, az);
+        if (p.chunk_flags && p.phase == 0u && threadIdx.x < 64u) {
+            // the senders' flags of THIS chunk (one lane per sender; bounded)
+            const uint32_t q = threadIdx.x, nchunks = p.count / 256u;
+            const uint32_t all_good = wait_counters(p.flags_mine + p.chunk_flags, q * nchunks + base / 256u, q < p.world && ((p.recv_mask >> q) & 1u), p.step,
+                                                    p.timeout_ticks, p.status, 1u + q);
+            if (threadIdx.x == 0) ok = all_good;
+        }
         __syncthreads();                                   // (the previous pass has read `part`)
         part[g][0][bl] = ax; part[g][1][bl] = ay; part[g][2][bl] = az;
         __syncthreads();
+        if (!ok) return;
+        if (p.chunk_flags && base == bid * B) stamp(3);    // the peers' rows of the first chunk are here
         if (g != 0u || !live) continue;
         ax = ay = az = 0.f;
 #pragma unroll
@@ -674,10 +698,8 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
 
     // (5) this rank's new slice is in memory once every workgroup's stores are acknowledged: then the counter
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // vmcnt(0) says the write-through stores were accepted by the L2, not that they have reached memory: a counter on another
-    // channel could overtake them (seen once in a soak of 4 processes x 300 steps at 32 768 bodies, caught by the rows' exchange
-    // number).  The release fence -- buffer_wbl2 + wait -- completes only when they have.  With the force rows stored
-    // write-through there is little left in the L2 for it to write back (round 2 measured 10+ us for it when the L2 was full of rows).
+    // (the system-scope write-through stores are acknowledged once performed; p.release puts a release fence -- buffer_wbl2 +
+    //  wait -- in front of the counter as well: belt and braces, +22 us per step measured, off by default: DESIGN 5 "Visibility")
     if (p.release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     __syncthreads();
     stamp(5);                                              // position stores acknowledged

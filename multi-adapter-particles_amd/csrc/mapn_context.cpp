@@ -630,8 +630,11 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     h.flags_mine = c->p2p_flags;
     h.recv_mine = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(c->p2p_flags) + mapn::SYM_RECV_OFFSET);
     h.ticket = c->sym_shard_ticket;
-    // arrival flags per (sender, 256-body chunk) behind the receive region (MAPN_SYM_SHARD_CHUNK_FLAGS=0: the ticket + one flag per sender, the A/B)
-    static const bool chunked = [] { const char *e = getenv("MAPN_SYM_SHARD_CHUNK_FLAGS"); return !(e && e[0] == '0'); }();
+    // arrival flags per (sender, 256-body chunk) behind the receive region -- with PUSHED positions (same box, rank 0 of 65 536 / 8:
+    // 93.2 against 93.5 us per step); where the launch also PULLS the peers' positions the workgroups' spread-out ends delay
+    // the position counters and the ticket form stays (95.1 against 96.6).  MAPN_SYM_SHARD_CHUNK_FLAGS=0 / 2: never / always (A/B)
+    static const int chunk_mode = [] { const char *e = getenv("MAPN_SYM_SHARD_CHUNK_FLAGS"); return e ? atoi(e) : 1; }();
+    const bool chunked = chunk_mode == 2 || (chunk_mode == 1 && push);
     h.chunk_flags = chunked ? (uint32_t)((mapn::SYM_RECV_OFFSET + (size_t)world * c->count * sizeof(float4)) / sizeof(uint32_t)) : 0u;
     h.status = c->async_status;
     h.rank = rank; h.world = world; h.count = c->count;

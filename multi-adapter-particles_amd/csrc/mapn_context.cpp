@@ -93,6 +93,7 @@ struct mapn_ctx {
     size_t sym_scratch_bytes = 0;
     uint32_t sym_parts = 0, sym_waves = 0;
     bool p2p_shared_device = false;          // a peer rank runs on THIS GPU (several processes on one device: tests)
+    uint32_t p2p_ranks_on_device = 1;        // ranks of the job that run on this GPU, this one included
     uint32_t sym_exchange_cap = 0;            // workgroups of sym_shard_exchange_kernel the device holds at once
     unsigned long long *stamp_buf = nullptr;  // mapn_measure_clock: per-wave clock stamps of a diagnostic launch
     size_t stamp_waves = 0;
@@ -476,6 +477,9 @@ int prepare_sym(mapn_ctx *c, bool sharded)
         // (HSA_CU_MASK / a partition leave fewer than the device properties say), not for the nominal count
         if (!c->cus_active) { c->cus_active = mapn::probe_active_compute_units(c->compute); if (c->cus_active <= 0 || c->cus_active > c->cus) c->cus_active = c->cus; }
         c->sym_exchange_cap = mapn::sym_shard_exchange_resident_workgroups(c->count, c->cus_active);
+        // ranks that share this GPU run their exchange launches side by side (every process has its own hardware queue, nothing
+        // time-slices them): together they must fit, or the device fills with workgroups waiting for peers whose own cannot start
+        if (c->p2p_ranks_on_device > 1u) c->sym_exchange_cap = std::max(1u, c->sym_exchange_cap / c->p2p_ranks_on_device);
     }
     return MAPN_OK;
 }
@@ -1810,7 +1814,7 @@ int mapn_p2p_import(mapn_ctx *c, const void *blobs, int count)
             c->p2p_peer_flags[q] = c->p2p_flags;
             continue;
         }
-        if (b.device_id && b.device_id == p2p_device_id(c->device)) c->p2p_shared_device = true;
+        if (b.device_id && b.device_id == p2p_device_id(c->device)) { c->p2p_shared_device = true; c->p2p_ranks_on_device++; }
         HIP_TRY(hipIpcOpenMemHandle(&c->p2p_peer_heap[q], b.heap, hipIpcMemLazyEnablePeerAccess));
         HIP_TRY(hipIpcOpenMemHandle(reinterpret_cast<void **>(&c->p2p_peer_flags[q]), b.flags, hipIpcMemLazyEnablePeerAccess));
     }

@@ -607,7 +607,12 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     a.shard_nbl = c->count / mapn::SYM_BLOCK;
     a.a0 = rank * a.shard_nbl;
     const bool push = c->gather_algo == 5;
-    if (push) {
+    if (push && c->p2p_shared_device && !c->p2p_loopback) {
+        // ranks SHARING this GPU (tests): a force launch that fills the device while it waits for the peers' counters keeps the
+        // peers' own launches out -- eight such launches waited for each other until the timeouts.  One small stream operation
+        // waits instead, in front of the launch.
+        if (int rc = settle_push(c)) return rc;
+    } else if (push) {
         // the replica this launch reads was completed by the peers' pushes of the previous step: wait for their counters in the launch
         a.wait_counters = c->p2p_flags + mapn::SYM_POS_BASE; a.wait_status = c->async_status; a.wait_timeout_ticks = c->p2p_timeout_ticks;
         a.wait_need = c->sym_pos_epoch * mapn::SYM_COUNT_PER_LAUNCH; a.wait_world = world; a.wait_rank = rank; a.wait_self = c->p2p_loopback ? 1u : 0u;

@@ -122,15 +122,16 @@ parity1000)
   python tests/parity_report.py --bodies 65536 --steps 1,10,100,1000 --f64-max-steps 100 --out $O/parity_1000_65536.json > $O/parity_1000.txt 2>&1; tail -30 $O/parity_1000.txt ;;
 soak)
   mode=${1:-sympush}; mkdir -p /tmp/soak
-  # (jobs whose launches fit the device TOGETHER: several processes time-slice one GPU here, and a force launch that fills it
-  #  while waiting for a peer only moves on when the driver preempts it -- 8 x 65 536 took more than half an hour)
-  for cfg in "2 8192 1500" "4 8192 1500" "8 8192 1500" "8 16384 600" "2 32768 200"; do
+  # (several processes share ONE GPU here, each with its own hardware queue: the library sizes its waiting launches for that --
+  #  mapn_p2p_import counts the ranks on this device -- or eight of them fill the device waiting for each other: DESIGN 5)
+  for cfg in "2 8192 1500" "4 8192 1500" "8 8192 1500" "8 16384 600" "2 32768 600" "4 32768 600" "2 65536 400" "8 65536 300"; do
     set -- $cfg; Wd=$1; N=$2; S=$3
     for m in p2p $mode; do
       rm -rf /tmp/soak/$m; mkdir -p /tmp/soak/$m; pids=""
       for r in $(seq 0 $((Wd - 1))); do python tests/shard_gpu_worker.py $r $Wd $((29850 + Wd)) $N $S /tmp/soak/$m $m > /tmp/soak/$m/log_$r.txt 2>&1 & pids="$pids $!"; done
-      ok=1; for p in $pids; do wait $p || ok=0; done
-      [ $ok = 1 ] || { echo "world=$Wd n=$N steps=$S mode=$m FAILED"; for f in /tmp/soak/$m/log_*.txt; do tail -n 2 $f; done; }
+      t0=$(date +%s); ok=1; for p in $pids; do wait $p || ok=0; done
+      [ $ok = 1 ] && echo "world=$Wd n=$N steps=$S mode=$m: done in $(( $(date +%s) - t0 )) s" | tee -a $O/soak_$mode.txt
+      [ $ok = 1 ] || { echo "world=$Wd n=$N steps=$S mode=$m FAILED" | tee -a $O/soak_$mode.txt; for f in /tmp/soak/$m/log_*.txt; do tail -n 2 $f; done; }
     done
     python - $Wd $N $S $mode <<'PY' | tee -a $O/soak_$mode.txt
 import sys, numpy as np

@@ -322,6 +322,10 @@ int mapn_set_gather_algorithm(mapn_ctx *ctx, int algorithm);
  * bounded (mapn_set_timeouts, default 2 s): a wait that timed out makes the next mapn_simulate /
  * mapn_wait_idle / mapn_download_* return MAPN_ERR_COMM naming the peer; mapn_p2p_status() != 0
  * reports the same without failing (peer q = status - 1).
+ * One rank per GPU is the intended use.  The blob also carries the exporting GPU's PCI id: ranks found to SHARE a device (the
+ * multi-process tests on a one-GPU box) size every launch that waits for a peer so that all of them fit the device together
+ * (processes have separate hardware queues; their launches run side by side, not in turns) and keep the equal-wave 4-wave
+ * plan of the symmetric kernel.
  */
 #define MAPN_P2P_BLOB_BYTES 192
 int mapn_p2p_export(mapn_ctx *ctx, void *out_blob);

@@ -417,9 +417,11 @@ int prepare_sym(mapn_ctx *c, bool sharded)
         } else if (!(t && t[0] == '0') && !pl && !bias_env && !sharded) {
             // biased 8-wave workgroups (one per compute unit) where the launch's workgroups fill whole rounds of the device
             const uint32_t cus = c->cus > 0 ? (uint32_t)c->cus : 256u;
-            for (uint32_t q : {4u, 8u, 5u, 6u, 7u, 3u, 2u, 10u, 12u, 13u, 16u}) {
+            for (uint32_t q : {4u, 5u, 6u, 7u, 8u, 9u, 10u, 11u, 12u, 13u, 14u, 15u, 16u, 3u, 2u}) {
                 const uint64_t wg = (uint64_t)nb * q, rounds = (wg + cus - 1u) / cus;
-                if (wg < cus || (rounds < 16u && wg * 50u < rounds * cus * 49u)) continue;      // (the last round at least 98 % full)
+                // (the last round at least 97 % full: 69 632 bodies, 68 blocks x 11 = 748 of 768: +2 % over the tapered 4-wave shape;
+                //  90 112 bodies, 88 x 14 = 1232 of 1280 = 96 %: -0.9 %)
+                if (wg < cus || (rounds < 16u && wg * 100u < rounds * cus * 97u)) continue;
                 tries.push_back({q, q, 0, 8, 10, 3}); tries.push_back({q, q, 0, 8, 3, 1});
                 break;
             }

@@ -223,12 +223,12 @@ def test_symmetric_context_falls_back_where_the_kernel_does_not_apply(oracle):
 
 
 @pytest.mark.parametrize("n,want", [(65536, (8, 4, (10, 3))), (100000, (8, 13, (10, 3))), (32768, (8, 8, (10, 3))), (262144, (8, 4, (10, 3))),
-                                    (69632, (4, 40, (1, 1))), (16384, (4, 32, (1, 1))), (1024, (4, 4, (1, 1)))])
+                                    (69632, (8, 11, (10, 3))), (90112, (4, 40, (1, 1))), (16384, (4, 32, (1, 1))), (1024, (4, 4, (1, 1)))])
 def test_default_launch_shapes(n, want):
     """The default shape of the unsharded launch (prepare_sym): 8-wave workgroups with biased waves and as many parts per block
     as fill whole rounds of the 256 compute units (65 536 bodies: 64 blocks x 4 parts = one round; 100 000: 98 x 13 = 1274 of
-    1280); where no part count up to 16 fills the last round to 98 % (69 632 bodies: 68 blocks) or the small waves would fall
-    under 64 steps (16 384) the equal-wave 4-wave shape stays."""
+    1280; 69 632: 68 x 11 = 748 of 768); where no part count up to 16 fills the last round to 97 % (90 112 bodies: 88 blocks) or
+    the small waves would fall under 64 steps (16 384) the equal-wave 4-wave shape stays."""
     with mapn.Compute(n, mass=70000.0 / n, kernel=mapn.KERNEL_SYMMETRIC) as c:
         pl = c.sym_plan()
         assert (pl.waves, pl.parts, pl.wave_bias) == want, (pl.waves, pl.parts, pl.taper1, pl.taper2, pl.wave_bias)

@@ -432,7 +432,16 @@ int prepare_sym(mapn_ctx *c, bool sharded)
         } else if (sharded && !pl && !bias_env && !c->p2p_shared_device) {
             // (not when several ranks share this GPU: an 8-wave workgroup needs BOTH wave slots of all four SIMDs of a compute
             //  unit, and cannot be placed on one where a peer's exchange workgroup sits waiting -- for this very launch's rows)
-            const uint32_t p8 = std::max(16u, (256u + nbl - 1u) / nbl);
+            // the fewest parts per block that fill whole rounds of the device (as above; 196 608 bodies over 8 ranks, 24 blocks:
+            // 21 parts = 504 of 512 workgroups: 703 us per step against 862 with 16 parts = one and a half rounds)
+            const uint32_t cus = c->cus > 0 ? (uint32_t)c->cus : 256u;
+            uint32_t p8 = std::max(16u, (cus + nbl - 1u) / nbl);
+            for (uint32_t q = 4u; q <= 64u; q++) {
+                const uint64_t wg = (uint64_t)nbl * q, rounds = (wg + cus - 1u) / cus;
+                if (wg < cus || (rounds < 16u && wg * 100u < rounds * cus * 97u)) continue;
+                p8 = q;
+                break;
+            }
             tries.push_back({p8, p8, 0, 8, 10, 3}); tries.push_back({p8, p8, 0, 8, 3, 1}); tries.push_back({p8, p8, 0, 8, 2, 1});
         }
         if (!c->sym_user_plan)

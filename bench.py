@@ -3,7 +3,7 @@
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched as
 ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`` (one rank per
-GPU).  W untimed warm-up steps, then EXACTLY K steps timed between barrier + device sync on both
+GPU) -- or WITHOUT a launcher: ``python bench.py --gpus N`` then starts its N ranks itself (launch_ranks).  W untimed warm-up steps, then EXACTLY K steps timed between barrier + device sync on both
 sides, MAX over ranks, rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json configs[1]): 65 536 bodies, fp32, seeded two-shell state (seed 1),
@@ -160,8 +160,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
+            # no launcher around this process: start the ranks here (before anything touches the GPU) and relay rank 0's line
+            sys.exit(launch_ranks(a.gpus))
         a.gpus = world
     dist = None
     torch = None
@@ -583,6 +584,52 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` with no launcher environment: this process becomes the launcher.  It starts N children of
+    this same command line -- one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way
+    torch.distributed.run sets them -- passes their output through (rank 0 prints the ONE JSON line) and returns the worst
+    exit code.  The parent never loads the library, never touches the GPU and never exec's (a process that has initialised the
+    GPU must not be replaced).  A rank that dies takes the others down after a grace period instead of leaving them in a
+    collective for ever.  (Particles.cpp:446-448 is the caller sequence every rank then runs.)"""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    children = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks), "GROUP_RANK": "0",
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # the host driver supports dmabuf IPC only (hipIpc handles, RCCL)
+        env.setdefault("OMP_NUM_THREADS", "1")
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True))
+    worst, deadline = 0, None
+    try:
+        while any(ch.poll() is None for ch in children):
+            codes = [ch.poll() for ch in children]
+            if deadline is None and any(rc not in (None, 0) for rc in codes):
+                deadline = time.monotonic() + 20.0             # a rank failed: the others get 20 s to notice (bounded waits, barriers)
+            if deadline is not None and time.monotonic() > deadline:
+                for ch in children:
+                    if ch.poll() is None:
+                        os.killpg(ch.pid, signal.SIGKILL)      # exactly the process groups started above
+                deadline = float("inf")
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for ch in children:
+            if ch.poll() is None:
+                os.killpg(ch.pid, signal.SIGKILL)
+        worst = 130
+    for r, ch in enumerate(children):
+        rc = ch.wait()
+        if rc != 0:
+            print(f"[bench launcher] rank {r} exited with code {rc}", file=sys.stderr, flush=True)
+            worst = worst or (rc if rc > 0 else 128 - rc)
+    return worst
 
 
 def make_torch_gather(c, torch, dist, n, rank, world):

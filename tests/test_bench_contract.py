@@ -22,6 +22,20 @@ def test_bench_fails_loudly_without_a_gpu():
     assert not any(line.startswith("{") for line in r.stdout.splitlines())
 
 
+def test_bench_launches_its_own_ranks_and_relays_their_failure_without_a_gpu():
+    """`python bench.py --gpus 2` with NO launcher environment must start its two ranks itself (the driver's
+    8-GPU command may have exactly this shape).  Without a GPU both ranks fail loudly; the launcher relays the worst exit
+    code and no JSON line appears."""
+    if mapn.compute.device_count() > 0:
+        pytest.skip("a GPU is present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--bodies", "2048",
+                        "--same-device", "--dist-backend", "gloo", "--gather", "p2p"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "[bench launcher] rank 0 exited with code" in r.stderr and "[bench launcher] rank 1 exited with code" in r.stderr
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())
+
+
 def test_committed_pmc_summaries_belong_to_the_current_kernel_sources():
     """bench.py attaches `roofline.traffic` only while the committed PMC summary was measured on the kernel
     sources being run (their sha is stored in it): a kernel edit without a fresh `--pmc` pass must show up
@@ -97,6 +111,21 @@ def test_bench_two_ranks_one_gpu_with_the_direct_exchange():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["exchange"] == "p2p"
     assert d["config"]["replicas_bit_identical_after_run"] is True
     assert d["config"]["parallelism"] == "bodies sharded x2" and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO torch.distributed.run around it -- the process becomes the
+    launcher (before any GPU call), starts one child per rank with RANK / WORLD_SIZE / MASTER_* set, relays rank 0's single
+    JSON line and the worst exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "3", "--gather", "p2p",
+                        "--dist-backend", "gloo", "--same-device", "--prewarm-ms", "20"], capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 30 and d["config"]["exchange"] == "p2p"
+    assert d["config"]["replicas_bit_identical_after_run"] is True and d["config"]["parallelism"] == "bodies sharded x2"
 
 
 @pytest.mark.gpu

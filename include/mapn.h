@@ -62,11 +62,14 @@ typedef enum mapn_kernel {
                                    mapn_create -- which fails if the memory is not to be had.  Under
                                    MAPN_KERNEL_AUTO the same failure only selects the one-sided kernel
                                    (mapn_get_sym_plan tells why). */
-    /* No MFMA variant (BASELINE configs[4] A/B, closed in round 2): on gfx950 the f32 MFMA shapes do NOT
-       run beside the packed fp32 VALU stream of the same SIMD -- their times add (16 v_pk_fma_f32 + one
-       v_mfma_f32_16x16x4_f32: 105 cycles against 74 + 32) -- so every recast of the pair term is slower
-       than the packed-VALU form, and the two that remove the most VALU work lose 3 decimal digits
-       (profiles/r02_ubench.txt, profiles/r02_mfma_recast_error.txt). */
+    /* No MFMA variant (BASELINE configs[4] A/B; re-measured by `pytest -m gpu` on every run since round 4:
+       tests/test_gpu_mfma_ab.py): on gfx950 the f32 MFMA shapes do NOT run beside the packed fp32 VALU stream
+       of the same SIMD -- their times add (16 v_pk_fma_f32 + one v_mfma_f32_16x16x4_f32: 106 cycles against
+       75 + 32) -- so every recast of the pair term is slower than the packed-VALU form (register-resident
+       upper bounds: -7 % ... -65 %; the product's scalar kernel at one rank's share of the 1 048 576-body
+       job, loads and integrator included, beats all of them), and the two that remove the most VALU work
+       lose 3 decimal digits (profiles/r04_ubench_ab.txt, profiles/r04_ubench_ab_rocprofv3_kernel_stats.csv,
+       profiles/r02_mfma_recast_error.txt). */
 } mapn_kernel;
 
 /* The three #if variants of LoadParticles (Compute.cpp:581-583), all seeded per body. */

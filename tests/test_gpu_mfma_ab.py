@@ -1,0 +1,137 @@
+"""BASELINE configs[4]: "1 048 576 bodies, fp32, 8 x MI355X, MFMA-tiled force accumulation vs scalar kernel (rocprof A/B)".
+
+north_star allows MFMA "only if the pairwise accumulation is recast as a dense fp32 outer-product tile and rocprof shows it
+wins".  It does not win on gfx950, and this file is where that is MEASURED on the device the suite runs on instead
+of being quoted from round 2's text files:
+
+  (i)   f32 MFMA does not run beside the packed-fp32 VALU stream of the same SIMD: 16 v_pk_fma_f32 with one
+        v_mfma_f32_16x16x4_f32 in their middle cost at least the SUM of the two alone, nowhere near the larger of them;
+  (ii)  every recast of the pair term (nBodyGravityCS.hlsl:46-56) that moves work onto MFMA -- accumulate on 4x4x1 / 16x16x4 /
+        32x32x2, r^2 on 16x16x4 with the sum-form accumulate -- runs FEWER pairs per second, register-resident and with no
+        memory traffic at all (an upper bound for any kernel built on it), than the packed-VALU pair term that ships;
+  (iii) the two recasts that remove the most VALU work lose three decimal digits on the real two-shell state
+        (tools/mfma_recast_error.py, numpy) -- at configs[4]'s own size too;
+  (iv)  at configs[4] AS WRITTEN -- one rank's share (131 072 bodies against 1 048 576) of the 8-way job -- the product's scalar
+        kernel, loads, reduction and integrator included, is faster than every MFMA recast's register-resident upper bound.
+
+The microbenchmarks live in tools/ubench.hip (`ubench --ab`: JSON lines; times from the launch wall).  No product MFMA kernel
+exists: include/mapn.h says why and cites profiles/r04_ubench_ab.txt, which is this test's measurement on the round's box.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import mapn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+MFMA_PAIR_VARIANTS = ("pair packed, accumulate on mfma 4x4x1", "pair packed, accumulate on mfma16x16x4",
+                      "pair packed, accumulate on mfma32x32x2", "pair: r^2 on mfma16x16x4, sum-form accumulate")
+
+
+def ubench_binary():
+    """tools/ubench, rebuilt when tools/ubench.hip is newer (hipcc cross-compiles: __graft_entry__.build() makes it too)."""
+    src, exe = os.path.join(ROOT, "tools", "ubench.hip"), os.path.join(ROOT, "tools", "ubench")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", src, "-o", exe], check=True, timeout=600)
+    return exe
+
+
+def run_ab(iters=20000):
+    r = subprocess.run([ubench_binary(), "--ab", str(iters)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return {(d["mix"], d["waves_per_simd"]): d for d in rows}
+
+
+def test_ubench_source_builds_for_gfx950_and_lists_the_ab_variants():
+    """CPU side: the microbenchmark cross-compiles, and the variants this file asserts on are the ones it knows."""
+    exe = ubench_binary()
+    assert os.path.exists(exe)
+    src = open(os.path.join(ROOT, "tools", "ubench.hip")).read()
+    for name in MFMA_PAIR_VARIANTS + ("pair packed (2 bodies)", "16 v_pk_fma + 1 mfma16x16x4", "v_mfma_f32_16x16x4_f32 x8", "v_pk_fma_f32 x16"):
+        assert '"' + name + '"' in src, name
+
+
+def test_mfma_recasts_lose_three_digits_on_the_two_shell_state():
+    """(iii), numpy only: against the float64 acceleration the shipped form (differences first) is good to 1e-7; the r^2
+    expansion (|x|^2 ~ 5e5 against soft^2 = 25) and the sum-form accumulate are 100 x worse -- at 65 536 bodies and at
+    configs[4]'s 1 048 576."""
+    from mfma_recast_error import recast_errors
+    for n, k in ((65536, 48), (1048576, 6)):
+        e = recast_errors(n, k)
+        ship = e["kernel form (differences first, fp32)"]
+        assert ship[1] < 3e-7, (n, ship)
+        r2 = e["r2-expansion on MFMA, difference-form accumulate"]
+        sf = e["exact fp32 r2, sum-form accumulate on MFMA"]
+        both = e["r2-expansion + sum-form (all on MFMA)"]
+        assert r2[0] > 1e-5 and r2[1] > 3e-5, (n, r2)           # median, max of |da| / |a| (the max over few bodies at 1 Mi)
+        assert sf[0] > 8e-6 and sf[1] > 1e-5, (n, sf)
+        assert both[0] > 1e-5 and both[1] > 3e-5, (n, both)
+        assert min(r2[0], sf[0], both[0]) > 100 * ship[0], (n, e)
+        assert e["d_rel"][2] > 1e-4                              # some pairs' expanded r^2 is off by more than 1e-4 relative
+
+
+@pytest.mark.gpu
+def test_config4_mfma_against_packed_valu_measured_on_this_device(tmp_path):
+    ab = run_ab()
+    report = []
+    for w in (2, 8):
+        pk16 = ab[("v_pk_fma_f32 x16", w)]["cycles_per_body_per_simd"]                    # 16 packed fma
+        mf16 = ab[("v_mfma_f32_16x16x4_f32 x8", w)]["cycles_per_body_per_simd"] / 8.0     # ONE 16x16x4
+        mf32 = ab[("v_mfma_f32_32x32x2_f32 x4", w)]["cycles_per_body_per_simd"] / 4.0     # ONE 32x32x2
+        c1 = ab[("16 v_pk_fma + 1 mfma16x16x4", w)]["cycles_per_body_per_simd"]
+        c2 = ab[("16 v_pk_fma + 2 mfma16x16x4", w)]["cycles_per_body_per_simd"]
+        c3 = ab[("16 v_pk_fma + 1 mfma32x32x2", w)]["cycles_per_body_per_simd"]
+        report.append(f"waves/SIMD {w}: 16 v_pk_fma {pk16:.1f} cycles per SIMD; one mfma16x16x4 {mf16:.1f}, one mfma32x32x2 {mf32:.1f}; "
+                      f"16 pk + 1 mfma16 {c1:.1f} (sum {pk16 + mf16:.1f}, max {max(pk16, mf16):.1f}); + 2 mfma16 {c2:.1f} (sum {pk16 + 2 * mf16:.1f}); "
+                      f"+ 1 mfma32 {c3:.1f} (sum {pk16 + mf32:.1f})")
+        assert 30.0 < mf16 < 36.0 and 60.0 < mf32 < 70.0, report[-1]         # 1024 / 2048 MACs at 32 per cycle, at any occupancy
+        if w != 8:
+            continue                                           # (two waves per SIMD: the dependent fma chain is latency-bound, an MFMA fits its bubbles)
+        # (i) with the SIMD's issue saturated the unit costs are what the ISA says (16 x 4 cycles + issue gaps) ...
+        assert 60.0 < pk16 < 80.0, report[-1]
+        # ... and together they ADD: at least 93 % of the sum, at least 1.3 x the larger one (overlap would give 64)
+        for combo, parts in ((c1, (pk16, mf16)), (c2, (pk16, 2 * mf16)), (c3, (pk16, mf32))):
+            assert combo >= 0.93 * sum(parts), report[-1]
+            assert combo >= 1.3 * max(parts), report[-1]
+    # (ii) pairs per second of the whole pair term, register-resident: every MFMA variant below the packed-VALU form
+    best = {}
+    for name in ("pair packed (2 bodies)",) + MFMA_PAIR_VARIANTS:
+        best[name] = max(ab[(name, w)]["pairs_per_s"] for w in (2, 8))
+        report.append(f"{name:52s} {best[name]:.3e} pairs/s ({best[name] / best['pair packed (2 bodies)'] - 1:+.1%} against the packed-VALU pair term)")
+    shipped = best["pair packed (2 bodies)"]
+    assert 4.0e12 < shipped < 6.0e12, report
+    for name in MFMA_PAIR_VARIANTS:
+        assert best[name] < 0.97 * shipped, report
+    assert best["pair packed, accumulate on mfma16x16x4"] < 0.65 * shipped and best["pair packed, accumulate on mfma32x32x2"] < 0.45 * shipped, report
+
+    # (iv) configs[4] as written: rank 0's share of 1 048 576 bodies over 8 ranks through the product's scalar kernel -- one launch
+    # per step with loads, reduction and integrator -- against the recasts' register-resident upper bounds
+    n, world = 1048576, 8
+    with mapn.Compute(n, device=0, mass=70000.0 / n, rank=0, world_size=world, kernel=mapn.KERNEL_SCALAR) as c:
+        c.set_external_gather(True)                            # (no exchange: the A/B is about the force kernel)
+        c.set_timers(1)
+        for _ in range(2):
+            c.Simulate(n, 0)
+        c.WaitForGpu(); c.kernel_stats(reset=True)
+        for _ in range(4):
+            c.Simulate(n, 0)
+        c.WaitForGpu()
+        st = c.kernel_stats()
+    real = (n // world) * float(n) / st.avg_seconds
+    report.append(f"product scalar kernel ({st.kernel_name.decode()}), rank 0 of {n} / {world}: {st.avg_seconds * 1e3:.2f} ms per launch = {real:.3e} pairs/s")
+    assert st.kernel_name.decode() == "force_sgpr_kernel" and st.launches == 4
+    for name in MFMA_PAIR_VARIANTS:
+        assert best[name] < real, report
+    text = "\n".join(report)
+    print(text)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):                                     # evidence: copied to profiles/r04_ubench_ab.txt by hand
+        with open(os.path.join(out, "ubench_ab_test_report.txt"), "w") as f:
+            f.write(text + "\n")

@@ -14,6 +14,7 @@
 #   loopback [N]                 rank 0's compute per step at the shard size, one-sided against symmetric, WORLD = 2, 4, 8
 #   sizes                        symmetric against one-sided kernel at 65 536 ... 4 194 304 bodies
 #   parity1000                   tests/parity_report.py at 65 536 bodies, 1000 steps, all legs -> JSON
+#   ubench                       BASELINE configs[4]: the MFMA-against-packed-VALU A/B (tools/ubench --ab) under rocprofv3 --kernel-trace --stats + the gpu test's report
 #   soak MODE                    several real processes on one GPU, long runs: MODE = flow | sym | sympush (against p2p)
 set -u
 R=$PWD; W=${1:-suite}; shift || true
@@ -118,6 +119,12 @@ sizes)
     st=$((n > 1000000 ? 4 : n > 200000 ? 30 : 200)); wu=$((n > 1000000 ? 1 : 5))
     for k in sym sgpr; do python bench.py --bodies $n --steps $st --warmup $wu --prewarm-ms $((n > 1000000 ? 0 : 400)) --no-cpu-baseline --kernel $k 2>/dev/null | line "$n $k" | tee -a $O/sizes.txt; done
   done ;;
+ubench)
+  [ tools/ubench -nt tools/ubench.hip ] || hipcc --offload-arch=gfx950 -O3 tools/ubench.hip -o tools/ubench
+  cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $R/tools/ubench --ab 20000 > $O/ubench_ab.jsonl 2> $O/ubench_ab.err
+  cd $R; f=$(ls -t $(find $O/stats -name "*kernel_stats.csv") | head -1); cp $f $O/ubench_ab_kernel_stats.csv; head -30 $f
+  python -m pytest tests/test_gpu_mfma_ab.py -m gpu -q -s 2>&1 | tee $O/pytest_mfma_ab.txt | tail -25
+  cp gpurun_out/ubench_ab_test_report.txt $O/ 2>/dev/null ;;
 parity1000)
   python tests/parity_report.py --bodies 65536 --steps 1,10,100,1000 --f64-max-steps 100 --out $O/parity_1000_65536.json > $O/parity_1000.txt 2>&1; tail -30 $O/parity_1000.txt ;;
 soak)

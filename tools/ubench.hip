@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <string>
 #include <algorithm>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e)); exit(1); } } while (0)
@@ -344,6 +345,8 @@ __global__ __launch_bounds__(256) void ub(float *out, unsigned long long *cyc, u
     }
 }
 
+static bool g_json = false;     // --ab: one JSON object per line instead of the table (tests/test_gpu_mfma_ab.py parses it)
+
 template <int MIX>
 static void run(int waves_per_simd, int iters)
 {
@@ -372,6 +375,16 @@ static void run(int waves_per_simd, int iters)
     // per SIMD: waves_per_simd waves, each issuing `insts` wave-instructions in cmed cycles
     const double ipc = insts * waves_per_simd / cmed;
     const double ghz = cmed / rmed * 0.1;
+    if (g_json) {
+        // cycles_per_body_per_simd from the launch WALL (a kernel that needs more registers than `waves_per_simd` waves leave
+        // runs its workgroups in turns; the wall accounts for that, the in-kernel stamps of one wave do not)
+        const double pairs = (double)iters * mix_pairs[MIX] * 64.0 * waves;
+        printf("{\"mix\": \"%s\", \"id\": %d, \"waves_per_simd\": %d, \"iters\": %d, \"insts_per_body\": %d, \"wall_ms\": %.5f, \"clk_ghz\": %.4f, "
+               "\"cycles_per_body_per_simd\": %.3f, \"pairs_per_s\": %.5e}\n", mix_name[MIX], (int)MIX, waves_per_simd, iters, mix_insts[MIX], ms, ghz,
+               ms * 1e-3 * ghz * 1e9 / ((double)iters * waves_per_simd), pairs / (ms * 1e-3));
+        CHECK(hipFree(out)); CHECK(hipFree(cyc)); CHECK(hipFree(rt));
+        return;
+    }
     printf("%-32s waves/SIMD=%d  cyc/inst/SIMD=%6.3f  inst/cyc/SIMD=%5.3f  clk=%.2f GHz  wall=%.3f ms", mix_name[MIX], waves_per_simd, 1.0 / ipc, ipc, ghz, ms);
     if (mix_pairs[MIX] > 0) {
         const double pairs = (double)iters * mix_pairs[MIX] * 64.0 * waves;
@@ -389,6 +402,17 @@ static void sweep(int iters)
 
 int main(int argc, char **argv)
 {
+    // ubench --ab [iters]: the MFMA-against-packed-VALU A/B of BASELINE configs[4] only, as JSON lines
+    if (argc > 1 && std::string(argv[1]) == "--ab") {
+        const int it = argc > 2 ? atoi(argv[2]) : 20000;
+        g_json = true;
+        for (int w : {2, 8}) {
+            run<PKFMA>(w, it); run<MFMA4>(w, it); run<MFMA16>(w, it); run<MFMA32>(w, it);
+            run<PK16_MFMA16_1>(w, it); run<PK16_MFMA16_2>(w, it); run<PK16_MFMA32_1>(w, it);
+            run<PAIR_PK>(w, it); run<PAIR_PK8>(w, it); run<PAIR_MFMA>(w, it); run<PAIR_ACC_MFMA16>(w, it); run<PAIR_ACC_MFMA32>(w, it); run<PAIR_R2_MFMA16>(w, it);
+        }
+        return 0;
+    }
     int iters = argc > 1 ? atoi(argv[1]) : 20000;
     hipDeviceProp_t pr; CHECK(hipGetDeviceProperties(&pr, 0));
     printf("device: %s  arch=%s  CUs=%d  clock=%d kHz  wave=%d\n", pr.name, pr.gcnArchName, pr.multiProcessorCount, pr.clockRate, pr.warpSize);

@@ -187,8 +187,11 @@ def main():
     mode = mapn.FORCE_ALL_PAIRS if a.mode == "all_pairs" else mapn.FORCE_CENTRAL_WELL
     flags = (mapn.FLAG_USE_GRAPH if a.graph else 0) | (mapn.FLAG_SHARD_OVERLAP if a.overlap else 0)
     kern = {"auto": mapn.KERNEL_AUTO, "lds": mapn.KERNEL_LDS, "sgpr": mapn.KERNEL_SCALAR, "sym": mapn.KERNEL_SYMMETRIC}[a.kernel]
+    # XCD-aware parts (1 GPU, symmetric kernel): the LIBRARY calibrates the dies when the context is created (MAPN_FLAG_XCD_CALIBRATE:
+    # the plan any C-ABI caller gets with that one config bit); below, an untimed A/B decides whether the weights stay
+    xcd_by_library = dist is None and a.mode == "all_pairs" and a.xcd != "off" and kern in (mapn.KERNEL_AUTO, mapn.KERNEL_SYMMETRIC) and not a.plan and not a.graph
     c = mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed,
-                     rank=rank, world_size=world, flags=flags, kernel=kern)
+                     rank=rank, world_size=world, flags=flags | (mapn.FLAG_XCD_CALIBRATE if xcd_by_library else 0), kernel=kern)
     info = device_info(local_rank)
     transport = "none"
     gather_fn = None
@@ -234,12 +237,14 @@ def main():
     def replicas_consistent():
         """Every rank keeps a full replica of the positions; after any correct exchange they are
         bit-identical.  Compares a checksum of both ping-pong buffers across ranks."""
-        c.WaitForGpu()
-        import numpy as np
-        sums = [int(np.frombuffer(c.download_buffer(b)[0].tobytes(), np.uint32).sum(dtype=np.uint64)) for b in (0, 1)]
+        try:
+            sums = list(c.replica_checksum())            # mapn_replica_checksum: one C call (drains, reports failed device-side waits)
+        except mapn.MapnError as e:                      # (every rank must still take part in the collective below)
+            print(f"[bench rank {rank}] replica check: {e}", file=sys.stderr, flush=True)
+            sums = None
         allsums = [None] * world
         dist.all_gather_object(allsums, sums)
-        return all(x == allsums[0] for x in allsums)
+        return all(x is not None and x == allsums[0] for x in allsums)
 
     p2p_failure = None
     if dist is not None and transport == "rccl":
@@ -413,8 +418,8 @@ def main():
             c.WaitForGpu()
     # XCD-aware parts (1 GPU, symmetric kernel): the eight dies do not run at one speed and a launch gives each the same work.
     # Untimed: calibrate, then an A/B of the weighted plan against the default one; the weights stay only if they win.
-    xcd = {"mode": a.xcd, "weights": None, "used": False}
-    if dist is None and a.mode == "all_pairs" and a.xcd != "off" and kern in (mapn.KERNEL_AUTO, mapn.KERNEL_SYMMETRIC) and not a.plan and not a.graph:
+    xcd = {"mode": a.xcd, "weights": None, "used": False, "source": None}
+    if xcd_by_library:
         try:
             def burst(k):
                 c.WaitForGpu(); t = time.perf_counter()
@@ -423,16 +428,19 @@ def main():
                 c.WaitForGpu()
                 return (time.perf_counter() - t) / k
             kk = max(8, min(120, int(0.08 / (0.65e-3 * (n / 65536.0) ** 2))))
-            w = c.calibrate_sym_xcds(4 if n <= 262144 else 1)
-            xcd["weights"] = w
-            t_def = min(burst(kk), burst(kk))
-            c.set_sym_xcd_weights(w)
-            t_w = min(burst(kk), burst(kk)) if c.sym_plan().sets > 2 else float("inf")
-            xcd["trial_ms"] = {"default": t_def * 1e3, "weighted": None if t_w == float("inf") else t_w * 1e3}
-            if a.xcd == "on" or t_w < t_def * 0.998:
-                xcd["used"] = c.sym_plan().sets > 2
-            if not xcd["used"]:
+            pl = c.sym_plan()
+            if pl.sets > 2:                                # the library's creation-time calibration applied its weights
+                w = list(pl.xcd_weight)
+                xcd["weights"], xcd["source"] = w, "library (MAPN_FLAG_XCD_CALIBRATE at mapn_create)"
+                t_w = min(burst(kk), burst(kk))
                 c.set_sym_xcd_weights(None)
+                t_def = min(burst(kk), burst(kk))
+                xcd["trial_ms"] = {"default": t_def * 1e3, "weighted": t_w * 1e3}
+                if a.xcd == "on" or t_w < t_def * 0.998:
+                    c.set_sym_xcd_weights(w)
+                    xcd["used"] = c.sym_plan().sets > 2
+            else:
+                xcd["note"] = "the library's calibration did not apply (block count not a multiple of 8, or the one-sided kernel runs)"
         except mapn.MapnError as e:
             xcd["error"] = str(e)[:200]
             try:

@@ -84,6 +84,15 @@ typedef enum mapn_init_variant {
 #define MAPN_FLAG_SHARD_OVERLAP 0x4u /* sharded mode: own-segment launch overlapped with the all-gather */
 #define MAPN_FLAG_STRICT_CONSUMER 0x8u /* mapn_simulate(wait_value) returns MAPN_ERR_STATE instead of queueing
                                           the wait when the consumer has not yet signalled wait_value - 1 */
+#define MAPN_FLAG_XCD_CALIBRATE 0x10u  /* mapn_create / mapn_create_from measure the eight dies' speeds under the symmetric kernel
+                                          (about 0.2 s: a clock-ramp phase, then mapn_calibrate_sym_xcds on the context's own state,
+                                          which is put back bit for bit together with the fence value and the buffer index) and
+                                          size every part of the launch plan by the die it runs on (mapn_set_sym_xcd_weights) --
+                                          the plan bench.py's headline number is measured with, for any C-ABI caller
+                                          (compat/Compute.hpp: one config bit).  A hint: where XCD weights do not apply
+                                          (one-sided kernel, block count not a multiple of 8, a sharded context, a partitioned
+                                          device) creation succeeds with the default plan and mapn_last_error() says why;
+                                          mapn_get_sym_plan(...)->sets == 16 tells whether the weights are in use. */
 
 /*
  * Everything `Compute::Compute(numParticles, adapter, useIntelExt, old)` (Compute.h:36-39)
@@ -337,6 +346,17 @@ int mapn_p2p_status(mapn_ctx *ctx);
 /* alternative transport: the caller all-gathers the written position buffer itself after every
  * step (e.g. torch.distributed.all_gather_into_tensor on the exported buffers) */
 int mapn_set_external_gather(mapn_ctx *ctx, int enabled);
+/*
+ * Sharded mode: every rank keeps a full replica of both position buffers, and after any correct exchange the replicas are
+ * bit-identical on all ranks.  out[b] = the sum of the 4 N 32-bit words of position buffer b as a 64-bit integer (drains the
+ * context first, like mapn_download_buffer: a timed-out or failed device-side wait is reported here).  The launcher compares
+ * the two numbers across ranks (bench.py does after every trial and after the timed run); equal sums on all ranks do not prove
+ * the exchange delivered the RIGHT data -- the pushed positions of gather algorithm 5 are therefore also checked on the device,
+ * every step, against checksums their pusher stores behind them (a mismatch makes the next mapn_simulate / mapn_wait_idle /
+ * mapn_download_* fail with MAPN_ERR_COMM naming the pusher) -- the analogue of the reference's fence protocol between the
+ * two adapters (Compute.cpp:1012, Render.cpp:796-826), which has no data check at all.
+ */
+int mapn_replica_checksum(mapn_ctx *ctx, uint64_t out[2]);
 /* the slice [first, first+count) of bodies this context owns */
 int mapn_shard_range(const mapn_ctx *ctx, uint32_t *first, uint32_t *count);
 
@@ -397,7 +417,7 @@ int mapn_set_force_plan(mapn_ctx *ctx, int kernel, uint32_t bodies_per_lane, uin
  * windows[4 k ..] = {g0, g1, meetings of a class-0 block, of a class-1 block}; tables = per window
  * bounds[sets][parts * waves + 1] (first linear step of every wave) then split[sets][max_meetings] (the part whose
  * head row holds the last steps of a meeting cut between two workgroups, 0xffffffff otherwise); class 0 = the blocks
- * that also run the half-ring group (even block count, a < nb / 2); set = class, or class + 2 * (block mod 8) when the
+ * that also run the half-ring group (even block count; of the pair (p, p + nb / 2) block p when p is even, block p + nb / 2 when p is odd); set = class, or class + 2 * (block mod 8) when the
  * parts are XCD-weighted (sets = 16; the block counted within its launch).  What an order-matched checker must reproduce
  * (the CPU checker restates exactly this): per wave one fused-multiply-add chain per body over its steps in
  * order; the workgroup's waves added in ascending order into ONE row per (block, part); the reaction of a meeting as

@@ -8,7 +8,7 @@ library, or without a gfx950 device, construction raises.
 """
 from ._lib import (  # noqa: F401
     FORCE_ALL_PAIRS, FORCE_CENTRAL_WELL, KERNEL_AUTO, KERNEL_LDS, KERNEL_SCALAR, KERNEL_SYMMETRIC,
-    FLAG_NO_INIT, FLAG_SHARD_OVERLAP, FLAG_STRICT_CONSUMER, FLAG_USE_GRAPH, INIT_LCG, INIT_MT, INIT_SSE, Config, DeviceInfo, KernelStats, MapnError, SharedHandles,
+    FLAG_NO_INIT, FLAG_SHARD_OVERLAP, FLAG_STRICT_CONSUMER, FLAG_USE_GRAPH, FLAG_XCD_CALIBRATE, INIT_LCG, INIT_MT, INIT_SSE, Config, DeviceInfo, KernelStats, MapnError, SharedHandles,
     build_library, library_path, load_library,
 )
 from .compute import Compute, IpcView, SymPlan, describe_sym_plan, generate_initial_state  # noqa: F401
@@ -18,5 +18,5 @@ __all__ = [
     "Compute", "IpcView", "Config", "MapnError", "ShardPlan", "shard_range", "remote_segments",
     "generate_initial_state", "SymPlan", "describe_sym_plan", "build_library", "load_library", "library_path",
     "FORCE_ALL_PAIRS", "FORCE_CENTRAL_WELL", "KERNEL_AUTO", "KERNEL_LDS", "KERNEL_SCALAR", "KERNEL_SYMMETRIC",
-    "FLAG_NO_INIT", "FLAG_USE_GRAPH", "FLAG_SHARD_OVERLAP", "FLAG_STRICT_CONSUMER", "INIT_LCG", "INIT_SSE", "INIT_MT",
+    "FLAG_NO_INIT", "FLAG_USE_GRAPH", "FLAG_SHARD_OVERLAP", "FLAG_STRICT_CONSUMER", "FLAG_XCD_CALIBRATE", "INIT_LCG", "INIT_SSE", "INIT_MT",
 ]

@@ -18,6 +18,7 @@ INIT_LCG, INIT_SSE, INIT_MT = 0, 1, 2
 FLAG_NO_INIT = 0x2
 FLAG_SHARD_OVERLAP = 0x4
 FLAG_STRICT_CONSUMER = 0x8
+FLAG_XCD_CALIBRATE = 0x10
 IPC_BLOB_BYTES = 256
 UNIQUE_ID_BYTES = 128
 P2P_BLOB_BYTES = 192
@@ -132,6 +133,7 @@ SIGNATURES = {
     "mapn_p2p_import": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "mapn_p2p_status": (C.c_int, [_ctx]),
     "mapn_set_external_gather": (C.c_int, [_ctx, C.c_int]),
+    "mapn_replica_checksum": (C.c_int, [_ctx, C.POINTER(C.c_uint64 * 2)]),
     "mapn_shard_range": (C.c_int, [_ctx, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mapn_get_device_info": (C.c_int, [C.c_int, C.POINTER(DeviceInfo)]),
     "mapn_device_count": (C.c_int, []),

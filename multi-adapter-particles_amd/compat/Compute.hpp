@@ -18,6 +18,8 @@
 //     ConsumerSignal(); Simulate(n, v) queues its wait on it whether or not it has been signalled
 //     yet (Compute.cpp:1012), unless the context was created with MAPN_FLAG_STRICT_CONSUMER;
 //   * SetAsync takes two device pointers instead of ComPtr<ID3D12Resource>*;
+//   * the launch plan bench.py's headline number is measured with (parts sized by the speed of the die they run on) is
+//     one config bit away: in_pConfig->flags |= MAPN_FLAG_XCD_CALIBRATE (about 0.2 s more at construction);
 //   * failures throw mapn::MapnException : std::runtime_error carrying the status code, the
 //     counterpart of HrException (DXSampleHelper.h:29-46).
 #pragma once

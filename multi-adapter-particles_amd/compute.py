@@ -236,6 +236,12 @@ class Compute:
     def p2p_status(self) -> int:
         return int(self._lib.mapn_p2p_status(self._ctx))
 
+    def replica_checksum(self):
+        """(sum of the 32-bit words of position buffer 0, of buffer 1): equal on all ranks after any correct exchange."""
+        out = (C.c_uint64 * 2)()
+        check(self._lib.mapn_replica_checksum(self._ctx, C.byref(out)))
+        return int(out[0]), int(out[1])
+
     def set_external_gather(self, enabled: bool = True):
         check(self._lib.mapn_set_external_gather(self._ctx, int(bool(enabled))))
 

@@ -43,6 +43,14 @@ int fail(int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                      \
     } while (0)
 
+// Test and experiment hooks (fault injection, loopback modes): honoured only when MAPN_TEST_HOOKS=1 is ALSO set, so that a
+// variable left over in a production environment cannot change what the library does (VERDICT r3 "weak" #9).
+const char *test_hook(const char *name)
+{
+    const char *on = getenv("MAPN_TEST_HOOKS");
+    return (on && on[0] == '1') ? getenv(name) : nullptr;
+}
+
 constexpr uint32_t kBlock = 64;            // defines.h:37 BLOCK_SIZE: granularity of num_active
 constexpr int kTimerRing = 64;             // in-flight step timers
 constexpr int kAverageOver = 20;           // D3D12GpuTimer.h averageOver (Compute.cpp:445)
@@ -239,6 +247,10 @@ int check_async_errors(mapn_ctx *c)
     if (!c->async_status) return MAPN_OK;
     const uint32_t p2p = reinterpret_cast<volatile uint32_t *>(c->async_status)[0];
     const uint32_t cons = reinterpret_cast<volatile uint32_t *>(c->async_status)[1];
+    if (p2p >= 0x200u)
+        return fail(MAPN_ERR_COMM, "sharded symmetric step: the positions rank %u PUSHED into this rank's replica do not match the checksums it stored "
+                    "behind them (stale, torn or misplaced data: its counter overtook its stores, or it went on after a timed-out wait of its own); "
+                    "this rank's position replica is not to be trusted from that step on", p2p - 0x200u);
     if (p2p >= 0x100u)
         return fail(MAPN_ERR_COMM, "sharded symmetric step: a reaction row read after its sender's counter did not carry this exchange's number "
                     "(sender %u places behind this rank on the ring): either that sender went on after a timed-out wait of its own "
@@ -329,14 +341,14 @@ void release_sym(mapn_ctx *c)
 }
 
 // which ranks this rank produces reactions for / receives reactions from: the meeting schedule of
-// force_sym_kernel (I-block a meets a+1 .. a+D, and a+nb/2 when nb is even and a < nb/2), block -> owner
+// force_sym_kernel (I-block a meets a+1 .. a+D, and a+nb/2 when nb is even and a is that pair's runner: sym_runs_half), block -> owner
 void sym_shard_masks(uint32_t nb, uint32_t world, uint32_t rank, uint32_t &send, uint32_t &recv)
 {
     const uint32_t nbl = nb / world, D = (nb - 1u) / 2u, half = (nb & 1u) ? 0u : nb / 2u;
     send = recv = 0;
     for (uint32_t a = 0; a < nb; a++) {
         for (uint32_t d = 1; d <= D + (half ? 1u : 0u); d++) {
-            if (d > D && !(d == half && a < half)) continue;
+            if (d > D && !(d == half && mapn::sym_runs_half(a, half))) continue;
             const uint32_t b = (a + d) % nb, ra = a / nbl, rb = b / nbl;
             if (ra == rank) send |= 1u << rb;
             if (rb == rank) recv |= 1u << ra;
@@ -372,7 +384,7 @@ int prepare_sym(mapn_ctx *c, bool sharded)
     const uint32_t nb = (c->n + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK, nbl = sharded ? c->count / mapn::SYM_BLOCK : nb;
     const uint32_t gsym = (nb - 1u) / 2u + ((nb & 1u) ? 0u : 1u);
     const char *e = getenv("MAPN_SYM_MAX_MB");
-    const bool simulate_failure = getenv("MAPN_SYM_FAIL_ALLOC") != nullptr;     // tests: behave as if hipMalloc had failed
+    const bool simulate_failure = test_hook("MAPN_SYM_FAIL_ALLOC") != nullptr;     // tests: behave as if hipMalloc had failed
     // unsharded: 1 GiB of b-rows by default (1 048 576 bodies: 9 windows, 4 194 304 bodies: 129); sharded: one window, up to 16 GiB
     const uint64_t cap = (e ? strtoull(e, nullptr, 10) : (sharded ? 16384ull : 1024ull)) << 20;
     uint32_t gpw = 0;                                                           // symmetric groups per window (0: all in one)
@@ -594,12 +606,21 @@ bool sym_shard_eligible(const mapn_ctx *c, uint32_t active)
 // Gather algorithm 5: the peers store their new slices into this rank's replica; whoever reads the replica next must first
 // wait for their counters.  The sharded symmetric force launch does that itself; every other reader (a one-sided step, a
 // download, wait_idle) gets this stream operation in front.
+// are the positions of gather algorithm 5 checked against their pushers' checksums (default; MAPN_SYM_PUSH_CHECK=0: the A/B without)
+bool sym_push_check()
+{
+    static const bool on = [] { const char *e = getenv("MAPN_SYM_PUSH_CHECK"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int settle_push(mapn_ctx *c)
 {
     if (!c->push_pending) return MAPN_OK;
     c->push_pending = false;
+    // (the latest step wrote buffer 1 - index: that is where the peers pushed; their checksums are verified as the force launch would)
     HIP_TRY(mapn::launch_p2p_wait(c->p2p_flags + mapn::SYM_POS_BASE, c->sym_pos_epoch * mapn::SYM_COUNT_PER_LAUNCH, (uint32_t)c->cfg.world_size, (uint32_t)c->cfg.rank, c->p2p_loopback ? 1u : 0u,
-                                  c->p2p_timeout_ticks, c->async_status, c->compute));
+                                  c->p2p_timeout_ticks, c->async_status, c->pos[1 - c->buffer_index],
+                                  sym_push_check() ? c->p2p_flags + mapn::sym_region_pos_sums_word((uint32_t)c->cfg.world_size, c->count) : nullptr, c->sym_pos_epoch, c->count, c->compute));
     return MAPN_OK;
 }
 
@@ -627,6 +648,9 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
         // the replica this launch reads was completed by the peers' pushes of the previous step: wait for their counters in the launch
         a.wait_counters = c->p2p_flags + mapn::SYM_POS_BASE; a.wait_status = c->async_status; a.wait_timeout_ticks = c->p2p_timeout_ticks;
         a.wait_need = c->sym_pos_epoch * mapn::SYM_COUNT_PER_LAUNCH; a.wait_world = world; a.wait_rank = rank; a.wait_self = c->p2p_loopback ? 1u : 0u;
+        if (c->push_pending && sym_push_check()) {         // pushes nobody has checked yet (not after an upload: that data is not the peers')
+            a.verify_sums = c->p2p_flags + mapn::sym_region_pos_sums_word(world, c->count); a.verify_epoch = c->sym_pos_epoch; a.verify_count = c->count;
+        }
         c->push_pending = false;
     }
     if (int rc = stamps_prepare(c, (size_t)a.shard_nbl * pl.nwaves, a)) return rc;
@@ -655,13 +679,15 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     // the position counters and the ticket form stays (95.1 against 96.6).  MAPN_SYM_SHARD_CHUNK_FLAGS=0 / 2: never / always (A/B)
     static const int chunk_mode = [] { const char *e = getenv("MAPN_SYM_SHARD_CHUNK_FLAGS"); return e ? atoi(e) : 1; }();
     const bool chunked = chunk_mode == 2 || (chunk_mode == 1 && push);
-    h.chunk_flags = chunked ? (uint32_t)((mapn::SYM_RECV_OFFSET + (size_t)world * c->count * sizeof(float4)) / sizeof(uint32_t)) : 0u;
+    h.chunk_flags = chunked ? (uint32_t)mapn::sym_region_chunk_flags_word(world, c->count) : 0u;
+    h.pos_sums = push && sym_push_check() ? (uint32_t)mapn::sym_region_pos_sums_word(world, c->count) : 0u;
     h.status = c->async_status;
     h.rank = rank; h.world = world; h.count = c->count;
     h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = pl.parts; h.nwaves = pl.nwaves; h.max_meetings = pl.max_meetings; h.sets = pl.sets;
     h.send_mask = c->sym_send_mask; h.recv_mask = c->sym_recv_mask;
     h.step = ++c->sym_shard_step;
     h.pos_step = pull ? ++c->sym_pos_epoch : 0u;
+    if (push) { const char *cp = test_hook("MAPN_TEST_CORRUPT_PUSH"); if (cp && (uint32_t)strtoul(cp, nullptr, 10) == h.pos_step) h.corrupt_push = 1u; }
     c->step_pulled = pull;
     c->push_pending = push;
     h.pull_self = c->p2p_loopback ? 1u : 0u;
@@ -1163,6 +1189,64 @@ int mapn_config_default(mapn_config *cfg)
     return MAPN_OK;
 }
 
+// MAPN_FLAG_XCD_CALIBRATE: measure the dies under the context's OWN state and give the plan their weights; the state, the fence
+// value and the buffer index come back exactly as they were (nothing has been exported yet at creation, so nobody can have seen
+// the steps in between).  Never fatal: where it does not apply the default plan stays and the note is left in mapn_last_error().
+static int calibrate_at_creation(mapn_ctx *c)
+{
+    if (!(c->cfg.flags & MAPN_FLAG_XCD_CALIBRATE)) return MAPN_OK;
+    if (!sym_eligible(c, c->n) || c->sym_plan.nb % 8u != 0u || c->cfg.world_size != 1) {
+        g_last_error = "MAPN_FLAG_XCD_CALIBRATE: XCD weights do not apply to this context (they need the unsharded symmetric kernel and a block count that is a multiple of 8); the default plan runs";
+        return MAPN_OK;
+    }
+    std::vector<float> pos[2], vel[2];
+    for (uint32_t b = 0; b < 2; b++) {
+        pos[b].resize((size_t)c->n * 4); vel[b].resize((size_t)c->n * 3);
+        if (int rc = mapn_download_buffer(c, b, pos[b].data(), vel[b].data())) return rc;
+    }
+    const uint64_t fence = c->fence_value, completed = c->completed;
+    const uint32_t index = c->buffer_index;
+    const bool timers = c->timers_enabled;
+    const float ema = c->ema_seconds;
+    c->timers_enabled = false;
+    // clock ramp: the chip needs a few hundred ms of load before the dies settle at the speeds they hold under this kernel
+    int rc = MAPN_OK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        float ms = 0.f;
+        (void)hipEventRecord(e0, c->compute);
+        for (int burst = 0; burst < 400 && ms < 200.f && !rc; burst++) {
+            for (int k = 0; k < 8 && !rc; k++) rc = mapn_simulate(c, (int)c->n, 0);
+            (void)hipEventRecord(e1, c->compute);
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) break;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipGetLastError();
+    uint32_t w[8];
+    if (!rc) rc = mapn_calibrate_sym_xcds(c, c->n <= 262144u ? 4 : 1, w);
+    if (!rc) rc = mapn_set_sym_xcd_weights(c, w);
+    const std::string note = rc ? "MAPN_FLAG_XCD_CALIBRATE: " + g_last_error + "; the default plan runs" : std::string();
+    if (rc) (void)mapn_set_sym_xcd_weights(c, nullptr);
+    // put everything back
+    rc = mapn_wait_idle(c);
+    for (uint32_t b = 0; b < 2 && !rc; b++) {
+        if (hipMemcpy(c->pos[b], pos[b].data(), (size_t)c->n * 16, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->vel[b], vel[b].data(), (size_t)c->n * 12, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(MAPN_ERR_HIP, "MAPN_FLAG_XCD_CALIBRATE: restoring the state failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    c->fence_value = fence; c->completed = completed; c->buffer_index = index;
+    for (int k = 0; k < kTimerRing; k++) c->fence_event_value[k] = 0;
+    c->exported_value = 0;
+    c->timers_enabled = timers; c->ema_seconds = ema;
+    c->steps_enqueued = 0; c->steps_since_reset = 0; c->force_seconds_sum = 0.0; c->force_launches = 0; c->samples.clear();
+    c->last_launches = 0;
+    drop_graphs(c);
+    if (!rc && !note.empty()) g_last_error = note;
+    return rc;
+}
+
 int mapn_create(const mapn_config *cfg, mapn_ctx **out_ctx)
 {
     if (!out_ctx) return fail(MAPN_ERR_INVALID_ARGUMENT, "mapn_create: out_ctx is null");
@@ -1177,6 +1261,7 @@ int mapn_create(const mapn_config *cfg, mapn_ctx **out_ctx)
         if (rc) fail(rc, "init_variant %d", cfg->init_variant);
         if (!rc) rc = mapn_upload_state(c, pos.data(), vel.data());
     }
+    if (!rc) rc = calibrate_at_creation(c);    // (MAPN_FLAG_XCD_CALIBRATE only; state and fence value come back unchanged)
     if (!rc) rc = mapn_wait_idle(c);           // Compute.cpp:922
     if (!rc) rc = mapn_wait_idle(c);           // Compute.cpp:97
     if (rc) { std::string keep = g_last_error; mapn_destroy(c); g_last_error = keep; *out_ctx = nullptr; return rc; }
@@ -1206,6 +1291,7 @@ int mapn_create_from(const mapn_config *cfg, mapn_ctx *old, mapn_ctx **out_ctx)
     }
     c->buffer_index = old->buffer_index;
     (void)hipSetDevice(c->device);
+    if (!rc) rc = calibrate_at_creation(c);    // (MAPN_FLAG_XCD_CALIBRATE only; the copied state comes back unchanged)
     if (!rc) rc = mapn_wait_idle(c);           // Compute.cpp:354 / :409
     if (!rc) rc = mapn_wait_idle(c);           // Compute.cpp:97
     if (rc) { std::string keep = g_last_error; mapn_destroy(c); g_last_error = keep; *out_ctx = nullptr; return rc; }
@@ -1703,7 +1789,7 @@ int mapn_comm_init(mapn_ctx *c, const void *id128)
     // context joins a ONE-rank communicator, so the step runs its real structure (own-segment
     // kernel, remote-segment kernel, reduce, ncclAllGather launch) at the true shard size; the
     // other ranks' slices are then never refreshed, so results are not a simulation.
-    const char *loop = getenv("MAPN_COMM_LOOPBACK");
+    const char *loop = test_hook("MAPN_COMM_LOOPBACK");
     if (loop && loop[0] == '1' && c->cfg.rank == 0)
         c->comm = mapn::comm_create(id128, 0, 1);
     else
@@ -1743,7 +1829,7 @@ int mapn_set_gather_algorithm(mapn_ctx *c, int algorithm)
         } else {
             HIP_TRY(hipMemset(c->sym_recv, 0, bytes));
             sym_shard_masks(c->n / mapn::SYM_BLOCK, (uint32_t)c->cfg.world_size, (uint32_t)c->cfg.rank, c->sym_send_mask, c->sym_recv_mask);
-            const char *loop = getenv("MAPN_COMM_LOOPBACK");                     // a 1-rank communicator: nobody to exchange with
+            const char *loop = test_hook("MAPN_COMM_LOOPBACK");                     // a 1-rank communicator: nobody to exchange with
             if (loop && loop[0] == '1') { c->sym_send_mask &= 1u << c->cfg.rank; c->sym_recv_mask = 1u << c->cfg.rank; }
         }
     }
@@ -1785,8 +1871,8 @@ int mapn_p2p_export(mapn_ctx *c, void *out_blob)
         // Behind the counters (same allocation, same hipIpc handle): the receive region of the sharded symmetric
         // step, one float4 row per sender rank and body of this rank -- peers store into it, this GPU reads it.
         // ... and behind that the arrival flags of the reaction rows, one word per sender and 256-body chunk
-        const size_t bytes = mapn::SYM_RECV_OFFSET + (size_t)c->cfg.world_size * c->count * sizeof(float4) +
-                             (size_t)c->cfg.world_size * ((c->count + 255u) / 256u) * sizeof(uint32_t);
+        // ... and behind those the checksums of pushed positions, one word per sender and 32 bodies (mapn_kernels.h: sym_region_*)
+        const size_t bytes = mapn::sym_region_bytes((uint32_t)c->cfg.world_size, c->count);
         HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void **>(&c->p2p_flags), bytes, hipDeviceMallocUncached));
         HIP_TRY(hipMemset(c->p2p_flags, 0, bytes));
         HIP_TRY(hipDeviceSynchronize());
@@ -1814,7 +1900,7 @@ int mapn_p2p_import(mapn_ctx *c, const void *blobs, int count)
     // job maps every peer to ITSELF, so a step runs its real kernels at the true shard size (force, send with
     // all its destinations, reduce); the position pull is skipped and only this rank's own row is waited for --
     // the other slices are never refreshed, so results are not a simulation.
-    const char *loop = getenv("MAPN_P2P_LOOPBACK");
+    const char *loop = test_hook("MAPN_P2P_LOOPBACK");
     // MAPN_P2P_LOOPBACK=2 (tests): the same, but nothing is SENT to the other ranks either (their rows would land on this rank's
     // own), so this rank's bodies come out exactly as the schedule says: own meetings plus reactions between own blocks.
     c->p2p_loopback = loop && (loop[0] == '1' || loop[0] == '2');
@@ -1853,6 +1939,19 @@ int mapn_p2p_status(mapn_ctx *c)
     if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
     if (!c->async_status) return 0;
     return (int)reinterpret_cast<volatile uint32_t *>(c->async_status)[0];
+}
+
+int mapn_replica_checksum(mapn_ctx *c, uint64_t out[2])
+{
+    if (!c || !out) return fail(MAPN_ERR_INVALID_ARGUMENT, "replica_checksum: null argument");
+    std::vector<uint32_t> host((size_t)c->n * 4);
+    for (uint32_t b = 0; b < 2; b++) {
+        if (int rc = mapn_download_buffer(c, b, reinterpret_cast<float *>(host.data()), nullptr)) return rc;
+        uint64_t s = 0;
+        for (uint32_t w : host) s += w;
+        out[b] = s;
+    }
+    return MAPN_OK;
 }
 
 int mapn_set_external_gather(mapn_ctx *c, int enabled)
@@ -1946,11 +2045,12 @@ int mapn_set_sym_xcd_weights(mapn_ctx *c, const uint32_t *w)
     if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");
     if (int rc = mapn_wait_idle(c)) return rc;
     HIP_TRY(hipSetDevice(c->device));
+    if (w)                                                 // (validated BEFORE anything is touched: ADVICE r3)
+        for (int k = 0; k < 8; k++)
+            if (w[k] == 0u || w[k] > 4096u) return fail(MAPN_ERR_INVALID_ARGUMENT, "set_sym_xcd_weights: weights must be 1 .. 4096 (1024 = the fastest die)");
     c->sym_xcd_weighted = false;
-    if (w) {
+    if (w)
         for (int k = 0; k < 8; k++) { c->sym_xcd_w[k] = w[k]; c->sym_xcd_weighted = c->sym_xcd_weighted || w[k] != w[0]; }
-        for (int k = 0; k < 8; k++) if (w[k] == 0u) return fail(MAPN_ERR_INVALID_ARGUMENT, "set_sym_xcd_weights: a weight is zero");
-    }
     if (!c->sym_ready) return MAPN_OK;                     // (kept for when the symmetric step is prepared: a sharded context before algorithm 4 / 5 / 6)
     drop_graphs(c);
     const bool sharded = c->sym_sharded;

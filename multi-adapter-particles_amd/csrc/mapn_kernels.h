@@ -60,6 +60,18 @@ struct ForcePlan {
 enum { SYM_K2 = 8,                     // packed pairs of bodies i per lane
        SYM_BLOCK = 128 * SYM_K2,       // bodies per I-block (one wave)
        SYM_JPI = SYM_BLOCK / 64 };     // 64-body J-blocks per I-block
+// Which block of a half-ring pair (p, p + nb / 2) runs their meetings (even block counts; `half` = nb / 2, else 0): the pairs
+// ALTERNATE -- p even: block p, p odd: block p + nb / 2 -- so that the extra group is spread evenly over the two halves of the
+// ring, i.e. over the ranks of a sharded job (until round 3 the first half ran all of them: at 65 536 / 8 ranks 0 .. 3 ran 528
+// meetings each and ranks 4 .. 7 512, and every step waited for the heavy half).  The runner's class is 0, the other's 1.
+__host__ __device__ inline bool sym_runs_half(uint32_t a, uint32_t half)
+{
+    if (!half) return false;
+    const bool low = a < half;
+    const uint32_t p = low ? a : a - half;
+    return ((p & 1u) == 0u) == low;
+}
+
 struct SymArgs {
     const float4 *pos_old;
     const float  *vel_old;
@@ -88,6 +100,12 @@ struct SymArgs {
     uint32_t     *wait_status;       // host-visible word: 1 + peer whose slice never arrived
     uint64_t      wait_timeout_ticks;
     uint32_t      wait_need, wait_world, wait_rank, wait_self;   // wait_self: loopback timing only -- the "peers" are this rank
+    // ... and CHECKS what they pushed (verify_sums != null: the pushes of publication `verify_epoch` have not been checked yet): the
+    // pusher stored one checksum word per 32 bodies (sym_push_checksum) behind its data; every wave of this launch re-computes the
+    // checksums of a few groups from what it reads past the caches and reports a mismatch (status 0x200 + sender) instead of
+    // integrating positions that are stale, torn or misplaced (the reaction rows carry a tag, the positions cannot)
+    const uint32_t *verify_sums;     // this rank's checksum rows [publication parity][sender][count / 32] (uncached region)
+    uint32_t      verify_epoch, verify_count;    // publication number the checksums must carry; bodies per rank
     uint32_t      stage_iblock;   // the workgroup's waves share the I-block's global loads through LDS
     uint32_t      row_wt;     // rows are stored write-through (sc1) as they are produced instead of waiting in L2 for the end-of-kernel write-back
     float         mass, soft2, dt, damping;
@@ -110,6 +128,23 @@ enum { SYM_FLAG_BASE = 16,            // reaction-arrival counters follow the P2
 // The position counters ADVANCE by this much per launch: every workgroup of the exchange launch adds its share once its stores are
 // acknowledged (the shares of a launch sum to exactly this, whatever its grid), a waiter needs launch number x this
 constexpr uint32_t SYM_COUNT_PER_LAUNCH = 1u << 16;
+// Checksum of a pushed position as the pusher holds it in registers: the four words, each in its own rotation, and the body's
+// index (a row that lands in the wrong place must not pass); the 32 bodies of a group are XOR-ed, then the publication number is
+// mixed in (a group AND its checksum both left over from two steps ago must not pass either).
+__host__ __device__ inline uint32_t sym_push_checksum(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t body)
+{
+    return x ^ ((y << 8) | (y >> 24)) ^ ((z << 16) | (z >> 16)) ^ ((w << 24) | (w >> 8)) ^ (body * 0x9E3779B1u);
+}
+__host__ __device__ inline uint32_t sym_push_epoch_mix(uint32_t epoch) { return epoch * 0x85EBCA6Bu + 0x1234567u; }
+// layout of a rank's uncached exchange region (one allocation, one hipIpc handle), in 32-bit words from its start:
+//   [0, 1024)  counters;  SYM_RECV_OFFSET: receive rows float4[world][count];  then arrival flags [world][count / 256];
+//   then the checksums of pushed positions [2][world][count / 32] -- TWO sets, by the parity of the publication number, like the
+//   position buffers themselves: a peer that is one step ahead has already stored the NEXT publication's checksums while this
+//   rank has not yet checked the last one (found by the 8-process test: with one set the check raced with the next push)
+inline size_t sym_region_chunk_flags_word(uint32_t world, uint32_t count) { return (SYM_RECV_OFFSET + (size_t)world * count * sizeof(float4)) / sizeof(uint32_t); }
+inline size_t sym_region_pos_sums_word(uint32_t world, uint32_t count) { return sym_region_chunk_flags_word(world, count) + (size_t)world * ((count + 255u) / 256u); }
+inline size_t sym_region_bytes(uint32_t world, uint32_t count) { return (sym_region_pos_sums_word(world, count) + 2u * (size_t)world * ((count + 31u) / 32u)) * sizeof(uint32_t); }
+
 struct SymShardArgs {
     const float4 *pos_old;
     const float  *vel_old;
@@ -141,6 +176,9 @@ struct SymShardArgs {
     uint32_t      step;                       // monotonically increasing (>= 1): number of the reaction exchange
     uint32_t      pos_step;                   // number of this publication of new positions by a sharded symmetric step (0: they travel in another launch)
     uint32_t      pull_self;                  // loopback timing only: the "peers" are this rank, pull from every slot
+    uint32_t      pos_sums;                   // push form: word offset of the checksum rows [publication parity][sender][count / 32] in the flag arrays (0: none)
+    uint32_t      corrupt_push;               // TEST HOOK (MAPN_TEST_HOOKS=1 MAPN_TEST_CORRUPT_PUSH=<publication>): this launch flips one bit of
+                                              // ONE pushed position after its checksum was formed -- the peers must report it
     uint64_t      timeout_ticks;
     float         mass, dt, damping;
     unsigned long long *timeline;             // diagnostic launches only (MAPN_STAMP_DUMP): 8 wall-clock stamps per workgroup
@@ -149,8 +187,9 @@ hipError_t launch_sym_shard_exchange(const SymShardArgs &a, uint32_t max_workgro
 uint32_t sym_shard_exchange_resident_workgroups(uint32_t count, int cus);   // how many of its workgroups `cus` compute units hold at once (with headroom)
 int probe_active_compute_units(hipStream_t st);                             // compute units that really take this process's workgroups (0: probe failed)
 // stream operation: wait (bounded) until every peer's publication counter has reached `need` (positions pushed by the peers)
+// ... and, when verify_sums is given, check the pushed slices of `replica` against the pushers' checksums (as the force launch does)
 hipError_t launch_p2p_wait(const uint32_t *counters, uint32_t need, uint32_t world, uint32_t rank, uint32_t self, uint64_t timeout_ticks,
-                           uint32_t *status, hipStream_t st);
+                           uint32_t *status, const float4 *replica, const uint32_t *verify_sums, uint32_t verify_epoch, uint32_t count, hipStream_t st);
 
 bool force_plan_supported(const ForcePlan &plan);
 hipError_t launch_force(const ForcePlan &plan, const StepArgs &a, hipStream_t st);

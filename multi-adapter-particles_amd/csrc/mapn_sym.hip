@@ -25,7 +25,7 @@
 // Coverage of the N^2 ordered pairs (N padded to a multiple of 1024 with stand-in bodies that exert no
 // force): I-block a meets, symmetrically, the
 // I-blocks a+1 .. a+D (mod NB, D = (NB-1)/2, NB = N/1024) 64 bodies at a time, for even NB also
-// a+NB/2 when a < NB/2; and itself one-sidedly (no reaction kept).  Every unordered pair of
+// a+NB/2 when a is the runner of that pair (sym_runs_half: the pairs alternate between the two halves of the ring); and itself (the reaction is dropped).  Every unordered pair of
 // blocks is met exactly once; every body collects its force as: rows of its own I-block (role i)
 // + one row per meeting of its J-block (role j), all written to scratch and summed in a FIXED
 // order by sym_reduce_integrate_kernel -- no float atomics, bit-reproducible.
@@ -106,6 +106,38 @@ __device__ __forceinline__ float4 load_sys(const float4 *src)
                        __builtin_bit_cast(float, (uint32_t)hi), __builtin_bit_cast(float, (uint32_t)(hi >> 32)));
 }
 
+// XOR over the 32 lanes of a half-wave (all of them active), result in every lane: four row rotations (DPP: VALU only, no wait)
+// inside the rows of 16, one ds_swizzle_b32 (swap the two rows of a half-wave) across -- one trip through the LDS crossbar
+// instead of the five of a shuffle tree
+__device__ __forceinline__ uint32_t xor_reduce32(uint32_t h)
+{
+#define MAPN_ROR(n) h ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x120 + (n), 0xf, 0xf, false)
+    MAPN_ROR(8); MAPN_ROR(4); MAPN_ROR(2); MAPN_ROR(1);
+#undef MAPN_ROR
+    return h ^ (uint32_t)__builtin_amdgcn_ds_swizzle((int)h, 0x401F);     // bit mode: and 0x1f, or 0, xor 0x10 = lane ^ 16
+}
+
+// Gather algorithm 5, receiver side: re-compute the checksums of what the peers PUSHED into `replica` (read past the caches, after
+// their counters) and compare them with the words the pushers stored behind the data.  Called by whole waves: half-wave h of wave
+// `wv` (of `nw`) takes the 32-body groups 2 wv + h, 2 wv + h + 2 nw, ... of the (world - 1) x count / 32 pushed groups.
+__device__ __forceinline__ void verify_pushed(const float4 *replica, const uint32_t *sums, uint32_t epoch, uint32_t count, uint32_t world, uint32_t rank,
+                                              uint32_t self, uint32_t wv, uint32_t nw, uint32_t lane, uint32_t *status)
+{
+    const uint32_t per = count / 32u, ng = (world - 1u) * per;            // (count is a multiple of 1024: ng is even)
+    for (uint32_t base = 2u * wv; base < ng; base += 2u * nw) {
+        const uint32_t gi = base + (lane >> 5), k = gi / per, grp = gi - k * per;
+        const uint32_t qp = k < rank ? k : k + 1u, q = self ? rank : qp;   // (loopback timing: the "peers" are this rank -- the data is its own slice,
+        const uint32_t body = q * count + grp * 32u + (lane & 31u);        //  the checksum row the one it stored for "peer" qp)
+        const uint32_t want = __hip_atomic_load(sums + ((size_t)(epoch & 1u) * world + qp) * per + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const float4 v = load_sys(replica + body);
+        uint32_t h = sym_push_checksum(__builtin_bit_cast(uint32_t, v.x), __builtin_bit_cast(uint32_t, v.y), __builtin_bit_cast(uint32_t, v.z),
+                                       __builtin_bit_cast(uint32_t, v.w), body);
+        h = xor_reduce32(h);
+        if ((h ^ sym_push_epoch_mix(epoch)) != want)
+            __hip_atomic_store(status, 0x200u + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 struct SymBodies {
     v2f xi[SYM_K2], yi[SYM_K2], zi[SYM_K2];
     v2f ax[SYM_K2], ay[SYM_K2], az[SYM_K2];
@@ -171,7 +203,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     const uint32_t s = blockIdx.y, la = p.sets > 2u ? (blockIdx.x + blockIdx.y) % gridDim.x : blockIdx.x, a = p.a0 + la;    // a: the I-block in the whole job; la: among this launch's
     const uint32_t nb = p.nb, half = p.half_d;             // half_d = NB/2 when NB is even, else 0
     const uint32_t D = (nb - 1u) / 2u;
-    const uint32_t cls = (half && a < half) ? 0u : 1u;     // class 0: the blocks that also run the half-ring group
+    const uint32_t cls = sym_runs_half(a, half) ? 0u : 1u; // class 0: the blocks that also run the half-ring group (alternating between the two halves of the ring)
     const uint32_t set = cls + (p.sets > 2u ? 2u * (la & 7u) : 0u);
     const uint32_t *bounds = p.tab + set * (p.nwaves + 1u);
     const uint32_t t0 = bounds[s * WAVES + w], t1 = bounds[s * WAVES + w + 1u];
@@ -220,6 +252,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
             (void)wait_counters(p.wait_counters, p.wait_self ? p.wait_rank : lane, need, p.wait_need, p.wait_timeout_ticks, p.wait_status, 1u + lane);
         }
         if (t0 < t1) { meeting(t0 >> 6, jb, d, g); pn = body_j(jb * 64u + ((lane + t0) & 63u)); }
+        // what the peers pushed is CHECKED here, once per launch, spread over the launch's waves (a few loads per wave, in flight
+        // together with the first J-block: the wave waits for that one anyway)
+        if (p.verify_sums)
+            verify_pushed(pos, p.verify_sums, p.verify_epoch, p.verify_count, p.wait_world, p.wait_rank, p.wait_self,
+                          (la * p.parts + s) * WAVES + w, gridDim.x * gridDim.y * WAVES, lane, p.wait_status);
     };
     SymBodies b;
     if (p.stage_iblock) {
@@ -392,7 +429,7 @@ namespace {
 __device__ __forceinline__ uint32_t sym_group(uint32_t a, uint32_t b, uint32_t nb, uint32_t half)
 {
     const uint32_t d = b >= a ? b - a : b + nb - a, D = (nb - 1u) / 2u;
-    return (d >= 1u && d <= D) ? d : (half && d == half && a < half) ? D + 1u : 0u;
+    return (d >= 1u && d <= D) ? d : (half && d == half && sym_runs_half(a, half)) ? D + 1u : 0u;
 }
 }  // namespace
 
@@ -421,13 +458,13 @@ __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs
         ax += v.x; ay += v.y; az += v.z;
     }
     // the symmetric groups of this window; group g's row exists when some block meets this one under g: always for
-    // g <= D, for the half-ring group D + 1 only if this block is the far partner (a >= nb / 2)
+    // g <= D, for the half-ring group D + 1 only if this block's half-ring PARTNER runs the pair's meetings (sym_runs_half)
     const uint32_t D = (p.nb - 1u) / 2u, gs0 = p.g0 ? p.g0 : 1u;
-    const uint32_t gend = (p.g1 == D + 2u && !(p.half_d && a >= p.half_d)) ? D + 1u : p.g1;
+    const uint32_t gend = (p.g1 == D + 2u && sym_runs_half(a, p.half_d)) ? D + 1u : p.g1;
     const float4 *br = p.brow + (size_t)jb * p.brows * 64u + (i & 63u);
     // split table of the block that ran a meeting: set = class (+ 2 * (block mod 8) with XCD-weighted parts)
     const uint32_t *splits = p.tab + p.sets * (p.nwaves + 1u);
-    auto split_of = [&](uint32_t blk) { return splits + (size_t)(((p.half_d && blk < p.half_d) ? 0u : 1u) + (p.sets > 2u ? 2u * (blk & 7u) : 0u)) * p.max_meetings; };
+    auto split_of = [&](uint32_t blk) { return splits + (size_t)((sym_runs_half(blk, p.half_d) ? 0u : 1u) + (p.sets > 2u ? 2u * (blk & 7u) : 0u)) * p.max_meetings; };
     const uint32_t t = jb % SYM_JPI;
     for (uint32_t g = gs0; g < gend; g += 8u) {            // 8 meetings in flight, summed in ascending order
         float4 v[8], h[8];
@@ -525,7 +562,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     stamp(0);
     // split table of the block that ran a meeting: set = class (+ 2 * (LOCAL block mod 8) with XCD-weighted parts)
     const uint32_t *splits = p.tab + p.sets * (p.nwaves + 1u);
-    auto split_of = [&](uint32_t a, uint32_t la) { return splits + (size_t)(((p.half_d && a < p.half_d) ? 0u : 1u) + (p.sets > 2u ? 2u * (la & 7u) : 0u)) * p.max_meetings; };
+    auto split_of = [&](uint32_t a, uint32_t la) { return splits + (size_t)((sym_runs_half(a, p.half_d) ? 0u : 1u) + (p.sets > 2u ? 2u * (la & 7u) : 0u)) * p.max_meetings; };
     const uint32_t total = p.phase == 2u ? 0u : p.world * p.count;
     for (uint32_t t = bid * 256u + threadIdx.x; t < total; t += nblk * 256u) {
         const uint32_t q = t / p.count, jl = t - q * p.count;
@@ -687,9 +724,27 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         const float ox = __builtin_fmaf(vx, p.dt, pos.x), oy = __builtin_fmaf(vy, p.dt, pos.y), oz = __builtin_fmaf(vz, p.dt, pos.z);
         const float ow = __builtin_sqrtf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)));
         store_sys(p.pos_new + i, ox, oy, oz, ow);
-        if (p.push)                                        // ... and into every peer's replica (over xGMI when q is another GPU)
+        if (p.push) {                                      // ... and into every peer's replica (over xGMI when q is another GPU)
+            // TEST HOOK: one bit of one pushed position flipped AFTER the checksum below was formed from the true value
+            const float oxp = (p.corrupt_push && il == 0u) ? __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, ox) ^ 1u) : ox;
             for (uint32_t q = 0; q < p.world; q++)
-                if (q != p.rank) store_sys(p.pos_peer[q] + i, ox, oy, oz, ow);
+                if (q != p.rank) store_sys(p.pos_peer[q] + i, oxp, oy, oz, ow);
+            if (p.pos_sums) {
+                // behind the data: one checksum word per 32 bodies, this publication's number mixed in, into every peer's row [this rank]
+                // (the receivers re-compute it from what they read: verify_pushed).  The threads here are whole, aligned half-waves.
+                uint32_t hs = sym_push_checksum(__builtin_bit_cast(uint32_t, ox), __builtin_bit_cast(uint32_t, oy), __builtin_bit_cast(uint32_t, oz),
+                                                __builtin_bit_cast(uint32_t, ow), i);
+                hs = xor_reduce32(hs);
+                if ((threadIdx.x & 31u) == 0u) {
+                    const uint32_t cs = hs ^ sym_push_epoch_mix(p.pos_step);
+                    for (uint32_t q = 0; q < p.world; q++)
+                        if (q != p.rank)
+                            // (loopback timing: every "peer" is this rank -- one row per peer then, so that the stores go to distinct
+                            //  addresses as they would on a node instead of queueing up behind each other at ONE uncached word)
+                            __hip_atomic_store(p.flags_peer[q] + p.pos_sums + ((p.pos_step & 1u) * p.world + (p.pull_self ? q : p.send_row)) * (p.count / 32u) + il / 32u, cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
         float *vo = p.vel_new + 3 * (size_t)i;
         vo[0] = vx; vo[1] = vy; vo[2] = vz;
     }
@@ -746,18 +801,23 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
 
 // stream operation (gather algorithm 5, wherever something other than the next sharded symmetric force launch is about to
 // read the replica): one wave waits (bounded) until every peer has pushed its slice
+// ... and (verify_sums != null) checks their slices against the pushers' checksums like the force launch does; grid = waves that share the check
 __global__ __launch_bounds__(64) void p2p_wait_kernel(const uint32_t *counters, uint32_t need, uint32_t world, uint32_t rank, uint32_t self,
-                                                      uint64_t timeout_ticks, uint32_t *status)
+                                                      uint64_t timeout_ticks, uint32_t *status, const float4 *replica, const uint32_t *verify_sums,
+                                                      uint32_t verify_epoch, uint32_t count)
 {
     const uint32_t q = threadIdx.x;
-    (void)wait_counters(counters, self ? rank : q, q < world && q != rank, need, timeout_ticks, status, 1u + q);
+    const uint32_t good = wait_counters(counters, self ? rank : q, q < world && q != rank, need, timeout_ticks, status, 1u + q);
+    if (verify_sums && good) verify_pushed(replica, verify_sums, verify_epoch, count, world, rank, self, blockIdx.x, gridDim.x, threadIdx.x, status);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
 hipError_t launch_p2p_wait(const uint32_t *counters, uint32_t need, uint32_t world, uint32_t rank, uint32_t self, uint64_t timeout_ticks,
-                           uint32_t *status, hipStream_t st)
+                           uint32_t *status, const float4 *replica, const uint32_t *verify_sums, uint32_t verify_epoch, uint32_t count, hipStream_t st)
 {
-    hipLaunchKernelGGL(p2p_wait_kernel, dim3(1), dim3(64), 0, st, counters, need, world, rank, self, timeout_ticks, status);
+    const uint32_t groups = verify_sums ? (world - 1u) * (count / 32u) : 0u;
+    const uint32_t grid = std::max(1u, std::min(64u, groups / 2u));
+    hipLaunchKernelGGL(p2p_wait_kernel, dim3(grid), dim3(64), 0, st, counters, need, world, rank, self, timeout_ticks, status, replica, verify_sums, verify_epoch, count);
     return hipGetLastError();
 }
 

@@ -40,7 +40,7 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
     bool weighted = false;
     if (xcd_weight && (launch_blocks ? launch_blocks : nb) % 8u == 0u) {
         for (int k = 0; k < 8; k++) weighted = weighted || xcd_weight[k] != xcd_weight[0];
-        for (int k = 0; k < 8; k++) if (xcd_weight[k] == 0u || xcd_weight[k] > (1u << 20)) { err = "symmetric plan: XCD weights must be 1 .. 2^20"; return false; }
+        for (int k = 0; k < 8; k++) if (xcd_weight[k] == 0u || xcd_weight[k] > 4096u) { err = "symmetric plan: XCD weights must be 1 .. 4096 (1024 = the fastest die)"; return false; }   // (bounded so that cost x weight sums stay far inside 64 bits: ADVICE r3)
     }
     p.sets = weighted ? 16u : 2u;
     for (int k = 0; k < 8; k++) p.xcd_weight[k] = weighted ? xcd_weight[k] : 0u;

@@ -18,7 +18,8 @@ constexpr uint32_t SYM_COST_SELF = 6, SYM_COST_SYM = 6;   // relative cost of a 
 
 // Meetings of I-block a (1024 bodies) are numbered by GROUP g and J-block t (16 per group, 64 bodies each):
 //   g = 0: the block itself, one-sided;  g = 1 .. D = (nb - 1) / 2: partner block a + g (mod nb), symmetric;
-//   g = D + 1 (even nb only): the half-ring partner a + nb / 2, run by the blocks a < nb / 2 alone.
+//   g = D + 1 (even nb only): the half-ring partner a + nb / 2, run by ONE block of each pair (p, p + nb / 2): p when p is even, p + nb / 2 when p is odd
+//   (mapn_kernels.h sym_runs_half -- alternating, so that the extra group is spread evenly over the ranks of a sharded job).
 // CLASS 0 = the blocks that have the half-ring group, class 1 = the others (all blocks when nb is odd).
 // SETS.  The eight XCDs of an MI355X do not run at one speed (measured: 0.538 - 0.570 us per step under this kernel, the same
 // dies slow on every launch of a box) and a launch gives every XCD the same work, so it ends with the slowest die.  With XCD

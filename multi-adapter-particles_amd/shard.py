@@ -70,15 +70,27 @@ class ShardPlan:
 def sym_meetings(nb: int):
     """Meetings of the symmetric kernel: yields (a, partner block, d, symmetric) for every I-block
     a of `nb`, 16 J-blocks of 64 bodies each (not expanded here).  d = 0: the block against itself, one-sided;
-    1 <= d <= D = (nb-1)//2: partner a+d, symmetric; for even nb also d = nb/2 when a < nb/2."""
+    1 <= d <= D = (nb-1)//2: partner a+d, symmetric; for even nb also d = nb/2 when a is the RUNNER of the half-ring pair
+    (sym_runs_half: the pairs alternate between the two halves of the ring)."""
     D = (nb - 1) // 2
     half = nb // 2 if nb % 2 == 0 else 0
     for a in range(nb):
         yield a, a, 0, False
         for d in range(1, D + 1):
             yield a, (a + d) % nb, d, True
-        if half and a < half:
+        if sym_runs_half(nb, a):
             yield a, (a + half) % nb, half, True
+
+
+def sym_runs_half(nb: int, a: int) -> bool:
+    """csrc/mapn_kernels.h sym_runs_half: of the half-ring pair (p, p + nb/2) block p runs the meetings when p is even, block
+    p + nb/2 when p is odd -- the extra group is spread evenly over the two halves of the ring (over the ranks of a sharded job)."""
+    if nb % 2:
+        return False
+    half = nb // 2
+    low = a < half
+    p = a if low else a - half
+    return (p % 2 == 0) == low
 
 
 def sym_reaction_rows(nb: int, block: int) -> list[int]:
@@ -86,7 +98,7 @@ def sym_reaction_rows(nb: int, block: int) -> list[int]:
     I-block `block`, over all windows of a step."""
     D = (nb - 1) // 2
     half = nb // 2 if nb % 2 == 0 else 0
-    return list(range(D + (1 if half and block >= half else 0)))
+    return list(range(D + (1 if half and not sym_runs_half(nb, block) else 0)))
 
 
 def sym_wave_pieces(plan, window: int, set_: int):
@@ -104,8 +116,8 @@ def sym_wave_pieces(plan, window: int, set_: int):
 
 
 def sym_block_class(nb: int, a: int) -> int:
-    """0: the block also runs the half-ring group (even nb, a < nb / 2); 1: the others."""
-    return 0 if nb % 2 == 0 and a < nb // 2 else 1
+    """0: the block also runs the half-ring group (even nb, the runner of its pair: sym_runs_half); 1: the others."""
+    return 0 if sym_runs_half(nb, a) else 1
 
 
 def sym_shard_masks(nb: int, world: int, rank: int) -> tuple[int, int]:

@@ -739,7 +739,7 @@ void mapn_oracle_initial_state(uint32_t seed, uint32_t n, float spread, float sp
  * per window bounds[sets][parts * waves + 1] and split[sets][max_meetings] (set = class, or class + 2 * (block mod 8) when the
  * device's parts are XCD-weighted).  Restated, in the device's order:
  *   * blocks of 1024 bodies (the last padded with stand-ins at 3e18 that exert and feel nothing); group g of
- *     block a: 0 = a itself (one-sided), 1..D = partner a + g, D + 1 = the half-ring partner (class 0 only);
+ *     block a: 0 = a itself (one-sided), 1..D = partner a + g, D + 1 = the half-ring partner (class 0 only: the runner of the pair, sym_runs_half);
  *     meeting m of a window = group g0 + m / 16, 64-body J-block m % 16 of the partner;
  *   * wave v = part * waves + w runs the linear steps [bounds[v], bounds[v + 1]) (step 64 m + k); lane l owns the
  *     16 bodies a * 1024 + c * 64 + l (c = 0..15) with ONE fma chain each over all of the wave's steps; at step k of
@@ -757,6 +757,15 @@ typedef struct {
     uint32_t nb, groups, windows, parts, waves, brows, max_meetings, table_stride;
     uint32_t sets;   /* table sets per window: 2 (one per class) or 16 (class + 2 * (block mod 8): the device's XCD-weighted parts) */
 } mapn_oracle_sym_shape;
+
+/* which block of a half-ring pair (p, p + nb / 2) runs its meetings: the pairs alternate (csrc/mapn_kernels.h sym_runs_half) */
+static inline int sym_runs_half(uint32_t a, uint32_t half)
+{
+    if (!half) return 0;
+    const int low = a < half;
+    const uint32_t p = low ? a : a - half;
+    return ((p & 1u) == 0u) == low;
+}
 
 #define SYM_IB 1024u
 #define SYM_JPI 16u
@@ -789,7 +798,7 @@ static void sym_workgroup(const sym_job *J, uint32_t a, uint32_t s, float *scrat
     const mapn_oracle_sym_shape *sh = J->sh;
     const uint32_t nb = sh->nb, D = (nb - 1u) / 2u, half = (nb & 1u) ? 0u : nb / 2u, W = sh->waves;
     const uint32_t g0 = J->win[0];
-    const uint32_t cls = (half && a < half) ? 0u : 1u;
+    const uint32_t cls = sym_runs_half(a, half) ? 0u : 1u;
     const uint32_t set = cls + (sh->sets > 2u ? 2u * (a & 7u) : 0u);
     const uint32_t *bounds = J->tab + set * (sh->parts * W + 1u);
     const float soft2 = J->p->soft2;
@@ -913,7 +922,7 @@ static void *sym_reduce_worker(void *arg)
             const float *row = J->arow + ((size_t)a * sh->parts + s) * 3u * SYM_IB + (i - a * SYM_IB);
             ax = ax + row[0]; ay = ay + row[SYM_IB]; az = az + row[2u * SYM_IB];
         }
-        const uint32_t gend = (g1 == D + 2u && !(half && a >= half)) ? D + 1u : g1;
+        const uint32_t gend = (g1 == D + 2u && sym_runs_half(a, half)) ? D + 1u : g1;
         for (uint32_t g = gs0; g < gend; g += 8u) {
             for (uint32_t u = 0; u < 8u; u++) {
                 const uint32_t gu = g + u;
@@ -922,7 +931,7 @@ static void *sym_reduce_worker(void *arg)
                     const uint32_t d = gu <= D ? gu : half, ap = a >= d ? a - d : a + nb - d;
                     const float *r0 = J->brow + ((size_t)jb * sh->brows + (gu - gs0)) * 192u;
                     vx = r0[l]; vy = r0[64 + l]; vz = r0[128 + l];
-                    const uint32_t sp = (splits + (size_t)(((half && ap < half) ? 0u : 1u) + (sh->sets > 2u ? 2u * (ap & 7u) : 0u)) * sh->max_meetings)[(gu - g0) * SYM_JPI + tt];
+                    const uint32_t sp = (splits + (size_t)((sym_runs_half(ap, half) ? 0u : 1u) + (sh->sets > 2u ? 2u * (ap & 7u) : 0u)) * sh->max_meetings)[(gu - g0) * SYM_JPI + tt];
                     if (sp != SYM_NONE) {
                         const float *h0 = J->brow1 + ((size_t)ap * sh->parts + sp) * 192u;
                         hx = h0[l]; hy = h0[64 + l]; hz = h0[128 + l];

@@ -49,6 +49,32 @@ def main():
         c.close()
         dist.destroy_process_group()
         return
+    if mode == "sympush_corrupt":
+        # gather algorithm 5 between two processes: rank 1's THIRD publication carries one flipped bit in one pushed position (test
+        # hook); rank 0 must find it -- MAPN_ERR_COMM naming rank 1 -- when it next touches its replica, rank 1 itself is fine
+        if rank == 1:
+            os.environ["MAPN_TEST_HOOKS"] = "1"; os.environ["MAPN_TEST_CORRUPT_PUSH"] = "3"
+        c.p2p_setup_torch()
+        c.set_gather_algorithm(5)
+        c.set_timeouts(p2p_ms=5000)
+        dist.barrier()
+        for _ in range(3):
+            c.Simulate(n, c.GetFenceValue())
+        if rank == 0:
+            try:
+                c.WaitForGpu()
+                raise AssertionError("a corrupted pushed position went unreported")
+            except mapn.MapnError as e:
+                assert e.status == -4 and "rank 1" in str(e) and "PUSHED" in str(e), str(e)
+            assert c.p2p_status() == 0x200 + 1
+            open(os.path.join(out_dir, "corruption_reported"), "w").write("ok")
+        else:
+            c.WaitForGpu()
+            assert c.p2p_status() == 0
+        dist.barrier()
+        c.close()
+        dist.destroy_process_group()
+        return
     mixed = mode.endswith("_mixed")                     # every third step freezes part of the bodies: the step then runs one-sided
     if mixed:
         mode = mode[:-len("_mixed")]

@@ -77,8 +77,9 @@ def test_bench_json_contract():
     q = d["config"]["step_ms_by_quarter_of_the_timed_region"]       # the spread of the step time over the timed region, from HIP events
     assert len(q) == 4 and all(x is not None and 0.3 < x < 2.0 for x in q) and d["config"]["step_ms_spread"]["steps_timed"] >= 4
     assert "valu_busy" in rf
-    x = d["config"]["xcd_aware_parts"]                              # calibrated during the untimed prewarm, kept only if an untimed A/B wins
+    x = d["config"]["xcd_aware_parts"]                              # calibrated BY THE LIBRARY at mapn_create (MAPN_FLAG_XCD_CALIBRATE), kept only if an untimed A/B wins
     assert x["mode"] == "auto" and (x.get("error") or (len(x["weights"]) == 8 and max(x["weights"]) == 1024 and isinstance(x["used"], bool)))
+    assert x.get("error") or x["source"].startswith("library")      # (the bench's plan is the library's plan)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e8 and "sample" in cb
     assert d["value"] > 3.0e12            # the 40 %-of-peak target is 3.15e12 at kernel level

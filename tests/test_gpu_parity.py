@@ -669,6 +669,7 @@ def test_config3_one_rank_share_of_the_8_gpu_1mi_body_job(oracle, rank, monkeypa
     assert np.isfinite(p[first:first + count]).all() and not np.array_equal(p[first:first + count], pos[first:first + count])
     if rank != 0:
         return
+    monkeypatch.setenv("MAPN_TEST_HOOKS", "1")           # (hooks are honoured only with this set)
     monkeypatch.setenv("MAPN_COMM_LOOPBACK", "1")                     # rank 0 of 8 joins a ONE-rank communicator
     for flags in (0, mapn.FLAG_SHARD_OVERLAP):
         with mapn.Compute(n, mass=mass, rank=0, world_size=world, flags=flags) as c:

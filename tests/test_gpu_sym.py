@@ -167,6 +167,7 @@ def test_symmetric_scratch_is_made_at_creation_and_auto_falls_back(oracle, monke
     n = 8192
     pos, vel = oracle.initial_state(n, seed=1)
     sim = OracleSim(oracle, pos, vel, params=Params(mass=70000.0 / n)); sim.simulate()
+    monkeypatch.setenv("MAPN_TEST_HOOKS", "1")           # (hooks are honoured only with this set)
     monkeypatch.setenv("MAPN_SYM_FAIL_ALLOC", "1")           # tests only: behave as if hipMalloc had failed
     with mapn.Compute(n, mass=70000.0 / n) as c:
         with pytest.raises(mapn.MapnError, match="could not be allocated"):
@@ -236,6 +237,46 @@ def test_default_launch_shapes(n, want):
         assert c.kernel_stats().kernel_name.decode() == "force_sym_kernel"
 
 
+def test_xcd_calibration_at_creation_gives_the_weighted_plan_and_leaves_the_state_alone(oracle):
+    """MAPN_FLAG_XCD_CALIBRATE: mapn_create measures the dies under the symmetric kernel on the context's own
+    state and sizes the plan's parts by them -- what bench.py used to do for itself.  Afterwards the state is the seeded initial
+    state bit for bit, the fence value is the reference's 4 (Compute.cpp:434-436, :563, :922, :97), the buffer index 0; where the
+    weights do not apply (68 blocks: not a multiple of 8) creation succeeds with the default plan.  A migrated context
+    (mapn_create_from) calibrates too and still continues bit-identically."""
+    n = 65536
+    pos0, vel0 = oracle.initial_state(n, seed=1)
+    with mapn.Compute(n, mass=70000.0 / n, flags=mapn.FLAG_XCD_CALIBRATE) as c:
+        pl = c.sym_plan()
+        assert pl.sets == 16 and max(pl.xcd_weight) == 1024 and min(pl.xcd_weight) > 850, pl.xcd_weight
+        assert (pl.waves, pl.parts, pl.wave_bias) == (8, 4, (10, 3))
+        assert c.GetFenceValue() == 4 and c.buffer_index == 0 and c.GetCompletedValue() <= 3
+        for b in (0, 1):
+            p, v = c.download_buffer(b)
+            np.testing.assert_array_equal(p, pos0); np.testing.assert_array_equal(v, vel0)
+        assert c.kernel_stats().launches == 0
+        draw(c, 3)
+        p3, v3 = c.download_state()
+        assert c.kernel_stats().kernel_name.decode() == "force_sym_kernel"
+        with mapn.Compute(n, mass=70000.0 / n) as d:           # the default plan from the same state: another summation order, same physics
+            draw(d, 3)
+            q3, _ = d.download_state()
+            assert d.sym_plan().sets == 2
+        assert errs(p3[:, :3], q3[:, :3], SPREAD)[0] < 1e-6
+        # migrate (Particles.cpp:515-516) with the flag: the copy calibrates on the copied state and continues like the source
+        with mapn.Compute(n, mass=70000.0 / n, flags=mapn.FLAG_XCD_CALIBRATE, old=c) as m:
+            assert m.sym_plan().sets == 16
+            c.set_sym_xcd_weights(m.sym_plan().xcd_weight)     # (same weights on both, so that the two continue bit for bit)
+            draw(c, 2); draw(m, 2)
+            np.testing.assert_array_equal(c.download_state()[0], m.download_state()[0])
+    with mapn.Compute(69632, mass=70000.0 / 69632, flags=mapn.FLAG_XCD_CALIBRATE) as c:    # 68 blocks
+        assert c.sym_plan().sets == 2 and c.GetFenceValue() == 4
+        draw(c, 1)
+        assert c.kernel_stats().kernel_name.decode() == "force_sym_kernel"
+    with mapn.Compute(4096, mass=70000.0 / 4096, flags=mapn.FLAG_XCD_CALIBRATE, kernel=mapn.KERNEL_SCALAR) as c:   # one-sided kernel: nothing to weigh
+        assert c.GetFenceValue() == 4
+        draw(c, 1)
+
+
 def _loopback_expectation(pos, vel, nb, nbl, mass, soft2, dt):
     """What rank 0 of a sharded job computes when no peer ever answers (float64): its blocks meet what the schedule says; its
     bodies get the forces of those meetings plus the reactions of meetings between two of its own blocks."""
@@ -261,6 +302,7 @@ def test_sharded_symmetric_step_with_biased_waves_one_rank_loopback(oracle, monk
     (the older wave of every SIMD) carry three times the steps of the last four -- under the pushed-positions exchange
     (algorithm 5) and the pulled one (4); both must give rank 0's bodies exactly what the schedule says, bit-identically to
     each other and to the equal-wave 4-wave plan's result within rounding."""
+    monkeypatch.setenv("MAPN_TEST_HOOKS", "1")           # (hooks are honoured only with this set)
     monkeypatch.setenv("MAPN_P2P_LOOPBACK", "2")               # (2: nothing is sent to the other ranks either)
     n, world = 65536, 8
     nb, nbl = n // 1024, n // 1024 // world
@@ -293,6 +335,44 @@ def test_sharded_symmetric_step_with_biased_waves_one_rank_loopback(oracle, monk
     assert errs(got[(5, True)][0][:, :3], got[(5, False)][0][:, :3], SPREAD)[0] < 1e-6
 
 
+@pytest.mark.parametrize("settle", [False, True])
+def test_pushed_positions_are_checked_against_their_checksums_loopback(monkeypatch, settle):
+    """VERDICT r3 #3 / ADVICE r3: the positions gather algorithm 5 stores into the peers' replicas carry |a| in .w, no tag, so the
+    pusher stores one checksum word per 32 bodies behind them (publication number mixed in) and whoever reads the replica next --
+    the next force launch, spread over its waves, or the wait in front of a download -- re-computes them from what it reads past
+    the caches.  Rank 0 of an 8-way job with every peer mapped to itself: 40 clean steps raise nothing; with the test hook
+    flipping ONE bit of ONE pushed position in publication 7 the very next consumer reports MAPN_ERR_COMM naming the pusher."""
+    monkeypatch.setenv("MAPN_TEST_HOOKS", "1")
+    monkeypatch.setenv("MAPN_P2P_LOOPBACK", "1")
+    n, world = 65536, 8
+    with mapn.Compute(n, mass=70000.0 / n, rank=0, world_size=world) as c:
+        blob = c.p2p_export()
+        c.p2p_import([blob] * world)
+        c.set_gather_algorithm(5)
+        draw(c, 40)
+        c.WaitForGpu()
+        assert c.p2p_status() == 0 and c.kernel_stats().kernel_name.decode() == "force_sym_kernel"
+    monkeypatch.setenv("MAPN_TEST_CORRUPT_PUSH", "7")
+    with mapn.Compute(n, mass=70000.0 / n, rank=0, world_size=world) as c:
+        blob = c.p2p_export()
+        c.p2p_import([blob] * world)
+        c.set_gather_algorithm(5)
+        draw(c, 6)
+        c.WaitForGpu()                                         # publications 1 .. 6: clean
+        assert c.p2p_status() == 0
+        c.Simulate(n, c.GetFenceValue())                       # publication 7 carries the flipped bit
+        with pytest.raises(mapn.MapnError) as e:
+            if settle:
+                c.download_state()                             # the one-wave wait in front of a download checks it ...
+            else:
+                c.Simulate(n, c.GetFenceValue())               # ... or the next force launch does, spread over its waves
+                c.WaitForGpu()
+        assert e.value.status == -4 and "PUSHED" in str(e.value) and "rank 0" in str(e.value), str(e.value)
+        assert c.p2p_status() == 0x200                         # 0x200 + the pusher (loopback: the rank itself)
+        with pytest.raises(mapn.MapnError):
+            c.Simulate(n, c.GetFenceValue())                   # the context stays failed: nothing is integrated on top of it
+
+
 def test_rccl_form_of_the_sharded_symmetric_step_one_rank_loopback(oracle, monkeypatch):
     """Gather algorithm 6: pack launch -> one group of ncclSend / ncclRecv -> reduce launch -> ncclAllGather.  RCCL refuses two
     ranks on one device, so what runs here is rank 0 of a 2-rank job on a ONE-rank communicator (MAPN_COMM_LOOPBACK): the pack
@@ -300,6 +380,7 @@ def test_rccl_form_of_the_sharded_symmetric_step_one_rank_loopback(oracle, monke
     Rank 1's reactions never arrive, so the expectation is built accordingly (float64): rank 0's blocks meet what the schedule
     says, its bodies get the forces from those meetings plus the reactions of meetings between two of rank 0's own blocks."""
     from mapn import shard
+    monkeypatch.setenv("MAPN_TEST_HOOKS", "1")           # (hooks are honoured only with this set)
     monkeypatch.setenv("MAPN_COMM_LOOPBACK", "1")
     n, world = 8192, 2
     nb, nbl = n // 1024, n // 1024 // world

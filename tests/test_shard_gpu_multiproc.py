@@ -103,6 +103,19 @@ def test_p2p_wait_timeout_is_reported_not_silent(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "timeout_reported"))
 
 
+def test_corrupted_pushed_position_is_reported_by_the_receiving_rank(tmp_path):
+    """two processes, gather algorithm 5; one bit of one position rank 1 pushes in its third publication is
+    flipped after its checksum was formed.  Rank 0 reports MAPN_ERR_COMM naming rank 1 the next time it touches its replica;
+    rank 1, whose own replica is fine, does not."""
+    port = 29600 + (os.getpid() % 2000) + 19
+    worker = os.path.join(ROOT, "tests", "shard_gpu_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), "8192", "3", str(tmp_path), "sympush_corrupt"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert os.path.exists(os.path.join(str(tmp_path), "corruption_reported"))
+
+
 @pytest.mark.parametrize("mode", ["sym", "sympush"])
 @pytest.mark.parametrize("world,n", [(2, 8192), (4, 8192), (8, 8192), (3, 9216), (2, 6144), (8, 16384)])
 def test_symmetric_step_sharded_over_processes(tmp_path, oracle, world, n, mode):

@@ -39,6 +39,24 @@ def test_symmetric_schedule_is_balanced(nb):
     assert max(per_block.values()) - min(per_block.values()) <= 1     # the half-ring partner: one extra meeting group
 
 
+@pytest.mark.parametrize("nb,world", [(64, 8), (64, 4), (64, 2), (16, 8), (256, 8), (1024, 8), (24, 3), (48, 6)])
+def test_half_ring_group_is_spread_evenly_over_the_ranks(nb, world):
+    """which block of a half-ring pair (p, p + nb/2) runs its meetings ALTERNATES with p, so every rank of a sharded
+    job runs the same number of meetings (65 536 / 8: 520 per block on average; until round 3 ranks 0 .. 3 ran 528 and ranks 4 .. 7 512 and every
+    step waited for the heavy half) -- and each pair is still run by exactly one of its two blocks."""
+    nbl, half = nb // world, nb // 2
+    per_rank = [0] * world
+    for a, b, d, symmetric in shard.sym_meetings(nb):
+        per_rank[a // nbl] += 16                              # 16 J-blocks per (block, partner) meeting group
+    assert max(per_rank) - min(per_rank) <= (16 if nbl % 2 else 0), per_rank
+    if (nb, world) == (64, 8):
+        assert per_rank == [8 * 520] * 8                      # 8 blocks a rank, 520 meetings a block on average (528 or 512 each)
+    for p in range(half):
+        assert shard.sym_runs_half(nb, p) != shard.sym_runs_half(nb, p + half)
+        assert shard.sym_runs_half(nb, p) == (p % 2 == 0)
+    assert not any(shard.sym_runs_half(nb + 1, a) for a in range(nb + 1))   # odd block counts have no half-ring group
+
+
 @pytest.mark.parametrize("n,world,waves,sb", [(65536, 8, 16, 16), (65536, 2, 8, 8), (4096, 8, 4, 1), (4096, 4, 8, 2),
                                               (1048576, 8, 8, 8), (3000 * 4, 4, 8, 3), (8192, 2, 16, 4)])
 def test_flow_rotation_starts_on_the_own_slice_and_is_a_permutation(n, world, waves, sb):
@@ -174,7 +192,7 @@ def test_force_kernel_writes_exactly_the_rows_the_reduce_kernel_reads(nb, gpw, p
     for k, w in enumerate(plan.windows):
         g0, g1 = int(w[0]), int(w[1])
         rows, heads = {}, {}                                   # (J-block, group) -> writes; (I-block, part) -> meeting it holds
-        for a in range(nb if nb <= 16 else 3):                 # every block for small jobs, else a class-0, class-0, class-0/1 sample
+        for a in range(nb if nb <= 16 else 3):                 # every block for small jobs, else a sample holding both classes
             a = a if nb <= 16 else (0, half - 1 if half else 1, nb - 1)[a]
             cls = shard.sym_block_class(nb, a)
             st = plan.set_of(cls, a)

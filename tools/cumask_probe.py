@@ -1,5 +1,5 @@
 import os, sys
-os.environ["MAPN_P2P_LOOPBACK"] = "1"
+os.environ["MAPN_TEST_HOOKS"] = "1"; os.environ["MAPN_P2P_LOOPBACK"] = "1"
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import mapn
 n, world = 16384, 2

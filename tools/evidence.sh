@@ -10,7 +10,7 @@
 #   issue [tree]                 SQ issue / wait counters of force_sym_kernel (three --pmc passes)
 #   ab <other-tree>              same-box A/B of another checkout (e.g. ab/old: `git archive <rev> | tar -x -C ab/old && make -C ...`)
 #   timeline N WORLD RANK ALGO   per-wave timeline of one sharded symmetric force launch in loopback (tools/shard_timeline.py)
-#   shardstep [N WORLD]          kernel trace of the loopback step, ranks 0 and WORLD/2, algorithms 4 and 5: durations, gaps, period
+#   shardstep [N WORLD [TREE]]   kernel trace of the loopback step, ranks 0 and WORLD/2, algorithms 4 and 5: durations, gaps, period
 #   loopback [N]                 rank 0's compute per step at the shard size, one-sided against symmetric, WORLD = 2, 4, 8
 #   sizes                        symmetric against one-sided kernel at 65 536 ... 4 194 304 bodies
 #   parity1000                   tests/parity_report.py at 65 536 bodies, 1000 steps, all legs -> JSON
@@ -70,11 +70,12 @@ ab)
 timeline)
   python tools/shard_timeline.py "$@" 2>&1 | tee $O/timeline_$(echo "$*" | tr ' ' '_').txt ;;
 shardstep)
-  n=${1:-65536}; world=${2:-8}; cd /tmp
+  n=${1:-65536}; world=${2:-8}; tree=${3:-}; [ -n "$tree" ] && { O=$O/$(basename $tree); mkdir -p $O; export MAPN_TREE=$R/$tree; }   # [TREE]: another checkout, for a same-box A/B
+  rm -rf $O/trace_*; cd /tmp
   cat > /tmp/loopstep.py <<'PY'
 import os, sys
-os.environ["MAPN_P2P_LOOPBACK"] = "1"
-sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+os.environ["MAPN_TEST_HOOKS"] = "1"; os.environ["MAPN_P2P_LOOPBACK"] = "1"
+sys.path.insert(0, os.environ.get("MAPN_TREE") or os.environ["GRAFT_REPO_ROOT"])
 import mapn
 n, world, algo, rank = (int(x) for x in sys.argv[1:5])
 with mapn.Compute(n, device=0, mass=70000.0 / n, rank=rank, world_size=world) as c:
@@ -86,12 +87,31 @@ PY
   for algo in 5 4 2; do for rank in 0 $((world / 2)); do
     rocprofv3 --kernel-trace --output-format csv -d $O/trace_${algo}_$rank -- python3 /tmp/loopstep.py $n $world $algo $rank > /dev/null 2> $O/trace_${algo}_$rank.err
   done; done
+  # the forms that need NO mapped peer memory (hipIpc unavailable): rank 0 on a ONE-rank RCCL communicator (MAPN_COMM_LOOPBACK): the
+  # launches and the collective calls are real, the wire is not.  6 = sharded symmetric step over RCCL, 0 = one-sided + ncclAllGather, 10 = 0 + overlap
+  cat > /tmp/loopstep_comm.py <<'PY'
+import os, sys
+os.environ["MAPN_TEST_HOOKS"] = "1"; os.environ["MAPN_COMM_LOOPBACK"] = "1"
+sys.path.insert(0, os.environ.get("MAPN_TREE") or os.environ["GRAFT_REPO_ROOT"])
+import mapn
+n, world, algo = (int(x) for x in sys.argv[1:4])
+with mapn.Compute(n, device=0, mass=70000.0 / n, rank=0, world_size=world) as c:
+    c.comm_init(mapn.Compute.comm_unique_id()); c.set_gather_algorithm(algo % 10); c.set_shard_overlap(algo >= 10); c.set_timers(0)
+    for _ in range(2000):
+        c.Simulate(n, c.GetFenceValue())
+    c.WaitForGpu()
+PY
+  for algo in 6 0 10; do
+    rocprofv3 --kernel-trace --output-format csv -d $O/trace_${algo}_0 -- python3 /tmp/loopstep_comm.py $n $world $algo > /dev/null 2> $O/trace_${algo}_0.err
+  done
   cd $R; python - "$O" $n $world <<'PY' | tee $O/shard_step_timeline.txt
 import csv, glob, collections, sys
 O, n, world = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 print(f"# kernel trace (rocprofv3 --kernel-trace) of one rank's step at {n} / {world} in loopback (every peer mapped to the rank itself), second half of 2000 steps:")
 print("# MEDIAN (mean) durations and gaps; step period = median distance between two force launches' starts.  Algorithm 5: the exchange launch pushes the new positions; 4: it pulls them; 2: one-sided kernel, separate pull launch (skipped in loopback)")
-for algo in (5, 4, 2):
+names = {5: "5 (symmetric, positions pushed)", 4: "4 (symmetric, positions pulled)", 2: "2 (one-sided kernel + pull)", 6: "6 (symmetric over RCCL alone; 1-rank communicator)",
+         0: "0 (one-sided kernel + ncclAllGather; 1-rank communicator)", 10: "0 + overlap (own-segment launch || all-gather; 1-rank communicator)"}
+for algo in (5, 4, 2, 6, 0, 10):
     for rank in (0, world // 2):
         f = glob.glob(f"{O}/trace_{algo}_{rank}/**/*kernel_trace.csv", recursive=True)
         if not f: continue
@@ -102,12 +122,14 @@ for algo in (5, 4, 2):
             k = a["Kernel_Name"].split("(")[0][-40:]
             dur[k].append(int(a["End_Timestamp"]) - int(a["Start_Timestamp"]))
             gap[k + " -> next"].append(int(b["Start_Timestamp"]) - int(a["End_Timestamp"]))
-        print(f"== gather algorithm {algo}, rank {rank}")
+        print(f"== gather algorithm {names[algo]}, rank {rank}")
         med = lambda v: sorted(v)[len(v) // 2]
         for k, v in dur.items(): print("  %-48s %7.2f us  (mean %.2f, x%d)" % (k, med(v) / 1e3, sum(v) / len(v) / 1e3, len(v)))
         for k, v in gap.items(): print("  gap %-44s %7.2f us  (mean %.2f)" % (k, med(v) / 1e3, sum(v) / len(v) / 1e3))
         top = collections.Counter(r["Kernel_Name"] for r in rows if "force" in r["Kernel_Name"]).most_common(1)[0][0]
         starts = [int(r["Start_Timestamp"]) for r in rows if r["Kernel_Name"] == top]
+        per = 2 if algo == 10 and sum("force" in k for k in dur) == 1 else 1      # (overlap structure: two launches of one kernel per step)
+        starts = starts[::per]
         d = [b - a for a, b in zip(starts, starts[1:])]
         print("  step period %.2f us  (mean %.2f)" % (med(d) / 1e3, sum(d) / len(d) / 1e3))
 PY

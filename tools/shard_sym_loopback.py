@@ -7,7 +7,7 @@ import os
 import sys
 import time
 
-os.environ["MAPN_P2P_LOOPBACK"] = "1"
+os.environ["MAPN_TEST_HOOKS"] = "1"; os.environ["MAPN_P2P_LOOPBACK"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mapn  # noqa: E402
 

@@ -26,7 +26,7 @@ a = ap.parse_args()
 n = a.bodies
 KN = {"lds": mapn.KERNEL_LDS, "sgpr": mapn.KERNEL_SCALAR}
 with mapn.Compute(n, mass=70000.0 / n, rank=0, world_size=a.world, flags=mapn.FLAG_SHARD_OVERLAP if a.overlap else 0) as c:
-    if a.world > 1 and os.environ.get("MAPN_COMM_LOOPBACK") == "1":
+    if a.world > 1 and os.environ.get("MAPN_COMM_LOOPBACK") == "1":    # (run as: MAPN_TEST_HOOKS=1 MAPN_COMM_LOOPBACK=1 python tools/sweep.py ...)
         c.comm_init(mapn.Compute.comm_unique_id())      # real sharded step structure, 1-rank RCCL
     elif a.world > 1:
         c.set_external_gather(True)

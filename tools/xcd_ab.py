@@ -6,7 +6,7 @@ import sys
 import time
 
 if "--shard" in sys.argv:
-    os.environ["MAPN_P2P_LOOPBACK"] = "1"
+    os.environ["MAPN_TEST_HOOKS"] = "1"; os.environ["MAPN_P2P_LOOPBACK"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mapn  # noqa: E402
 

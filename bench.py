@@ -65,6 +65,8 @@ def parse():
                     help="XCD-aware parts of the symmetric kernel (1 GPU): calibrate the dies' speeds during the untimed prewarm and size "
                          "every part by the die it runs on; auto keeps them only if an untimed A/B against the default plan wins")
     ap.add_argument("--overlap", action="store_true", help="sharded mode: own-segment launch overlapped with the all-gather")
+    ap.add_argument("--trial-seconds", type=float, default=90.0,
+                    help="wall-time budget of the exchange trial (N > 1, --gather auto): once it is spent the candidates not yet tried are skipped")
     ap.add_argument("--force-comm", action="store_true",
                     help="create the torch.distributed group and the in-library RCCL communicator even for one rank (exercises the sharded code path on a 1-GPU box)")
     return ap.parse_args()
@@ -249,11 +251,15 @@ def main():
     p2p_failure = None
     if dist is not None and transport == "rccl":
         # every way of issuing the exchange that sets up on this node: (name, algorithm, overlap structure)
+        # The DEFAULT trial (--gather auto) holds the forms that can win, safest first: the RCCL collectives, the symmetric step over
+        # RCCL alone, then the peer-to-peer forms in the order they build on each other.  The overlap structures (two under-filled
+        # launches: 150 against 120 us in loopback) and the in-kernel exchange lose to these by the builder's own numbers and are
+        # run only when asked for by name (--overlap, --gather flow / p2pall): fewer code paths in the one run that counts.
         candidates = []
         if a.gather in ("auto", "allgather"):
-            candidates += [("allgather", 0, False), ("allgather+overlap", 0, True)]
+            candidates += [("allgather", 0, False)] + ([("allgather+overlap", 0, True)] if a.overlap or a.gather == "allgather" else [])
         if a.gather in ("auto", "sendrecv"):
-            candidates += [("sendrecv", 1, False), ("sendrecv+overlap", 1, True)]
+            candidates += [("sendrecv", 1, False)] + ([("sendrecv+overlap", 1, True)] if a.overlap or a.gather == "sendrecv" else [])
         if a.overlap:                                   # --overlap: only the overlap structures
             candidates = [x for x in candidates if x[2]]
         p2p_ok = False
@@ -274,8 +280,8 @@ def main():
             # LAST: these have to prove themselves on this node
             if p2p_ok and a.gather in ("auto", "p2p", "sym", "sympush", "p2pall"):
                 candidates.append(("p2p", 2, False))               # (also the yardstick the symmetric forms are verified against)
-            if p2p_ok and a.gather in ("auto", "flow", "p2pall"):
-                candidates.append(("p2p+inkernel", 3, False))  # the same exchange overlapped inside the force launch
+            if p2p_ok and a.gather in ("flow", "p2pall"):
+                candidates.append(("p2p+inkernel", 3, False))  # the same exchange overlapped inside the force launch (by name only)
             if p2p_ok and a.gather in ("auto", "sym", "p2pall") and sym_fits:
                 # the SYMMETRIC step sharded over the ranks: every unordered pair of the job once, reactions
                 # stored into the owners' receive regions, positions pulled by the same launch
@@ -333,8 +339,16 @@ def main():
                 c.set_timers(timer_interval)
 
             p2p_dead = False
+            t_trial0 = time.perf_counter()
             for name, algo, overlap in candidates:
-                if algo >= 2 and p2p_dead:
+                is_p2p = 2 <= algo <= 5
+                if is_p2p and p2p_dead:
+                    continue
+                over = torch.tensor([1 if (trial and time.perf_counter() - t_trial0 > a.trial_seconds) else 0], device=red_dev)
+                dist.all_reduce(over, op=dist.ReduceOp.MAX)     # (all ranks decide alike)
+                if over.item():
+                    if rank == 0:
+                        print(f"[bench] exchange trial: budget of {a.trial_seconds:.0f} s spent -> '{name}' not tried", file=sys.stderr, flush=True)
                     continue
                 failed = None
                 try:
@@ -352,7 +366,7 @@ def main():
                     failed, dt_trial = str(e), float("inf")
                 bad = torch.tensor([1 if failed else 0], device=red_dev)
                 dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-                if not bad.item() and (algo >= 2 or algo == 6):
+                if not bad.item() and algo >= 2:
                     bad = torch.tensor([0 if (c.p2p_status() == 0 and replicas_consistent()) else 1], device=red_dev)
                     dist.all_reduce(bad, op=dist.ReduceOp.MAX)
                     if bad.item() and not failed:
@@ -369,10 +383,15 @@ def main():
                     if rank == 0:
                         print(f"[bench] exchange '{name}' failed on this node ({failed or 'on another rank'}) -> not used; state re-initialised",
                               file=sys.stderr, flush=True)
-                    if algo >= 2 and algo != 6:
+                    # a context whose device-side wait gave up or whose row / position check failed STAYS failed, whatever the
+                    # algorithm (6 sets the status word too): replace it on every rank, or the next candidate inherits the fault
+                    stuck = torch.tensor([1 if c.p2p_status() != 0 else 0], device=red_dev)
+                    dist.all_reduce(stuck, op=dist.ReduceOp.MAX)
+                    if is_p2p:
                         p2p_failure = f"{name}: {failed or 'failed on another rank'}"
-                        p2p_dead = algo == 2                    # the plain exchange failed: the in-kernel form shares its transport
-                        rebuild(with_p2p="p2p" in trial)
+                        p2p_dead = algo == 2                    # the plain exchange failed on a healthy context: every peer-to-peer form shares its transport
+                    if is_p2p or stuck.item():
+                        rebuild(with_p2p=p2p_ok and not p2p_dead and ("p2p" in trial or not is_p2p))
                     else:
                         reinit()
                     continue
@@ -476,6 +495,25 @@ def main():
                       "max_ms": round(float(step_ms.max()), 5)}
     except mapn.MapnError:
         pass
+    # with >= 100 steps, four more repeats of the same K steps (untimed by the contract: `value` stays the first region's)
+    # and the median of the five -- how far one region is from the typical one on this box
+    repeats = None
+    if a.steps >= 100:
+        reps = [elapsed / a.steps * 1e3]
+        for _ in range(4):
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            sync()
+            dt_rep = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([dt_rep], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_rep = float(t.item())
+            reps.append(dt_rep / a.steps * 1e3)
+        repeats = {"ms_per_step": [round(x, 5) for x in reps], "median_ms_per_step": round(sorted(reps)[2], 5),
+                   "note": "the timed region (first entry: `ms_per_step`, `value`) and four more regions of the same K steps right behind it"}
     first, count = c.shard_range()
     # the clock the chip held under this kernel: stamped diagnostic steps right behind the timed region
     # (same state of the chip; untimed).  Single GPU, scalar-cache kernel only.
@@ -531,6 +569,7 @@ def main():
                        "epilogue": {0: "partial rows + reduce_integrate launch", 1: "fused in the workgroup", 2: "last-arriver ticket (one launch per step)", 3: "symmetric kernel: force rows + sym_reduce_integrate launch"}.get(st.epilogue, "?"),
                        "launches_per_step": int(st.force_launches_per_step) * (1 if st.fused else 2), "timer_interval": timer_interval,
                        "step_ms_by_quarter_of_the_timed_region": quarters, "step_ms_spread": spread if quarters else None,
+                       "repeats": repeats,
                        "step_ms_note": "device time (HIP events on the compute stream) of the steps of the timed region that carried events; ms_per_step is the wall clock over all of them",
                        "p2p_failure": p2p_failure, "sharded_symmetric_deviation_after_run": sym_dev_after,
                        "xcd_aware_parts": xcd, "symmetric_plan": sym_plan_desc},

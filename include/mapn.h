@@ -29,8 +29,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* libmapn.so is built with -fvisibility=hidden: what this header declares is ALL it exports */
+#endif
 
-#define MAPN_ABI_VERSION 2
+#define MAPN_ABI_VERSION 3   /* 3 (round 4): windows_capacity in the two plan queries, mapn_replica_checksum, MAPN_FLAG_XCD_CALIBRATE */
 
 typedef struct mapn_ctx mapn_ctx;
 
@@ -451,8 +454,11 @@ typedef struct mapn_sym_plan_info {
 int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2,
                            uint32_t waves, uint32_t wave_bias_hi, uint32_t wave_bias_lo, const uint32_t *xcd_weights,
                            uint32_t launch_blocks, mapn_sym_plan_info *info,
-                           uint32_t *windows, uint32_t *tables, uint64_t tables_capacity);
-int mapn_get_sym_plan(mapn_ctx *ctx, mapn_sym_plan_info *info, uint32_t *windows, uint32_t *tables, uint64_t tables_capacity);
+                           uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity);
+/* Two-call pattern: first with windows = tables = NULL to learn info->windows and info->windows * info->table_stride, then with
+ * buffers; BOTH capacities are counted in uint32 (4 per window) and checked -- a caller that sized its arrays from an earlier plan
+ * (before mapn_set_sym_plan / another MAPN_SYM_MAX_MB changed the window count) gets MAPN_ERR_INVALID_ARGUMENT, not an overflow. */
+int mapn_get_sym_plan(mapn_ctx *ctx, mapn_sym_plan_info *info, uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity);
 int mapn_set_sym_plan(mapn_ctx *ctx, uint32_t waves, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t groups_per_window,
                       uint32_t wave_bias_hi, uint32_t wave_bias_lo);
 /*
@@ -494,6 +500,9 @@ int mapn_set_timers(mapn_ctx *ctx, int interval);
 /* The compute stream (hipStream_t) steps are enqueued on, for callers that record events. */
 void *mapn_compute_stream(mapn_ctx *ctx);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -144,8 +144,8 @@ SIGNATURES = {
     "mapn_calibrate_sym_xcds": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_uint32 * 8)]),
     "mapn_set_sym_xcd_weights": (C.c_int, [_ctx, C.POINTER(C.c_uint32 * 8)]),
     "mapn_sym_plan_describe": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32 * 8), C.c_uint32,
-                                         C.POINTER(SymPlanInfo), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint64]),
-    "mapn_get_sym_plan": (C.c_int, [_ctx, C.POINTER(SymPlanInfo), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint64]),
+                                         C.POINTER(SymPlanInfo), C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32), C.c_uint64]),
+    "mapn_get_sym_plan": (C.c_int, [_ctx, C.POINTER(SymPlanInfo), C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32), C.c_uint64]),
     "mapn_set_sym_plan": (C.c_int, [_ctx, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "mapn_measure_clock": (C.c_int, [_ctx, C.c_int, C.POINTER(ClockInfo)]),
     "mapn_set_timers": (C.c_int, [_ctx, C.c_int]),

@@ -272,11 +272,11 @@ class Compute:
     def sym_plan(self) -> "SymPlan":
         """The plan the symmetric kernel runs in this context (raises MapnError if it does not run)."""
         info = _lib.SymPlanInfo()
-        check(self._lib.mapn_get_sym_plan(self._ctx, C.byref(info), None, None, 0))
+        check(self._lib.mapn_get_sym_plan(self._ctx, C.byref(info), None, 0, None, 0))
         win = np.zeros((info.windows, 4), np.uint32)
         tab = np.zeros(info.windows * info.table_stride, np.uint32)
         u32p = C.POINTER(C.c_uint32)
-        check(self._lib.mapn_get_sym_plan(self._ctx, C.byref(info), win.ctypes.data_as(u32p), tab.ctypes.data_as(u32p), tab.size))
+        check(self._lib.mapn_get_sym_plan(self._ctx, C.byref(info), win.ctypes.data_as(u32p), win.size, tab.ctypes.data_as(u32p), tab.size))
         return SymPlan(info, win, tab)
 
     def set_shard_overlap(self, enabled: bool):
@@ -385,13 +385,13 @@ def describe_sym_plan(nb: int, groups_per_window: int = 0, parts: int = 32, tape
     info = _lib.SymPlanInfo()
     t1 = parts if taper1 is None else taper1
     xw = C.byref((C.c_uint32 * 8)(*[int(x) for x in xcd_weights])) if xcd_weights is not None else None
-    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, int(wave_bias[0]), int(wave_bias[1]), xw, launch_blocks, C.byref(info), None, None, 0)
+    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, int(wave_bias[0]), int(wave_bias[1]), xw, launch_blocks, C.byref(info), None, 0, None, 0)
     if rc:
         raise MapnError(rc, info.error.decode(errors="replace"))
     win = np.zeros((info.windows, 4), np.uint32)
     tab = np.zeros(info.windows * info.table_stride, np.uint32)
     u32p = C.POINTER(C.c_uint32)
-    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, int(wave_bias[0]), int(wave_bias[1]), xw, launch_blocks, C.byref(info), win.ctypes.data_as(u32p), tab.ctypes.data_as(u32p), tab.size)
+    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, int(wave_bias[0]), int(wave_bias[1]), xw, launch_blocks, C.byref(info), win.ctypes.data_as(u32p), win.size, tab.ctypes.data_as(u32p), tab.size)
     if rc:
         raise MapnError(rc, info.error.decode(errors="replace"))
     return SymPlan(info, win, tab)

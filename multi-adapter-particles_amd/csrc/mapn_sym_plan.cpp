@@ -130,7 +130,7 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
 // ---- C ABI: the plan as data, without a device (tests, the order-matched oracle) ------------------
 extern "C" int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2,
                                       uint32_t waves, uint32_t wave_bias_hi, uint32_t wave_bias_lo, const uint32_t *xcd_weights, uint32_t launch_blocks, mapn_sym_plan_info *info,
-                                      uint32_t *windows, uint32_t *tables, uint64_t tables_capacity)
+                                      uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity)
 {
     if (!info) return MAPN_ERR_INVALID_ARGUMENT;
     mapn::SymPlanHost p;
@@ -145,6 +145,10 @@ extern "C" int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, u
     info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
     info->sets = p.sets; for (int k = 0; k < 8; k++) info->xcd_weight[k] = p.xcd_weight[k];
     info->a0 = 0; info->nbl = 0; info->active_compute_units = 0; info->exchange_workgroups = 0; info->scratch_bytes = 0;
+    if (windows && windows_capacity < 4u * p.windows.size()) {
+        snprintf(info->error, sizeof info->error, "windows_capacity %llu < %zu", (unsigned long long)windows_capacity, 4u * p.windows.size());
+        return MAPN_ERR_INVALID_ARGUMENT;
+    }
     if (windows)
         for (size_t k = 0; k < p.windows.size(); k++) {
             windows[4 * k + 0] = p.windows[k].g0; windows[4 * k + 1] = p.windows[k].g1;

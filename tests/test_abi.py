@@ -28,8 +28,17 @@ def test_library_exports_every_declared_symbol(lib):
     assert sorted(_lib.SIGNATURES) == names, "python binding and header disagree"
 
 
+def test_library_exports_nothing_but_the_declared_c_abi():
+    """The drop-in boundary is a C ABI: libmapn.so is built with -fvisibility=hidden and every FUNCTION it exports is one that
+    include/mapn.h declares (the device-kernel handle objects hipcc emits are data symbols, not entry points)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", mapn.library_path()], capture_output=True, text=True, check=True).stdout
+    funcs = sorted(ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in ("T", "t"))
+    assert funcs == _declared(), sorted(set(funcs) ^ set(_declared()))
+
+
 def test_abi_version_and_timer_name(lib):
-    assert lib.mapn_abi_version() == 2
+    assert lib.mapn_abi_version() == 3
     assert lib.mapn_timer_name() == b"simulate ms"          # Compute.cpp:446
 
 

@@ -82,7 +82,39 @@ def test_bench_json_contract():
     assert x.get("error") or x["source"].startswith("library")      # (the bench's plan is the library's plan)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e8 and "sample" in cb
+    assert d["config"]["repeats"] is None  # (40 steps: the five-repeat median starts at 100)
     assert d["value"] > 3.0e12            # the 40 %-of-peak target is 3.15e12 at kernel level
+
+
+@pytest.mark.gpu
+def test_bench_reports_a_median_of_five_repeats_from_100_steps_on():
+    """>= 100 timed steps and a median of five repeats.  `value` / `ms_per_step` stay the contract's ONE timed region
+    of exactly K steps; four more regions of K steps follow it and the five are listed with their median."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--warmup", "5", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    rep = d["config"]["repeats"]
+    assert len(rep["ms_per_step"]) == 5 and abs(rep["ms_per_step"][0] - d["ms_per_step"]) < 1e-4
+    assert sorted(rep["ms_per_step"])[2] == rep["median_ms_per_step"] and 0.4 < rep["median_ms_per_step"] < 1.0
+    assert max(rep["ms_per_step"]) / min(rep["ms_per_step"]) < 1.08, rep      # one box, one clock state: the regions agree
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_two_real_gpus_when_the_box_has_them():
+    """every multi-process test shares ONE device, so the cross-GPU forms (hipIpc over xGMI, RCCL with N > 1 ranks) never run
+    in this suite -- unless the box has a second GPU.  Then: the default `--gather auto` trial with one rank per GPU, launched by
+    bench.py itself, replicas bit-identical, the symmetric forms verified against the one-sided step."""
+    if mapn.compute.device_count() < 2:
+        pytest.skip("one GPU on this box: the cross-GPU exchange cannot run here (the driver's 8-GPU run is its first execution)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=1200, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["valid"] is True and d["config"]["replicas_bit_identical_after_run"] is True
+    assert len(d["config"]["exchange_trial_us_per_step"]) >= 2, d["config"]
 
 
 @pytest.mark.gpu

@@ -448,16 +448,17 @@ def main():
                 return (time.perf_counter() - t) / k
             kk = max(8, min(120, int(0.08 / (0.65e-3 * (n / 65536.0) ** 2))))
             pl = c.sym_plan()
-            if pl.sets > 2:                                # the library's creation-time calibration applied its weights
+            if pl.xcd_mode != 0:                           # the library's creation-time calibration applied its weights
                 w = list(pl.xcd_weight)
                 xcd["weights"], xcd["source"] = w, "library (MAPN_FLAG_XCD_CALIBRATE at mapn_create)"
+                xcd["form"] = "class-aware" if pl.xcd_mode == 2 else "spread"
                 t_w = min(burst(kk), burst(kk))
                 c.set_sym_xcd_weights(None)
                 t_def = min(burst(kk), burst(kk))
                 xcd["trial_ms"] = {"default": t_def * 1e3, "weighted": t_w * 1e3}
                 if a.xcd == "on" or t_w < t_def * 0.998:
                     c.set_sym_xcd_weights(w)
-                    xcd["used"] = c.sym_plan().sets > 2
+                    xcd["used"] = c.sym_plan().xcd_mode != 0
             else:
                 xcd["note"] = "the library's calibration did not apply (block count not a multiple of 8, or the one-sided kernel runs)"
         except mapn.MapnError as e:
@@ -545,7 +546,8 @@ def main():
             try:
                 pl = c.sym_plan()
                 sym_plan_desc = {"waves_per_workgroup": pl.waves, "parts_per_block": pl.parts, "taper": [pl.taper1, pl.taper2],
-                                 "wave_bias_older_to_younger": list(pl.wave_bias), "windows": len(pl.windows), "table_sets": pl.sets}
+                                 "wave_bias_older_to_younger": list(pl.wave_bias), "windows": len(pl.windows), "table_sets": pl.sets,
+                                 "xcd_mode": {0: "none", 1: "spread", 2: "class-aware (heavy blocks on the faster dies)"}.get(pl.xcd_mode), "class_dies": pl.class_die if pl.xcd_mode == 2 else None}
             except mapn.MapnError:
                 pass
         out = {

@@ -427,6 +427,9 @@ int mapn_set_force_plan(mapn_ctx *ctx, int kernel, uint32_t bodies_per_lane, uin
  * two chains (even / odd bodies of the lane) folded once per piece, pieces of a cut meeting added first steps + last
  * steps; per body: rows of its block in ascending part order, then per group in ascending order the meeting's row and
  * its head row, windows in ascending order; the mass multiplies the total.
+ * (The tables array holds info->windows * info->table_stride words, then the info->wgmap_entries words of the class-aware workgroup map.
+ *  launch_a0: first block of the launch in the whole job -- a rank's first block, 0 unsharded; xcd_mode 0: class-aware where it applies,
+ *  else spread; 1: spread only.)
  * mapn_sym_plan_describe computes the plan of a shape WITHOUT a device (CPU tests, the oracle);
  * mapn_get_sym_plan returns the plan a context runs (a0 / nbl: first block and block count of this rank when sharded);
  * mapn_set_sym_plan is the tuning hook (waves 4 or 8; taper1 = taper2 = 0: equal parts; groups_per_window 0: as many
@@ -444,7 +447,13 @@ typedef struct mapn_sym_plan_info {
     uint32_t wave_bias[2];       /* share of a workgroup's steps: first half of its waves : second half (1 : 1 = equal) */
     uint32_t brows, max_meetings, table_stride;
     uint32_t sets;               /* table sets per window: 2 (one per class) or 16 (class + 2 * (block mod 8): XCD-weighted parts) */
-    uint32_t xcd_weight[8];      /* the relative die speeds the parts were weighted with (sets == 16), else 0 */
+    uint32_t xcd_weight[8];      /* the relative die speeds the parts were weighted with (xcd_mode != 0), else 0 */
+    uint32_t xcd_mode;           /* 0: no XCD weights; 1: "spread" (16 table sets: the parts of every block spread over the dies); 2: "class-aware"
+                                    (round 4): the blocks that run the half-ring group -- 3.1 % more steps at 65 536 bodies -- put their parts on
+                                    the four FASTEST dies, the others on the four slowest, every part sized by its die (2 table sets + wgmap) */
+    uint32_t wgmap_offset, wgmap_entries;   /* class-aware: tables[wgmap_offset + y * blocks + x] = (block of the launch << 16) | part that
+                                               workgroup (x, y) of the grid runs; wgmap_entries = blocks * parts (0: none) */
+    uint32_t class_die[8];       /* class-aware: dispatch slots (workgroup number mod 8) of class 0's four dies, then class 1's, fastest first */
     uint32_t a0, nbl;
     uint32_t active_compute_units;  /* sharded: compute units that really take this process's workgroups (probed; a CU mask leaves fewer) */
     uint32_t exchange_workgroups;   /* sharded: most workgroups the exchange launch may have (they must all be resident at once) */
@@ -453,7 +462,7 @@ typedef struct mapn_sym_plan_info {
 } mapn_sym_plan_info;
 int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2,
                            uint32_t waves, uint32_t wave_bias_hi, uint32_t wave_bias_lo, const uint32_t *xcd_weights,
-                           uint32_t launch_blocks, mapn_sym_plan_info *info,
+                           uint32_t launch_blocks, uint32_t launch_a0, uint32_t xcd_mode, mapn_sym_plan_info *info,
                            uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity);
 /* Two-call pattern: first with windows = tables = NULL to learn info->windows and info->windows * info->table_stride, then with
  * buffers; BOTH capacities are counted in uint32 (4 per window) and checked -- a caller that sized its arrays from an earlier plan

@@ -77,6 +77,7 @@ class SymPlanInfo(C.Structure):
         ("parts", C.c_uint32), ("taper1", C.c_uint32), ("taper2", C.c_uint32), ("waves", C.c_uint32), ("wave_bias", C.c_uint32 * 2),
         ("brows", C.c_uint32), ("max_meetings", C.c_uint32), ("table_stride", C.c_uint32),
         ("sets", C.c_uint32), ("xcd_weight", C.c_uint32 * 8),
+        ("xcd_mode", C.c_uint32), ("wgmap_offset", C.c_uint32), ("wgmap_entries", C.c_uint32), ("class_die", C.c_uint32 * 8),
         ("a0", C.c_uint32), ("nbl", C.c_uint32), ("active_compute_units", C.c_uint32), ("exchange_workgroups", C.c_uint32),
         ("scratch_bytes", C.c_uint64), ("error", C.c_char * 256),
     ]
@@ -143,7 +144,7 @@ SIGNATURES = {
     "mapn_set_shard_overlap": (C.c_int, [_ctx, C.c_int]),
     "mapn_calibrate_sym_xcds": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_uint32 * 8)]),
     "mapn_set_sym_xcd_weights": (C.c_int, [_ctx, C.POINTER(C.c_uint32 * 8)]),
-    "mapn_sym_plan_describe": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32 * 8), C.c_uint32,
+    "mapn_sym_plan_describe": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32 * 8), C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.POINTER(SymPlanInfo), C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32), C.c_uint64]),
     "mapn_get_sym_plan": (C.c_int, [_ctx, C.POINTER(SymPlanInfo), C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32), C.c_uint64]),
     "mapn_set_sym_plan": (C.c_int, [_ctx, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),

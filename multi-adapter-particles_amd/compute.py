@@ -274,7 +274,7 @@ class Compute:
         info = _lib.SymPlanInfo()
         check(self._lib.mapn_get_sym_plan(self._ctx, C.byref(info), None, 0, None, 0))
         win = np.zeros((info.windows, 4), np.uint32)
-        tab = np.zeros(info.windows * info.table_stride, np.uint32)
+        tab = np.zeros(info.windows * info.table_stride + info.wgmap_entries, np.uint32)
         u32p = C.POINTER(C.c_uint32)
         check(self._lib.mapn_get_sym_plan(self._ctx, C.byref(info), win.ctypes.data_as(u32p), win.size, tab.ctypes.data_as(u32p), tab.size))
         return SymPlan(info, win, tab)
@@ -360,10 +360,17 @@ class SymPlan:
     def __init__(self, info, windows, tables):
         self.info, self.windows, self.tables = info, windows, tables
         self.wave_bias = (int(info.wave_bias[0]), int(info.wave_bias[1]))
-        for k in ("nb", "groups", "parts", "taper1", "taper2", "waves", "brows", "max_meetings", "table_stride", "sets", "a0", "nbl", "active_compute_units", "exchange_workgroups", "scratch_bytes"):
+        for k in ("nb", "groups", "parts", "taper1", "taper2", "waves", "brows", "max_meetings", "table_stride", "sets", "a0", "nbl", "active_compute_units", "exchange_workgroups", "scratch_bytes",
+                  "xcd_mode", "wgmap_offset", "wgmap_entries"):
             setattr(self, k, int(getattr(info, k)))
         self.nwaves = self.parts * self.waves
         self.xcd_weight = list(info.xcd_weight)
+        # class-aware XCD weights (xcd_mode 2): class_die[c] = the four dispatch slots class c's blocks run on; wgmap[y, x] = (block, part) of workgroup (x, y)
+        self.class_die = [list(info.class_die)[:4], list(info.class_die)[4:]]
+        self.wgmap = None
+        if self.wgmap_entries:
+            m = np.asarray(tables[self.wgmap_offset:self.wgmap_offset + self.wgmap_entries], np.uint32).reshape(self.parts, -1)
+            self.wgmap = np.stack([m >> 16, m & 0xffff], axis=-1)
 
     def set_of(self, cls: int, block_in_launch: int = 0) -> int:
         """Table set of a block: its class, plus 2 * (block mod 8) when the parts are XCD-weighted."""
@@ -379,19 +386,19 @@ class SymPlan:
 
 
 def describe_sym_plan(nb: int, groups_per_window: int = 0, parts: int = 32, taper1: int | None = None, taper2: int = 0, waves: int = 4,
-                      xcd_weights=None, launch_blocks: int = 0, wave_bias=(1, 1)) -> SymPlan:
+                      xcd_weights=None, launch_blocks: int = 0, wave_bias=(1, 1), launch_a0: int = 0, xcd_mode: int = 0) -> SymPlan:
     """The plan of a shape, computed on the host without a device (csrc/mapn_sym_plan.cpp)."""
     lib = load_library()
     info = _lib.SymPlanInfo()
     t1 = parts if taper1 is None else taper1
     xw = C.byref((C.c_uint32 * 8)(*[int(x) for x in xcd_weights])) if xcd_weights is not None else None
-    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, int(wave_bias[0]), int(wave_bias[1]), xw, launch_blocks, C.byref(info), None, 0, None, 0)
+    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, int(wave_bias[0]), int(wave_bias[1]), xw, launch_blocks, launch_a0, xcd_mode, C.byref(info), None, 0, None, 0)
     if rc:
         raise MapnError(rc, info.error.decode(errors="replace"))
     win = np.zeros((info.windows, 4), np.uint32)
-    tab = np.zeros(info.windows * info.table_stride, np.uint32)
+    tab = np.zeros(info.windows * info.table_stride + info.wgmap_entries, np.uint32)
     u32p = C.POINTER(C.c_uint32)
-    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, int(wave_bias[0]), int(wave_bias[1]), xw, launch_blocks, C.byref(info), win.ctypes.data_as(u32p), win.size, tab.ctypes.data_as(u32p), tab.size)
+    rc = lib.mapn_sym_plan_describe(nb, groups_per_window, parts, t1, taper2, waves, int(wave_bias[0]), int(wave_bias[1]), xw, launch_blocks, launch_a0, xcd_mode, C.byref(info), win.ctypes.data_as(u32p), win.size, tab.ctypes.data_as(u32p), tab.size)
     if rc:
         raise MapnError(rc, info.error.decode(errors="replace"))
     return SymPlan(info, win, tab)

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mapn_sym_plan.h"   // sym_runs_half: which block of a half-ring pair runs its meetings
+
 namespace mapn {
 
 enum { KERNEL_LDS = 1, KERNEL_SGPR = 2, KERNEL_SYM = 3 };
@@ -60,18 +62,6 @@ struct ForcePlan {
 enum { SYM_K2 = 8,                     // packed pairs of bodies i per lane
        SYM_BLOCK = 128 * SYM_K2,       // bodies per I-block (one wave)
        SYM_JPI = SYM_BLOCK / 64 };     // 64-body J-blocks per I-block
-// Which block of a half-ring pair (p, p + nb / 2) runs their meetings (even block counts; `half` = nb / 2, else 0): the pairs
-// ALTERNATE -- p even: block p, p odd: block p + nb / 2 -- so that the extra group is spread evenly over the two halves of the
-// ring, i.e. over the ranks of a sharded job (until round 3 the first half ran all of them: at 65 536 / 8 ranks 0 .. 3 ran 528
-// meetings each and ranks 4 .. 7 512, and every step waited for the heavy half).  The runner's class is 0, the other's 1.
-__host__ __device__ inline bool sym_runs_half(uint32_t a, uint32_t half)
-{
-    if (!half) return false;
-    const bool low = a < half;
-    const uint32_t p = low ? a : a - half;
-    return ((p & 1u) == 0u) == low;
-}
-
 struct SymArgs {
     const float4 *pos_old;
     const float  *vel_old;
@@ -88,7 +78,8 @@ struct SymArgs {
     uint32_t      parts;      // workgroups per I-block (gridDim.y)
     uint32_t      nwaves;     // parts * waves per workgroup
     uint32_t      max_meetings;
-    uint32_t      sets;       // table sets: 2, or 16 = XCD-weighted parts: workgroup (x, y) runs part y of block (x + y) mod blocks, set = class + 2 * (block mod 8)
+    uint32_t      sets;       // table sets: 2, or 16 = XCD-weighted parts ("spread"): workgroup (x, y) runs part y of block (x + y) mod blocks, set = class + 2 * (block mod 8)
+    const uint32_t *wgmap;    // XCD-weighted parts, class-aware form: workgroup (x, y) runs (block << 16 | part) = wgmap[y * gridDim.x + x] (null: the mappings above)
     uint32_t      g0, g1;     // meeting groups of this launch: 0 the block itself, 1 .. D partner a + g, D + 1 the half-ring partner
     uint32_t      brows;      // rows allocated per J-block (symmetric groups of the widest window)
     uint32_t      half_d;     // nb / 2 when nb is even (the half-ring partner), else 0

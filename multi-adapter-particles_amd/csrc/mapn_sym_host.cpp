@@ -145,8 +145,11 @@ int prepare_sym(mapn_ctx *c, bool sharded)
     }
     std::string err;
     bool built = false;
+    // XCD weights: class-aware where it applies (heavy blocks on the fast dies), else spread; MAPN_SYM_XCD_MODE=spread: the A/B of the earlier form
+    static const uint32_t xcd_mode = [] { const char *e = getenv("MAPN_SYM_XCD_MODE"); return (e && e[0] == 's') ? 1u : 0u; }();
     for (const Shape &sh : tries)
-        if ((built = mapn::build_sym_plan(nb, gpw, sh.parts, sh.t1, sh.t2, sh.waves, sh.hi, sh.lo, c->sym_xcd_weighted ? c->sym_xcd_w : nullptr, nbl, c->sym_plan, err))) break;
+        if ((built = mapn::build_sym_plan(nb, gpw, sh.parts, sh.t1, sh.t2, sh.waves, sh.hi, sh.lo, c->sym_xcd_weighted ? c->sym_xcd_w : nullptr, nbl,
+                                          sharded ? (uint32_t)c->cfg.rank * nbl : 0u, xcd_mode, c->sym_plan, err))) break;
     if (!built) {
         c->sym_note = err;
         return must ? fail(MAPN_ERR_INVALID_ARGUMENT, "%s", err.c_str()) : MAPN_OK;
@@ -241,6 +244,7 @@ mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t win
     a.pos_old = base.pos_old; a.vel_old = base.vel_old; a.pos_new = base.pos_new; a.vel_new = base.vel_new;
     a.arow = c->sym_arow; a.brow = c->sym_brow; a.brow1 = c->sym_brow1;
     a.tab = c->sym_tab + window * pl.table_stride;
+    a.wgmap = pl.wgmap_entries ? c->sym_tab + pl.wgmap_offset : nullptr;
     a.n = c->n; a.n_integrate = c->n; a.nb = pl.nb; a.parts = pl.parts; a.nwaves = pl.nwaves; a.max_meetings = pl.max_meetings; a.sets = pl.sets;
     a.g0 = pl.windows[window].g0; a.g1 = pl.windows[window].g1;
     a.brows = pl.brows; a.half_d = pl.half;
@@ -556,11 +560,17 @@ int mapn_calibrate_sym_xcds(mapn_ctx *c, int steps, uint32_t out[8])
         // on this device and the weighting would be meaningless.
         const mapn::SymPlanHost &pl = c->sym_plan;
         const uint32_t nblk = c->sym_sharded ? c->count / mapn::SYM_BLOCK : pl.nb;
+        std::vector<uint32_t> wg_x(pl.wgmap_entries);                                             // class-aware plan: (block, part) -> blockIdx.x
+        for (uint32_t e = 0; e < pl.wgmap_entries; e++) {
+            const uint32_t m = pl.tables[pl.wgmap_offset + e];
+            wg_x[(size_t)(m >> 16) * pl.parts + (m & 0xffffu)] = e % nblk;
+        }
         if (nblk % 8u) return fail(MAPN_ERR_STATE, "calibrate_sym_xcds: a launch covers %u blocks, not a multiple of 8: XCD weights do not apply", nblk);
         for (size_t wv = 0; wv < c->timeline_last; wv++) {
             const unsigned long long *o = &tl[6 * wv];
             const uint32_t wg = (uint32_t)(wv / pl.waves), la = wg / pl.parts, part = wg % pl.parts;
-            const uint32_t x = pl.sets > 2u ? (la + nblk * pl.parts - part) % nblk : la;      // blockIdx.x of the workgroup: its number mod 8 is x mod 8
+            uint32_t x = pl.sets > 2u ? (la + nblk * pl.parts - part) % nblk : la;            // blockIdx.x of the workgroup: its number mod 8 is x mod 8
+            if (pl.wgmap_entries) x = wg_x[(size_t)la * pl.parts + part];                     // (class-aware plan: from the workgroup map)
             const unsigned slot = x & 7u, xcc = (unsigned)((o[4] >> 32) & 15u);
             if (o[5] < 64 || o[2] <= o[1]) continue;
             if (slot_xcc[slot] < 0) slot_xcc[slot] = (int)xcc;
@@ -595,6 +605,8 @@ int mapn_get_sym_plan(mapn_ctx *c, mapn_sym_plan_info *info, uint32_t *windows, 
     info->wave_bias[0] = p.bias_hi; info->wave_bias[1] = p.bias_lo;
     info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
     info->sets = p.sets; for (int k = 0; k < 8; k++) info->xcd_weight[k] = p.xcd_weight[k];
+    info->xcd_mode = p.xcd_mode; info->wgmap_offset = p.wgmap_offset; info->wgmap_entries = p.wgmap_entries;
+    for (int k = 0; k < 8; k++) info->class_die[k] = p.class_die[k / 4][k % 4];
     info->a0 = c->sym_sharded ? (uint32_t)c->cfg.rank * (c->count / mapn::SYM_BLOCK) : 0u;
     info->nbl = c->sym_sharded ? c->count / mapn::SYM_BLOCK : 0u;
     info->scratch_bytes = c->sym_scratch_bytes;

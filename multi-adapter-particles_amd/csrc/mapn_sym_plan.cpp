@@ -20,7 +20,8 @@ uint32_t units(uint32_t x, uint32_t t1, uint32_t t2)
 }  // namespace
 
 bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t waves,
-                    uint32_t bias_hi, uint32_t bias_lo, const uint32_t *xcd_weight, uint32_t launch_blocks, SymPlanHost &out, std::string &err)
+                    uint32_t bias_hi, uint32_t bias_lo, const uint32_t *xcd_weight, uint32_t launch_blocks, uint32_t launch_a0, uint32_t xcd_mode,
+                    SymPlanHost &out, std::string &err)
 {
     char msg[256];
     if (bias_hi == 0u && bias_lo == 0u) bias_hi = bias_lo = 1u;
@@ -42,8 +43,38 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
         for (int k = 0; k < 8; k++) weighted = weighted || xcd_weight[k] != xcd_weight[0];
         for (int k = 0; k < 8; k++) if (xcd_weight[k] == 0u || xcd_weight[k] > 4096u) { err = "symmetric plan: XCD weights must be 1 .. 4096 (1024 = the fastest die)"; return false; }   // (bounded so that cost x weight sums stay far inside 64 bits: ADVICE r3)
     }
-    p.sets = weighted ? 16u : 2u;
+    // class-aware where it applies: heavy blocks (class 0) on the four fastest dies, the others on the four slowest
+    const uint32_t B = launch_blocks ? launch_blocks : nb;
+    std::vector<uint32_t> cls_blocks[2];
+    if (weighted && xcd_mode != 1u && p.half && parts % 4u == 0u && B <= 65535u && parts <= 65535u)
+        for (uint32_t la = 0; la < B; la++) cls_blocks[sym_runs_half(launch_a0 + la, p.half) ? 0 : 1].push_back(la);
+    const bool class_aware = !cls_blocks[0].empty() && cls_blocks[0].size() == cls_blocks[1].size();
+    p.xcd_mode = !weighted ? 0u : class_aware ? 2u : 1u;
+    p.sets = p.xcd_mode == 1u ? 16u : 2u;
     for (int k = 0; k < 8; k++) p.xcd_weight[k] = weighted ? xcd_weight[k] : 0u;
+    uint32_t die_class[8] = {0, 0, 0, 0, 0, 0, 0, 0}, die_rank[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // of a dispatch slot: its class and its place among the class's dies
+    if (class_aware) {
+        // which four dies take the heavy blocks: of the 70 ways to split the eight dies 4 : 4, the one whose speed ratio comes
+        // closest to the classes' work ratio -- (groups of a class-0 block) / sum of its dies' speeds against the same for class 1,
+        // the larger of the two as small as possible (65 536 bodies: 33 : 32 groups, so the faster four; 262 144: 129 : 128, a
+        // nearly even split)
+        const uint64_t work[2] = {(uint64_t)gsym + 1u, (uint64_t)gsym};               // groups of a step, the block itself included
+        uint32_t best_mask = 0x0f;
+        double best = 1e300;
+        for (uint32_t mask = 0; mask < 256u; mask++) {
+            if (__builtin_popcount(mask) != 4) continue;
+            uint64_t sa = 0, sb = 0;
+            for (uint32_t d = 0; d < 8u; d++) ((mask >> d) & 1u ? sa : sb) += xcd_weight[d];
+            const double cost = std::max((double)work[0] / (double)sa, (double)work[1] / (double)sb);
+            if (cost < best) { best = cost; best_mask = mask; }
+        }
+        for (uint32_t c = 0; c < 2u; c++) {
+            uint32_t dies[4], n = 0;
+            for (uint32_t d = 0; d < 8u; d++) if ((((best_mask >> d) & 1u) != 0u) == (c == 0u)) dies[n++] = d;
+            std::stable_sort(dies, dies + 4, [&](uint32_t a, uint32_t b) { return xcd_weight[a] > xcd_weight[b]; });
+            for (uint32_t k = 0; k < 4u; k++) { p.class_die[c][k] = dies[k]; die_class[dies[k]] = c; die_rank[dies[k]] = k; }
+        }
+    }
     // windows: the symmetric groups in nwin runs of (nearly) equal length; the block itself rides in the first
     const uint32_t cap = groups_per_window ? groups_per_window : std::max(1u, gsym);
     const uint32_t nwin = std::max(1u, (gsym + cap - 1u) / cap);
@@ -76,6 +107,7 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
             // weight of part s: its size in the taper (4 : 2 : 1) times the speed of the die it runs on
             auto part_weight = [&](uint32_t s) -> uint64_t {
                 const uint64_t size = units(s + 1u, taper1, taper2) - units(s, taper1, taper2);
+                if (class_aware) return size * p.xcd_weight[p.class_die[cls][s & 3u]];      // part s runs on the (s mod 4)-th die of its class
                 return size * (weighted ? p.xcd_weight[(r + 8u * parts - s) & 7u] : 1u);
             };
             // the first half of a workgroup's waves (the older wave of every SIMD) weighs bias_hi, the second half bias_lo
@@ -121,6 +153,19 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
             }
         }
     }
+    if (class_aware) {
+        // which (block, part) workgroup (x, y) of the grid runs: it lands on die x mod 8 -- the k-th die of class c -- and takes,
+        // in the order u = x / 8 + (B / 8) y, part 4 (u / (B / 2)) + k of the class's block number u mod (B / 2)
+        p.wgmap_offset = (uint32_t)p.tables.size();
+        p.wgmap_entries = B * parts;
+        p.tables.resize(p.tables.size() + p.wgmap_entries);
+        for (uint32_t y = 0; y < parts; y++)
+            for (uint32_t x = 0; x < B; x++) {
+                const uint32_t d = x & 7u, c = die_class[d], k = die_rank[d], u = x / 8u + (B / 8u) * y;
+                const uint32_t la = cls_blocks[c][u % (B / 2u)], part = 4u * (u / (B / 2u)) + k;
+                p.tables[p.wgmap_offset + (size_t)y * B + x] = (la << 16) | part;
+            }
+    }
     out = std::move(p);
     return true;
 }
@@ -129,13 +174,14 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
 
 // ---- C ABI: the plan as data, without a device (tests, the order-matched oracle) ------------------
 extern "C" int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2,
-                                      uint32_t waves, uint32_t wave_bias_hi, uint32_t wave_bias_lo, const uint32_t *xcd_weights, uint32_t launch_blocks, mapn_sym_plan_info *info,
+                                      uint32_t waves, uint32_t wave_bias_hi, uint32_t wave_bias_lo, const uint32_t *xcd_weights, uint32_t launch_blocks,
+                                      uint32_t launch_a0, uint32_t xcd_mode, mapn_sym_plan_info *info,
                                       uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity)
 {
     if (!info) return MAPN_ERR_INVALID_ARGUMENT;
     mapn::SymPlanHost p;
     std::string err;
-    if (!mapn::build_sym_plan(nb, groups_per_window, parts, taper1, taper2, waves, wave_bias_hi, wave_bias_lo, xcd_weights, launch_blocks, p, err)) {
+    if (!mapn::build_sym_plan(nb, groups_per_window, parts, taper1, taper2, waves, wave_bias_hi, wave_bias_lo, xcd_weights, launch_blocks, launch_a0, xcd_mode, p, err)) {
         snprintf(info->error, sizeof info->error, "%s", err.c_str());
         return MAPN_ERR_INVALID_ARGUMENT;
     }
@@ -144,6 +190,8 @@ extern "C" int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, u
     info->parts = p.parts; info->taper1 = p.taper1; info->taper2 = p.taper2; info->waves = p.waves; info->wave_bias[0] = p.bias_hi; info->wave_bias[1] = p.bias_lo;
     info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
     info->sets = p.sets; for (int k = 0; k < 8; k++) info->xcd_weight[k] = p.xcd_weight[k];
+    info->xcd_mode = p.xcd_mode; info->wgmap_offset = p.wgmap_offset; info->wgmap_entries = p.wgmap_entries;
+    for (int k = 0; k < 8; k++) info->class_die[k] = p.class_die[k / 4][k % 4];
     info->a0 = 0; info->nbl = 0; info->active_compute_units = 0; info->exchange_workgroups = 0; info->scratch_bytes = 0;
     if (windows && windows_capacity < 4u * p.windows.size()) {
         snprintf(info->error, sizeof info->error, "windows_capacity %llu < %zu", (unsigned long long)windows_capacity, 4u * p.windows.size());

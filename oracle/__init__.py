@@ -57,7 +57,7 @@ def sym_plan_args(plan):
     """(SymShape, windows, tables) from a plan object as the product's binding returns it (duck-typed: attributes
     nb, groups, parts, waves, brows, max_meetings, table_stride, sets and the uint32 arrays windows [k, 4], tables)."""
     win = np.ascontiguousarray(plan.windows, np.uint32)
-    tab = np.ascontiguousarray(plan.tables, np.uint32)
+    tab = np.ascontiguousarray(plan.tables, np.uint32)[:win.shape[0] * plan.table_stride]   # (a class-aware plan appends its workgroup map -- which workgroup runs a (block, part) does not change any sum)
     shape = SymShape(plan.nb, plan.groups, win.shape[0], plan.parts, plan.waves, plan.brows, plan.max_meetings, plan.table_stride, getattr(plan, "sets", 2))
     assert tab.size == win.shape[0] * plan.table_stride
     return shape, win, tab

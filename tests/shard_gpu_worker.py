@@ -92,7 +92,7 @@ def main():
             assert c.sym_plan().waves == 4 and c.sym_plan().wave_bias == (1, 1), (c.sym_plan().waves, c.sym_plan().wave_bias)
         if os.environ.get("MAPN_WORKER_XCD_W") and mode in ("sym", "sympush"):
             c.set_sym_xcd_weights([int(x) for x in os.environ["MAPN_WORKER_XCD_W"].split(",")])
-            assert c.sym_plan().sets == (16 if (count // 1024) % 8 == 0 else 2)
+            assert (c.sym_plan().xcd_mode != 0) == ((count // 1024) % 8 == 0)
         if os.environ.get("HSA_CU_MASK") and mode in ("sym", "sympush") and count % 1024 == 0:
             plan = c.sym_plan()                 # the probe must have seen the mask, and the launch must be sized for it
             assert plan.active_compute_units <= 64 and plan.exchange_workgroups <= 4 * plan.active_compute_units, (plan.active_compute_units, plan.exchange_workgroups)

@@ -107,11 +107,13 @@ def test_symmetric_kernel_against_its_order_matched_oracle(oracle, n, shape):
     assert errs(v, rv, SPEED)[0] < 1e-6
 
 
-@pytest.mark.parametrize("n", [8192, 65536])
+@pytest.mark.parametrize("n", [8192, 65536, 73728])
 def test_xcd_weighted_parts_against_the_order_matched_oracle(oracle, n):
     """mapn_calibrate_sym_xcds returns eight relative die speeds; with them (and with a deliberately lopsided set) the parts of
-    every block are spread over the dies and sized by their speed -- another summation order, restated by the oracle from the
-    same 16-set plan: bit-identical for most bodies again, and bit-reproducible for given weights."""
+    every block are sized by the speed of the die they run on -- class-aware where it applies (the blocks with the half-ring group on
+    the faster dies: 8192 and 65 536 bodies), spread over all dies otherwise (73 728 bodies: 72 blocks x 7 parts) -- another
+    summation order, restated by the oracle from the same plan: bit-identical for most bodies again, and bit-reproducible for
+    given weights."""
     mass = 70000.0 / n
     pos, vel = oracle.initial_state(n, seed=6)
     with mapn.Compute(n, mass=mass, seed=6, kernel=mapn.KERNEL_SYMMETRIC) as c:
@@ -123,7 +125,12 @@ def test_xcd_weighted_parts_against_the_order_matched_oracle(oracle, n):
             c.set_sym_xcd_weights(weights)
             plan = c.sym_plan()
             if len(set(weights)) > 1:
-                assert plan.sets == 16 and plan.xcd_weight == list(weights)
+                # 65 536 bodies: 64 blocks x 4 parts -> the class-aware form (heavy blocks on the faster dies); 8192: 8 x 32 likewise
+                if n == 73728:
+                    assert plan.xcd_mode == 1 and plan.sets == 16 and plan.wgmap is None and plan.parts % 4 != 0
+                else:
+                    assert plan.xcd_mode == 2 and plan.sets == 2 and plan.wgmap is not None
+                assert plan.xcd_weight == list(weights)
             draw(c, 2)
             p, v = c.download_state()
             c.upload_state(pos, vel)
@@ -135,7 +142,7 @@ def test_xcd_weighted_parts_against_the_order_matched_oracle(oracle, n):
             rel = np.linalg.norm(p[:, :3].astype(np.float64) - rp[:, :3], axis=1) / np.maximum(np.linalg.norm(rp[:, :3].astype(np.float64), axis=1), 1e-30)
             assert rel.max() <= 3e-7 and float((p[:, :3] == rp[:, :3]).all(axis=1).mean()) >= 0.9, rel.max()
         c.set_sym_xcd_weights(None)
-        assert c.sym_plan().sets == 2
+        assert c.sym_plan().sets == 2 and c.sym_plan().xcd_mode == 0
 
 
 def test_windows_of_partner_distance_change_only_the_rounding(oracle):
@@ -247,7 +254,7 @@ def test_xcd_calibration_at_creation_gives_the_weighted_plan_and_leaves_the_stat
     pos0, vel0 = oracle.initial_state(n, seed=1)
     with mapn.Compute(n, mass=70000.0 / n, flags=mapn.FLAG_XCD_CALIBRATE) as c:
         pl = c.sym_plan()
-        assert pl.sets == 16 and max(pl.xcd_weight) == 1024 and min(pl.xcd_weight) > 850, pl.xcd_weight
+        assert pl.xcd_mode == 2 and pl.wgmap is not None and max(pl.xcd_weight) == 1024 and min(pl.xcd_weight) > 850, pl.xcd_weight
         assert (pl.waves, pl.parts, pl.wave_bias) == (8, 4, (10, 3))
         assert c.GetFenceValue() == 4 and c.buffer_index == 0 and c.GetCompletedValue() <= 3
         for b in (0, 1):
@@ -264,12 +271,12 @@ def test_xcd_calibration_at_creation_gives_the_weighted_plan_and_leaves_the_stat
         assert errs(p3[:, :3], q3[:, :3], SPREAD)[0] < 1e-6
         # migrate (Particles.cpp:515-516) with the flag: the copy calibrates on the copied state and continues like the source
         with mapn.Compute(n, mass=70000.0 / n, flags=mapn.FLAG_XCD_CALIBRATE, old=c) as m:
-            assert m.sym_plan().sets == 16
+            assert m.sym_plan().xcd_mode == 2
             c.set_sym_xcd_weights(m.sym_plan().xcd_weight)     # (same weights on both, so that the two continue bit for bit)
             draw(c, 2); draw(m, 2)
             np.testing.assert_array_equal(c.download_state()[0], m.download_state()[0])
     with mapn.Compute(69632, mass=70000.0 / 69632, flags=mapn.FLAG_XCD_CALIBRATE) as c:    # 68 blocks
-        assert c.sym_plan().sets == 2 and c.GetFenceValue() == 4
+        assert c.sym_plan().xcd_mode == 0 and c.GetFenceValue() == 4
         draw(c, 1)
         assert c.kernel_stats().kernel_name.decode() == "force_sym_kernel"
     with mapn.Compute(4096, mass=70000.0 / 4096, flags=mapn.FLAG_XCD_CALIBRATE, kernel=mapn.KERNEL_SCALAR) as c:   # one-sided kernel: nothing to weigh

@@ -133,12 +133,15 @@ XCD_W = [1024, 970, 1010, 1000, 1020, 985, 1024, 990]      # what a calibration 
 
 
 def test_xcd_weighted_parts_are_sized_by_the_speed_of_the_die_they_run_on():
-    """mapn_set_sym_xcd_weights: with weights the plan has 16 table sets (class + 2 * (block mod 8)); part s of a block whose
+    """mapn_set_sym_xcd_weights, the SPREAD form (xcd_mode 1; what runs where the class-aware form does not apply, e.g. 63 blocks):
+    with weights the plan has 16 table sets (class + 2 * (block mod 8)); part s of a block whose
     index is r mod 8 runs on die (r - s) mod 8 and its waves get steps in proportion to that die's speed; equal weights, or a
     launch that does not cover a multiple of 8 blocks, give the default plan."""
     import mapn
-    plan = mapn.describe_sym_plan(64, 0, 32, None, 0, 4, xcd_weights=XCD_W)
-    assert plan.sets == 16 and plan.xcd_weight == XCD_W
+    plan = mapn.describe_sym_plan(64, 0, 32, None, 0, 4, xcd_weights=XCD_W, xcd_mode=1)
+    assert plan.sets == 16 and plan.xcd_weight == XCD_W and plan.xcd_mode == 1 and plan.wgmap is None
+    assert mapn.describe_sym_plan(72, 0, 30, None, 0, 4, xcd_weights=XCD_W).xcd_mode == 1      # parts not a multiple of 4: spread
+    assert mapn.describe_sym_plan(8 * 9 + 8, 0, 32, None, 0, 4, xcd_weights=XCD_W, launch_blocks=8, launch_a0=8).xcd_mode == 2
     base = mapn.describe_sym_plan(64, 0, 32, None, 0, 4)
     assert base.sets == 2 and mapn.describe_sym_plan(64, 0, 32, None, 0, 4, xcd_weights=[1000] * 8).sets == 2
     assert mapn.describe_sym_plan(98, 0, 32, None, 0, 4, xcd_weights=XCD_W).sets == 2          # 100 000 bodies: 98 blocks
@@ -151,6 +154,61 @@ def test_xcd_weighted_parts_are_sized_by_the_speed_of_the_die_they_run_on():
             want = w / w.sum() * b[-1]
             assert np.abs(per_part - want).max() <= 4, (r, cls)       # whole steps: a few steps of slack
             assert b[-1] == np.diff(base.bounds(0, cls).astype(np.int64)).sum()
+
+
+@pytest.mark.parametrize("nb,parts,waves,bias,blocks,a0", [(64, 4, 8, (10, 3), 0, 0), (64, 32, 8, (2, 1), 8, 0), (64, 32, 8, (2, 1), 8, 32), (128, 4, 8, (10, 3), 0, 0),
+                                                             (256, 8, 4, (1, 1), 32, 96), (16, 8, 4, (1, 1), 0, 0)])
+def test_class_aware_xcd_weights_put_the_heavy_blocks_on_the_fast_dies(nb, parts, waves, bias, blocks, a0):
+    """Round 4: the blocks that run the half-ring group (class 0) carry one group more than the others -- 3.1 % at 65 536 bodies --
+    and in a one-round launch nothing hides it; the dies' speeds differ by about as much.  With XCD weights the plan therefore maps
+    every class-0 block's parts onto four of the dies and every class-1 block's onto the other four -- the 4 : 4 split whose speed
+    ratio best matches the classes' work ratio: the faster four for the heavy blocks at 65 536 bodies -- a quarter of the
+    block's parts per die, each sized by its die's speed.  The workgroup map is a bijection onto (block, part); workgroup (x, y)
+    lands on die x mod 8; the tables stay per class."""
+    import mapn
+    from mapn import shard
+    plan = mapn.describe_sym_plan(nb, 0, parts, None, 0, waves, xcd_weights=XCD_W, wave_bias=bias, launch_blocks=blocks, launch_a0=a0)
+    B = blocks or nb
+    assert plan.xcd_mode == 2 and plan.sets == 2 and plan.wgmap.shape == (parts, B, 2)
+    # the 4 : 4 split of the dies whose speed ratio best matches the classes' work ratio (groups D + 2 : D + 1), each class's dies fastest first
+    import itertools
+    D = (nb - 1) // 2
+    cost = lambda A: max((D + 2) / sum(XCD_W[d] for d in A), (D + 1) / sum(XCD_W[d] for d in range(8) if d not in A))
+    best = min(itertools.combinations(range(8), 4), key=lambda A: (round(cost(A), 12), sum(1 << d for d in A)))
+    assert abs(cost(plan.class_die[0]) - cost(best)) < 1e-12 and sorted(plan.class_die[0] + plan.class_die[1]) == list(range(8))
+    for c in (0, 1):
+        assert [XCD_W[d] for d in plan.class_die[c]] == sorted((XCD_W[d] for d in plan.class_die[c]), reverse=True)
+    seen = set()
+    for y in range(parts):
+        for x in range(B):
+            la, s = (int(v) for v in plan.wgmap[y, x])
+            cls = shard.sym_block_class(nb, a0 + la)
+            assert (la, s) not in seen and la < B and s < parts
+            seen.add((la, s))
+            assert x % 8 == plan.class_die[cls][s % 4]             # part s of a class-c block runs on the (s mod 4)-th die of class c
+    assert len(seen) == B * parts
+    base = mapn.describe_sym_plan(nb, 0, parts, None, 0, waves, wave_bias=bias, launch_blocks=blocks, launch_a0=a0)
+    for cls in (0, 1):
+        b = plan.bounds(0, cls).astype(np.int64)
+        assert b[0] == 0 and b[-1] == base.bounds(0, cls)[-1]      # the same steps in total, dealt differently
+        per_part = np.diff(b).reshape(parts, waves).sum(axis=1)
+        w = np.array([XCD_W[plan.class_die[cls][s % 4]] for s in range(parts)], np.float64)
+        assert np.abs(per_part - w / w.sum() * b[-1]).max() <= 2 * waves, (cls, per_part)
+    # what it is for: time of a part = steps / speed of its die -- the slowest workgroup of the launch is earlier than with either
+    # the default plan (every die holds heavy blocks) or the spread form (which equalises the dies but not the classes)
+    def worst(pl, die_of):
+        t = 0.0
+        for la in range(B):
+            cls = shard.sym_block_class(nb, a0 + la)
+            b = pl.bounds(0, pl.set_of(cls, la)).astype(np.int64)
+            per_part = np.diff(b).reshape(parts, waves).sum(axis=1)
+            t = max(t, max(per_part[s] / XCD_W[die_of(pl, la, s, cls)] for s in range(parts)))
+        return t
+    t_class = worst(plan, lambda pl, la, s, cls: pl.class_die[cls][s % 4])
+    t_default = worst(base, lambda pl, la, s, cls: la % 8)
+    spread = mapn.describe_sym_plan(nb, 0, parts, None, 0, waves, xcd_weights=XCD_W, wave_bias=bias, launch_blocks=blocks, launch_a0=a0, xcd_mode=1)
+    t_spread = worst(spread, lambda pl, la, s, cls: (la - s) % 8)
+    assert t_class < t_default and t_class <= t_spread * 1.001, (t_class, t_spread, t_default)
 
 
 def test_wave_bias_gives_the_older_waves_of_a_workgroup_the_larger_share():
@@ -186,7 +244,7 @@ def test_force_kernel_writes_exactly_the_rows_the_reduce_kernel_reads(nb, gpw, p
     it is cut between two workgroups -- then its last steps go to the later workgroup's head row); sym_reduce_integrate_kernel
     reads a meeting's row and, where the split table says so, that very head row -- and nothing else is ever written."""
     import mapn
-    plan = mapn.describe_sym_plan(nb, gpw, parts, t1, t2, waves, xcd_weights=xw, wave_bias=bias)
+    plan = mapn.describe_sym_plan(nb, gpw, parts, t1, t2, waves, xcd_weights=xw, wave_bias=bias, xcd_mode=1)   # (the spread form: its 16 table sets are what this test walks)
     assert plan.sets == (16 if xw else 2) and plan.wave_bias == bias
     D, half = (nb - 1) // 2, (nb // 2 if nb % 2 == 0 else 0)
     for k, w in enumerate(plan.windows):

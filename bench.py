@@ -438,6 +438,43 @@ def main():
     # XCD-aware parts (1 GPU, symmetric kernel): the eight dies do not run at one speed and a launch gives each the same work.
     # Untimed: calibrate, then an A/B of the weighted plan against the default one; the weights stay only if they win.
     xcd = {"mode": a.xcd, "weights": None, "used": False, "source": None}
+    if dist is not None and world > 1 and "symmetric" in gather_algo and a.xcd != "off" and not a.plan:
+        # SHARDED symmetric step: every rank calibrates ITS GPU (mapn_calibrate_sym_xcds: four stamped real steps, collective -- all
+        # ranks call it, and it takes all of its steps before anything can fail) and sizes the parts of its own launch; then an
+        # untimed A/B, MAX over ranks, decides for all of them.  Loopback at 65 536 / 8: 94.4 -> 93.6 us per step.
+        try:
+            def burst_all(k):
+                sync(); t0 = time.perf_counter()
+                for _ in range(k):
+                    step()
+                sync()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t.item()) / k
+            kk = max(20, min(400, int(0.05 / (0.1e-3 * (n / 65536.0) ** 2 * 8 / world))))
+            try:
+                w, ok = c.calibrate_sym_xcds(4), 1
+            except mapn.MapnError as e:
+                w, ok = None, 0
+                xcd["error"] = str(e)[:200]
+            flag = torch.tensor([ok], device=red_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # all ranks or none (each has taken the same number of steps either way)
+            if flag.item():
+                t_def = min(burst_all(kk), burst_all(kk))
+                c.set_sym_xcd_weights(w)
+                t_w = min(burst_all(kk), burst_all(kk))
+                xcd.update({"weights": w, "source": "mapn_calibrate_sym_xcds on every rank (rank 0's weights shown)", "form": {1: "spread", 2: "class-aware"}.get(c.sym_plan().xcd_mode),
+                            "trial_ms": {"default": t_def * 1e3, "weighted": t_w * 1e3}})
+                if a.xcd == "on" or t_w < t_def * 0.998:
+                    xcd["used"] = c.sym_plan().xcd_mode != 0
+                else:
+                    c.set_sym_xcd_weights(None)
+        except mapn.MapnError as e:                            # (a failure here leaves the default plan: the run goes on)
+            xcd["error"] = str(e)[:200]
+            try:
+                c.set_sym_xcd_weights(None)
+            except mapn.MapnError:
+                pass
     if xcd_by_library:
         try:
             def burst(k):

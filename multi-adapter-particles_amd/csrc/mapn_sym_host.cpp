@@ -543,32 +543,44 @@ int mapn_calibrate_sym_xcds(mapn_ctx *c, int steps, uint32_t out[8])
     if (!(sym_eligible(c, c->n) || sym_shard_eligible(c, c->n)))
         return fail(MAPN_ERR_STATE, "calibrate_sym_xcds: the symmetric kernel does not run in this context");
     HIP_TRY(hipSetDevice(c->device));
-    std::vector<double> per[8];
-    int slot_xcc[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    const mapn::SymPlanHost &pl = c->sym_plan;
+    const uint32_t nblk = c->sym_sharded ? c->count / mapn::SYM_BLOCK : pl.nb;
+    // (refused BEFORE a step is taken: in a sharded job every rank calls this, and all of them must take the same number of steps)
+    if (nblk % 8u) return fail(MAPN_ERR_STATE, "calibrate_sym_xcds: a launch covers %u blocks, not a multiple of 8: XCD weights do not apply", nblk);
+    // first ALL the stamped steps (collective in a sharded job: nothing below may cut them short on one rank), then the analysis
+    std::vector<std::vector<unsigned long long>> stamps;
     int rc = MAPN_OK;
     for (int s = 0; s < steps && !rc; s++) {
         c->stamp_next = true; c->calibrating = true;
         rc = mapn_simulate(c, (int)c->n, 0);
         c->stamp_next = false; c->calibrating = false;
         if (!rc) rc = mapn_wait_idle(c);
-        if (rc || !c->timeline_buf || !c->timeline_last) break;
+        if (rc || !c->timeline_buf || !c->timeline_last) continue;
         std::vector<unsigned long long> tl(6 * c->timeline_last);
-        HIP_TRY(hipMemcpy(tl.data(), c->timeline_buf, c->timeline_last * 48, hipMemcpyDeviceToHost));
-        // A die is identified by the DISPATCH SLOT of the workgroups it gets -- workgroup number mod 8, what the plan's
-        // weights are indexed by -- not by its XCC_ID register (the two numberings need not agree); the register only has to
-        // be the same for all waves of a slot, which is checked: if it is not, workgroups are not dealt to the dies round-robin
-        // on this device and the weighting would be meaningless.
-        const mapn::SymPlanHost &pl = c->sym_plan;
-        const uint32_t nblk = c->sym_sharded ? c->count / mapn::SYM_BLOCK : pl.nb;
-        std::vector<uint32_t> wg_x(pl.wgmap_entries);                                             // class-aware plan: (block, part) -> blockIdx.x
-        for (uint32_t e = 0; e < pl.wgmap_entries; e++) {
-            const uint32_t m = pl.tables[pl.wgmap_offset + e];
-            wg_x[(size_t)(m >> 16) * pl.parts + (m & 0xffffu)] = e % nblk;
-        }
-        if (nblk % 8u) return fail(MAPN_ERR_STATE, "calibrate_sym_xcds: a launch covers %u blocks, not a multiple of 8: XCD weights do not apply", nblk);
-        for (size_t wv = 0; wv < c->timeline_last; wv++) {
+        if (hipMemcpy(tl.data(), c->timeline_buf, c->timeline_last * 48, hipMemcpyDeviceToHost) == hipSuccess) stamps.push_back(std::move(tl));
+        else (void)hipGetLastError();
+    }
+    if (rc) return rc;
+    // A die is identified by the DISPATCH SLOT of the workgroups it gets -- workgroup number mod 8, what the plan's
+    // weights are indexed by -- not by its XCC_ID register (the two numberings need not agree); the register only has to
+    // be the same for all waves of a slot, which is checked: if it is not, workgroups are not dealt to the dies round-robin
+    // on this device and the weighting would be meaningless.
+    std::vector<uint32_t> wg_x(pl.wgmap_entries);                                             // class-aware plan: (block, part) -> blockIdx.x
+    for (uint32_t e = 0; e < pl.wgmap_entries; e++) {
+        const uint32_t m = pl.tables[pl.wgmap_offset + e];
+        wg_x[(size_t)(m >> 16) * pl.parts + (m & 0xffffu)] = e % nblk;
+    }
+    std::vector<double> per[8];
+    int slot_xcc[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    // In an 8-wave workgroup the waves 0 .. 3 are the OLDER wave of their SIMDs: the SIMD serves them first, so their time per step
+    // is the die's own speed; the younger waves run in the gaps, and how long those are depends on how many steps the older wave
+    // has -- i.e. on the block's class, not on the die.  Only the older waves are read there.
+    const bool older_only = pl.waves == 8u;
+    for (const std::vector<unsigned long long> &tl : stamps)
+        for (size_t wv = 0; wv < tl.size() / 6; wv++) {
             const unsigned long long *o = &tl[6 * wv];
             const uint32_t wg = (uint32_t)(wv / pl.waves), la = wg / pl.parts, part = wg % pl.parts;
+            if (older_only && wv % pl.waves >= pl.waves / 2u) continue;
             uint32_t x = pl.sets > 2u ? (la + nblk * pl.parts - part) % nblk : la;            // blockIdx.x of the workgroup: its number mod 8 is x mod 8
             if (pl.wgmap_entries) x = wg_x[(size_t)la * pl.parts + part];                     // (class-aware plan: from the workgroup map)
             const unsigned slot = x & 7u, xcc = (unsigned)((o[4] >> 32) & 15u);
@@ -578,8 +590,6 @@ int mapn_calibrate_sym_xcds(mapn_ctx *c, int steps, uint32_t out[8])
                 return fail(MAPN_ERR_STATE, "calibrate_sym_xcds: workgroups of dispatch slot %u ran on XCC %d and %u: not dealt round-robin to the dies", slot, slot_xcc[slot], xcc);
             per[slot].push_back((double)(o[2] - o[1]) / (double)o[5]);   // 100 MHz ticks per step
         }
-    }
-    if (rc) return rc;
     double speed[8], best = 0.0;
     for (int x = 0; x < 8; x++) {
         if (per[x].empty()) return fail(MAPN_ERR_STATE, "calibrate_sym_xcds: no wave was seen in dispatch slot %d (a partitioned or masked device?)", x);

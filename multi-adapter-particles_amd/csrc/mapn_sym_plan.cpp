@@ -128,6 +128,28 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
                                                                    : Ls + (uint32_t)((target - (uint64_t)SYM_COST_SELF * Ls) / SYM_COST_SYM);
             }
             if (bounds[0] != 0u || bounds[p.nwaves] != L) { err = "symmetric plan: internal error (bounds do not span the meetings)"; return false; }
+            // XCD-weighted parts: a part on a slow die is a few per cent smaller, and where the younger waves of a biased workgroup
+            // sit right at the 64-step floor (65 536 / 8: 198 + 66 steps) that pushed them under it and the whole shape was refused
+            // -- the 2 : 1 bias that fitted instead lost what the weights gained.  The floor is kept INSIDE the part: waves under 64
+            // steps are raised to 64 and the part's other waves -- the older ones, which have steps to spare -- give them up.
+            if (weighted && L) {
+                for (uint32_t s = 0; s < parts; s++) {
+                    std::vector<uint32_t> len(waves);
+                    uint32_t lack = 0, spare = 0;
+                    for (uint32_t ww = 0; ww < waves; ww++) {
+                        len[ww] = bounds[s * waves + ww + 1u] - bounds[s * waves + ww];
+                        if (len[ww] < min_steps) lack += min_steps - len[ww]; else spare += len[ww] - min_steps;
+                    }
+                    if (!lack || spare < lack) continue;                   // nothing to do / not to be had: the check below refuses the shape
+                    for (uint32_t ww = 0; ww < waves; ww++) if (len[ww] < min_steps) len[ww] = min_steps;
+                    while (lack) {                                         // one step at a time from the longest wave (the sums involved are a few dozen)
+                        uint32_t big = 0;
+                        for (uint32_t ww = 1; ww < waves; ww++) if (len[ww] > len[big]) big = ww;
+                        len[big]--; lack--;
+                    }
+                    for (uint32_t ww = 0; ww + 1u < waves; ww++) bounds[s * waves + ww + 1u] = bounds[s * waves + ww] + len[ww];
+                }
+            }
             for (uint32_t v = 0; v < p.nwaves && L; v++) {
                 if (bounds[v + 1u] - bounds[v] < min_steps) {
                     snprintf(msg, sizeof msg, "symmetric plan: wave %u of window %u would run %u steps (< %u): %u meetings are too few for %u x %u waves (taper %u, %u)",

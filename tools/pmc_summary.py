@@ -33,7 +33,9 @@ for k, cs in sorted(agg.items()):
         d["hbm_write_bytes_per_launch"] = d["WRITE_SIZE"] * 1024
     if "hbm_read_bytes_per_launch" in d and "hbm_write_bytes_per_launch" in d:
         d["hbm_bytes_per_launch"] = d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
-    if "GRBM_GUI_ACTIVE" in d and "_dur_ns_grbm" in d:
+    # (GRBM_GUI_ACTIVE also counts the front end's work around a kernel: for a launch of a few microseconds "cycles / duration" is
+    #  not a clock -- round 3's summary showed 4.27 GHz for a 10 us kernel -- so no clock, and nothing derived from one, below 100 us)
+    if "GRBM_GUI_ACTIVE" in d and d.get("_dur_ns_grbm", 0) >= 100e3:
         d["effective_clock_ghz"] = d["GRBM_GUI_ACTIVE"] / 8 / d["_dur_ns_grbm"]
     if "SQ_ACTIVE_INST_VALU" in d and "_dur_ns_sq" in d and "effective_clock_ghz" in d:
         # SQ_ACTIVE_INST_* counts quad-cycles summed over all SIMDs (1024 on MI355X)

@@ -44,7 +44,7 @@ def main():
             pl = c.sym_plan()
             for k, v in res.items():
                 print(f"  {k:9s} ms/step {' '.join('%.4f' % x for x in v)}  best {min(v):.4f}", flush=True)
-            print(f"  weighted / default (best): {min(res['weighted']) / min(res['default']):.4f}   plan {pl.waves}x{pl.parts} ({pl.taper1},{pl.taper2}) sets {pl.sets}")
+            print(f"  weighted / default (best): {min(res['weighted']) / min(res['default']):.4f}   plan {pl.waves}x{pl.parts} ({pl.taper1},{pl.taper2}) sets {pl.sets} xcd_mode {pl.xcd_mode} bias {pl.wave_bias} class dies {pl.class_die if pl.xcd_mode == 2 else None}")
             w2 = c.calibrate_sym_xcds(4)
             print(f"  re-calibrated under the weighted plan: {w2}")
 

@@ -572,15 +572,13 @@ int mapn_calibrate_sym_xcds(mapn_ctx *c, int steps, uint32_t out[8])
     }
     std::vector<double> per[8];
     int slot_xcc[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-    // In an 8-wave workgroup the waves 0 .. 3 are the OLDER wave of their SIMDs: the SIMD serves them first, so their time per step
-    // is the die's own speed; the younger waves run in the gaps, and how long those are depends on how many steps the older wave
-    // has -- i.e. on the block's class, not on the die.  Only the older waves are read there.
-    const bool older_only = pl.waves == 8u;
+    // (Every wave's time per step is read, the older and the younger wave of a SIMD alike.  Reading the older waves only -- the SIMD
+    //  serves them first, so their time is the die's own -- was tried: same gain unsharded, and a LOSS sharded, 1.001 - 1.005 against
+    //  0.987 - 0.990 of the default step on one box: profiles/r04_xcd_class_aware_ab.txt.)
     for (const std::vector<unsigned long long> &tl : stamps)
         for (size_t wv = 0; wv < tl.size() / 6; wv++) {
             const unsigned long long *o = &tl[6 * wv];
             const uint32_t wg = (uint32_t)(wv / pl.waves), la = wg / pl.parts, part = wg % pl.parts;
-            if (older_only && wv % pl.waves >= pl.waves / 2u) continue;
             uint32_t x = pl.sets > 2u ? (la + nblk * pl.parts - part) % nblk : la;            // blockIdx.x of the workgroup: its number mod 8 is x mod 8
             if (pl.wgmap_entries) x = wg_x[(size_t)la * pl.parts + part];                     // (class-aware plan: from the workgroup map)
             const unsigned slot = x & 7u, xcc = (unsigned)((o[4] >> 32) & 15u);

@@ -128,7 +128,7 @@ int choose_epilogue(const mapn_ctx *c, const mapn::ForcePlan &p, bool allow_fuse
 {
     int want = c->plan_forced ? c->forced_epilogue : 1;
     if (c->p2p_ready && c->gather_algo == 3) return mapn::EPI_TICKET;   // flow mode publishes from the ticket epilogue
-    const char *e = getenv("MAPN_EPILOGUE");
+    const char *e = test_hook("MAPN_EPILOGUE");
     if (!c->plan_forced && e && strcmp(e, "rows") == 0) want = 0;
     if (want == 0) return mapn::EPI_ROWS;
     if (want == 1 && allow_fused && p.sb == 1 && p.nseg == 1) return mapn::EPI_FUSED;
@@ -175,7 +175,7 @@ mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_tota
 // MAPN_OWN_PLAN / MAPN_REM_PLAN = "k,waves,sb": tuning override of the two sharded launches
 bool env_plan(const char *name, mapn::ForcePlan &p)
 {
-    const char *e = getenv(name);
+    const char *e = test_hook(name);
     unsigned k = 0, w = 0, sb = 0;
     if (!e || sscanf(e, "%u,%u,%u", &k, &w, &sb) != 3) return false;
     mapn::ForcePlan q = p;
@@ -219,7 +219,7 @@ mapn::StepArgs base_args(const mapn_ctx *c, uint32_t w, uint32_t r)
     a.soft2 = c->cfg.softening_squared;
     a.dt = c->cfg.dt;
     a.damping = c->cfg.damping;
-    const char *nr = getenv("MAPN_NO_XCD_REMAP");          // A/B switch for the XCD-aware mapping
+    const char *nr = test_hook("MAPN_NO_XCD_REMAP");          // A/B switch for the XCD-aware mapping
     a.xcd_remap = (nr && nr[0] == '1') ? 0u : 1u;
     return a;
 }
@@ -901,7 +901,7 @@ int mapn_measure_clock(mapn_ctx *c, int steps, mapn_clock_info *out)
         : (size_t)((c->last_i_count + 64 * c->last_plan.k - 1) / (64 * c->last_plan.k)) * c->last_plan.sb * c->last_plan.waves;
     std::vector<unsigned long long> h(2 * waves);
     HIP_TRY(hipMemcpy(h.data(), c->stamp_buf, waves * 16, hipMemcpyDeviceToHost));
-    if (const char *dump = getenv("MAPN_STAMP_DUMP")) {
+    if (const char *dump = test_hook("MAPN_STAMP_DUMP")) {
         if (c->timeline_buf && c->timeline_last && c->last_plan.kind == mapn::KERNEL_SYM) {
             std::vector<unsigned long long> tl(6 * c->timeline_last);
             HIP_TRY(hipMemcpy(tl.data(), c->timeline_buf, c->timeline_last * 48, hipMemcpyDeviceToHost));

@@ -96,14 +96,14 @@ int prepare_sym(mapn_ctx *c, bool sharded)
     std::vector<Shape> tries;
     {
         unsigned ew = 0, ep = 0, tp = 0, t1 = 0, t2 = 0, eg = 0, bh = 1, bl = 1;
-        const char *pl = getenv(sharded ? "MAPN_SYM_SHARD_PLAN" : "MAPN_SYM_PLAN");     // "waves,parts" tuning override
+        const char *pl = test_hook(sharded ? "MAPN_SYM_SHARD_PLAN" : "MAPN_SYM_PLAN");     // "waves,parts" tuning override
         if (pl && sscanf(pl, "%u,%u", &ew, &ep) == 2 && (ew == 4 || ew == 8) && ep >= 1) { waves = ew; parts = ep; }
-        const char *wb = getenv(sharded ? "MAPN_SYM_SHARD_WAVE_BIAS" : "MAPN_SYM_WAVE_BIAS");   // "hi,lo": first half : second half of a workgroup's waves
+        const char *wb = test_hook(sharded ? "MAPN_SYM_SHARD_WAVE_BIAS" : "MAPN_SYM_WAVE_BIAS");   // "hi,lo": first half : second half of a workgroup's waves
         const bool bias_env = wb && sscanf(wb, "%u,%u", &bh, &bl) == 2 && bh >= 1 && bl >= 1;
         if (!bias_env) bh = bl = 1;
-        const char *tw = getenv("MAPN_SYM_WINDOW");                                    // groups per window (unsharded)
+        const char *tw = test_hook("MAPN_SYM_WINDOW");                                    // groups per window (unsharded)
         if (tw && !sharded && sscanf(tw, "%u", &eg) == 1 && eg >= 1) gpw = eg >= gsym ? 0u : eg;
-        const char *t = getenv(sharded ? "MAPN_SYM_SHARD_TAPER" : "MAPN_SYM_TAPER");     // "parts,taper1,taper2"; "0" = equal parts
+        const char *t = test_hook(sharded ? "MAPN_SYM_SHARD_TAPER" : "MAPN_SYM_TAPER");     // "parts,taper1,taper2"; "0" = equal parts
         if (c->sym_user_plan) {
             waves = c->sym_user[0]; parts = c->sym_user[1];
             tries.push_back({parts, c->sym_user[2] + c->sym_user[3] ? c->sym_user[2] : parts, c->sym_user[3], waves, c->sym_user[5], c->sym_user[6]});
@@ -209,7 +209,7 @@ bool sym_eligible(const mapn_ctx *c, uint32_t active)
 // its entry / loop start / loop end / exit times (100 MHz) and where it ran; mapn_measure_clock writes them to the file.
 int timeline_prepare(mapn_ctx *c, size_t nw, mapn::SymArgs &a)
 {
-    if (!c->stamp_next || !(c->calibrating || getenv("MAPN_STAMP_DUMP"))) return MAPN_OK;
+    if (!c->stamp_next || !(c->calibrating || test_hook("MAPN_STAMP_DUMP"))) return MAPN_OK;
     if (nw > c->timeline_waves) {
         if (c->timeline_buf) HIP_TRY(hipFree(c->timeline_buf));
         c->timeline_buf = nullptr; c->timeline_waves = 0;
@@ -251,11 +251,11 @@ mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t win
     a.mass = base.mass; a.soft2 = base.soft2; a.dt = base.dt; a.damping = base.damping;
     // rows leave the XCD as they are produced (write-through) instead of waiting in its L2 for the end-of-kernel write-back:
     // same box, rank 0 of 65 536 / 8: force launch 92.7 against 95.9 us; 65 536 unsharded 0.3 % faster (MAPN_SYM_ROW_WT=0: A/B)
-    static const uint32_t wt = [] { const char *e = getenv("MAPN_SYM_ROW_WT"); return e ? (uint32_t)atoi(e) : 1u; }();
+    static const uint32_t wt = [] { const char *e = test_hook("MAPN_SYM_ROW_WT"); return e ? (uint32_t)atoi(e) : 1u; }();
     a.row_wt = wt;
     // the I-block reaches the workgroup's waves through LDS (a quarter of the global loads at launch start): same box, rank 0 of
     // 65 536 / 8: prologue 2.9 against 5.0 us, force launch 89.9 against 92.4 us; 65 536 unsharded 0.45 % faster (MAPN_SYM_STAGE=0: A/B)
-    static const uint32_t stage = [] { const char *e = getenv("MAPN_SYM_STAGE"); return e ? (uint32_t)atoi(e) : 1u; }();
+    static const uint32_t stage = [] { const char *e = test_hook("MAPN_SYM_STAGE"); return e ? (uint32_t)atoi(e) : 1u; }();
     a.stage_iblock = stage;
     return a;
 }
@@ -315,7 +315,7 @@ int settle_push(mapn_ctx *c)
 // do the new positions travel inside the exchange launch (default) or in p2p_gather_kernel behind it (MAPN_SYM_SHARD_PULL=0: A/B)
 bool sym_shard_pull_folded()
 {
-    static const bool folded = [] { const char *e = getenv("MAPN_SYM_SHARD_PULL"); return !(e && e[0] == '0'); }();
+    static const bool folded = [] { const char *e = test_hook("MAPN_SYM_SHARD_PULL"); return !(e && e[0] == '0'); }();
     return folded;
 }
 
@@ -357,7 +357,7 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     }
     h.push = push ? 1u : 0u;
     h.send_row = rank;
-    static const uint32_t rel = [] { const char *e = getenv("MAPN_SYM_SHARD_RELEASE"); return e ? (uint32_t)atoi(e) : 0u; }();   // 1 = a release fence (L2 write-back) before each publication: +22 us per step measured, and the acknowledged write-through stores need none
+    static const uint32_t rel = [] { const char *e = test_hook("MAPN_SYM_SHARD_RELEASE"); return e ? (uint32_t)atoi(e) : 0u; }();   // 1 = a release fence (L2 write-back) before each publication: +22 us per step measured, and the acknowledged write-through stores need none
     h.release = rel;
     h.flags_mine = c->p2p_flags;
     h.recv_mine = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(c->p2p_flags) + mapn::SYM_RECV_OFFSET);
@@ -365,7 +365,7 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     // arrival flags per (sender, 256-body chunk) behind the receive region -- with PUSHED positions (same box, rank 0 of 65 536 / 8:
     // 93.2 against 93.5 us per step); where the launch also PULLS the peers' positions the workgroups' spread-out ends delay
     // the position counters and the ticket form stays (95.1 against 96.6).  MAPN_SYM_SHARD_CHUNK_FLAGS=0 / 2: never / always (A/B)
-    static const int chunk_mode = [] { const char *e = getenv("MAPN_SYM_SHARD_CHUNK_FLAGS"); return e ? atoi(e) : 1; }();
+    static const int chunk_mode = [] { const char *e = test_hook("MAPN_SYM_SHARD_CHUNK_FLAGS"); return e ? atoi(e) : 1; }();
     const bool chunked = chunk_mode == 2 || (chunk_mode == 1 && push);
     h.chunk_flags = chunked ? (uint32_t)mapn::sym_region_chunk_flags_word(world, c->count) : 0u;
     h.pos_sums = push && sym_push_check() ? (uint32_t)mapn::sym_region_pos_sums_word(world, c->count) : 0u;

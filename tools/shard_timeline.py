@@ -17,7 +17,7 @@ import numpy as np
 
 DUMP = "/tmp/mapn_timeline.bin"
 os.environ["MAPN_TEST_HOOKS"] = "1"; os.environ["MAPN_P2P_LOOPBACK"] = "1"
-os.environ["MAPN_STAMP_DUMP"] = DUMP
+os.environ["MAPN_STAMP_DUMP"] = DUMP        # (an experiment switch: honoured with MAPN_TEST_HOOKS=1, set above)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mapn  # noqa: E402
 

@@ -207,7 +207,7 @@ int mapn_consumer_signal(mapn_ctx *ctx, uint64_t value);
 int mapn_consumer_signal_event(mapn_ctx *ctx, uint64_t value, void *hip_event);
 /* bounds of the device-side waits in milliseconds (0 = leave unchanged): the peer-to-peer
  * exchange's wait for a peer's slice (default 2000: it also covers a peer whose HOST is late
- * enqueueing the step; bench.py sets 200) and the queued consumer-fence wait (default 10 000).  A wait that gives up is reported by the next mapn_simulate / mapn_wait_idle /
+ * enqueueing the step; bench.py sets 1000) and the queued consumer-fence wait (default 10 000).  A wait that gives up is reported by the next mapn_simulate / mapn_wait_idle /
  * mapn_download_* as MAPN_ERR_COMM (naming the peer) / MAPN_ERR_STATE. */
 int mapn_set_timeouts(mapn_ctx *ctx, uint32_t p2p_ms, uint32_t consumer_ms);
 

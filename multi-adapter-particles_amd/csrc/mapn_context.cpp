@@ -431,7 +431,14 @@ int alloc_state(mapn_ctx *c)
 {
     const uint64_t data = (uint64_t)c->n * sizeof(float4);
     c->aligned_data_size = (data + kHeapAlign - 1) / kHeapAlign * kHeapAlign;   // Compute.cpp:185-194
-    HIP_TRY(hipMalloc(&c->pos_heap, 2 * c->aligned_data_size));
+    // A SHARDED context's position heap is read and written by the peers' GPUs through hipIpc mappings (gather algorithms 2 - 5)
+    // with system-scope loads and stores: FINE-GRAINED memory is what the HIP memory model promises coherence for at that scope
+    // (coarse-grained memory is only guaranteed coherent between agents at kernel boundaries).  MAPN_TEST_HOOKS=1
+    // MAPN_SHARD_HEAP=coarse: the plain allocation of rounds 1 - 3, for the A/B.
+    const char *hk = test_hook("MAPN_SHARD_HEAP");
+    const bool fine = c->cfg.world_size > 1 && !(hk && hk[0] == 'c');
+    if (fine) HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void **>(&c->pos_heap), 2 * c->aligned_data_size, hipDeviceMallocFinegrained));
+    else HIP_TRY(hipMalloc(&c->pos_heap, 2 * c->aligned_data_size));
     HIP_TRY(hipMemset(c->pos_heap, 0, 2 * c->aligned_data_size));
     c->pos_own[0] = c->pos_heap;
     c->pos_own[1] = reinterpret_cast<float4 *>(reinterpret_cast<char *>(c->pos_heap) + c->aligned_data_size);

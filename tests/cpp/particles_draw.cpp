@@ -84,5 +84,21 @@ int main(int argc, char **argv)
     try { pStrict->GetSharedHandles(true); pStrict->Simulate((int)n, pStrict->GetFenceValue()); }
     catch (const mapn::MapnException &e) { threw = e.Error() == MAPN_ERR_STATE; }
     CHECK(threw);
+    // the plan bench.py's headline number is measured with, one config bit away (MAPN_FLAG_XCD_CALIBRATE): construction measures the
+    // dies and sizes the launch plan by them; the fence value after construction is still the reference's 4, and the steps run
+    {
+        mapn_config big;
+        mapn_config_default(&big);
+        big.mass = 70000.0f / 65536;
+        big.flags |= MAPN_FLAG_XCD_CALIBRATE;
+        std::unique_ptr<Compute> pBig(new Compute(65536, 0, false, nullptr, &big));
+        CHECK(pBig->GetFenceValue() == 4);
+        mapn_sym_plan_info info;
+        CHECK(mapn_get_sym_plan(pBig->Handle(), &info, nullptr, 0, nullptr, 0) == MAPN_OK);
+        CHECK(info.xcd_mode == 2u && info.wgmap_entries == 64u * info.parts);            // class-aware weights at 65 536 bodies
+        for (int frame = 0; frame < 3; frame++) pBig->Simulate(65536, pBig->GetFenceValue());
+        pBig->WaitForGpu();
+        CHECK(pBig->GetFenceValue() == 4 + 3 + 1);
+    }
     return g_fail;
 }

@@ -439,9 +439,10 @@ def main():
     # Untimed: calibrate, then an A/B of the weighted plan against the default one; the weights stay only if they win.
     xcd = {"mode": a.xcd, "weights": None, "used": False, "source": None}
     if dist is not None and world > 1 and "symmetric" in gather_algo and a.xcd != "off" and not a.plan:
-        # SHARDED symmetric step: every rank calibrates ITS GPU (mapn_calibrate_sym_xcds: four stamped real steps, collective -- all
-        # ranks call it, and it takes all of its steps before anything can fail) and sizes the parts of its own launch; then an
-        # untimed A/B, MAX over ranks, decides for all of them.  Loopback at 65 536 / 8: 94.4 -> 93.6 us per step.
+        # SHARDED symmetric step: every rank measures the dies of ITS GPU with a temporary UNSHARDED context of the same size (the
+        # library's creation-time calibration: no collective anywhere in it, and every die holds heavy and light blocks there, so the
+        # measurement is of the dies, not of the blocks' classes) and sizes the parts of its own sharded launch with those weights;
+        # then an untimed A/B, MAX over ranks, decides for all of them.  Loopback at 65 536 / 8: -1.2 ... -1.5 % per step.
         try:
             def burst_all(k):
                 sync(); t0 = time.perf_counter()
@@ -453,7 +454,9 @@ def main():
                 return float(t.item()) / k
             kk = max(20, min(400, int(0.05 / (0.1e-3 * (n / 65536.0) ** 2 * 8 / world))))
             try:
-                w, ok = c.calibrate_sym_xcds(4), 1
+                with mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed, flags=mapn.FLAG_XCD_CALIBRATE, kernel=kern) as tmp:
+                    w = list(tmp.sym_plan().xcd_weight)
+                ok = 1 if len(set(w)) > 1 else 0
             except mapn.MapnError as e:
                 w, ok = None, 0
                 xcd["error"] = str(e)[:200]
@@ -463,7 +466,7 @@ def main():
                 t_def = min(burst_all(kk), burst_all(kk))
                 c.set_sym_xcd_weights(w)
                 t_w = min(burst_all(kk), burst_all(kk))
-                xcd.update({"weights": w, "source": "mapn_calibrate_sym_xcds on every rank (rank 0's weights shown)", "form": {1: "spread", 2: "class-aware"}.get(c.sym_plan().xcd_mode),
+                xcd.update({"weights": w, "source": "an unsharded context's MAPN_FLAG_XCD_CALIBRATE on every rank's GPU (rank 0's weights shown)", "form": {1: "spread", 2: "class-aware"}.get(c.sym_plan().xcd_mode),
                             "trial_ms": {"default": t_def * 1e3, "weighted": t_w * 1e3}})
                 if a.xcd == "on" or t_w < t_def * 0.998:
                     xcd["used"] = c.sym_plan().xcd_mode != 0

@@ -37,6 +37,12 @@ def main():
             c.WaitForGpu()
             w = c.calibrate_sym_xcds(4)
             print(f"N={n}{' / 8 loopback' if shard else ''}: calibrated XCD weights {w}", flush=True)
+            if shard and "--from-unsharded" in sys.argv:
+                # the dies' speeds measured by an UNSHARDED context of the same size on this GPU (every die holds heavy and light blocks there:
+                # no class in the measurement), applied to the sharded launch
+                with mapn.Compute(n, mass=70000.0 / n, flags=mapn.FLAG_XCD_CALIBRATE) as t:
+                    w = list(t.sym_plan().xcd_weight)
+                print(f"  ... weights of an unsharded context's creation-time calibration instead: {w}", flush=True)
             res = {"default": [], "weighted": []}
             for rep in range(4):
                 c.set_sym_xcd_weights(None); res["default"].append(run(c, n, steps))

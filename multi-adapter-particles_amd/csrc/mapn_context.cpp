@@ -102,9 +102,10 @@ int check_async_errors(mapn_ctx *c)
                     "behind them (stale, torn or misplaced data: its counter overtook its stores, or it went on after a timed-out wait of its own); "
                     "this rank's position replica is not to be trusted from that step on", p2p - 0x200u);
     if (p2p >= 0x100u)
-        return fail(MAPN_ERR_COMM, "sharded symmetric step: a reaction row read after its sender's counter did not carry this exchange's number "
-                    "(sender %u places behind this rank on the ring): either that sender went on after a timed-out wait of its own "
-                    "(it reports the timeout) and overwrote the row, or its counter overtook its data", p2p - 0x100u);
+        return fail(MAPN_ERR_COMM, "sharded symmetric step: a reaction row of this exchange never arrived whole within %.0f ms, or (flag forms) a row read "
+                    "after its sender's flag did not carry this exchange's number (sender %u places behind this rank on the ring): that sender is "
+                    "late or gone, went on after a timed-out wait of its own (it reports the timeout) and overwrote the row, or its flag overtook its data",
+                    c->p2p_timeout_ticks / 1e5, p2p - 0x100u);
     if (p2p)
         return fail(MAPN_ERR_COMM, "peer-to-peer exchange: the wait for rank %u's slice timed out (%.0f ms); "
                     "this rank's position replica is stale from that step on", p2p - 1u, c->p2p_timeout_ticks / 1e5);

@@ -127,6 +127,13 @@ __host__ __device__ inline uint32_t sym_push_checksum(uint32_t x, uint32_t y, ui
     return x ^ ((y << 8) | (y >> 24)) ^ ((z << 16) | (z >> 16)) ^ ((w << 24) | (w >> 8)) ^ (body * 0x9E3779B1u);
 }
 __host__ __device__ inline uint32_t sym_push_epoch_mix(uint32_t epoch) { return epoch * 0x85EBCA6Bu + 0x1234567u; }
+// The tag a reaction row carries in .w when the receiver polls the rows themselves (SymShardArgs::poll_rows): a hash of the row's
+// three words and the exchange number, never 0 for the rows a peer-to-peer exchange sends (the receive region starts zeroed).
+__host__ __device__ inline uint32_t sym_row_tag(uint32_t x, uint32_t y, uint32_t z, uint32_t step)
+{
+    const uint32_t h = (x ^ ((y << 11) | (y >> 21)) ^ ((z << 22) | (z >> 10))) * 0x9E3779B1u + step * 0x85EBCA6Bu;
+    return h | 1u;
+}
 // layout of a rank's uncached exchange region (one allocation, one hipIpc handle), in 32-bit words from its start:
 //   [0, 1024)  counters;  SYM_RECV_OFFSET: receive rows float4[world][count];  then arrival flags [world][count / 256];
 //   then the checksums of pushed positions [2][world][count / 32] -- TWO sets, by the parity of the publication number, like the
@@ -160,6 +167,11 @@ struct SymShardArgs {
     uint32_t     *ticket;                     // workgroups of this launch whose sends are acknowledged (zero between launches)
     uint32_t      chunk_flags;                // != 0: arrival flags per (sender, 256-body chunk) at this word offset of the flag arrays instead of
                                               // the ticket + one flag per sender
+    uint32_t      poll_rows;                  // 1 (round 4): NO arrival flags at all -- every reaction row validates ITSELF: its .w is a hash of its
+                                              // x, y, z and the exchange number (sym_row_tag), the receiver re-reads a body's rows (bounded) until
+                                              // every one of them carries the tag its contents demand.  One trip through memory (row store -> row
+                                              // load) instead of three (row store -> acknowledgement -> flag store -> flag load -> row load); a torn
+                                              // or stale row cannot pass, whatever the order in which its bytes arrive
     uint32_t     *status;                     // host-visible word: non-zero = a wait timed out
     uint32_t      rank, world, count;         // count = bodies per rank (a multiple of SYM_BLOCK)
     uint32_t      nb, nbl, a0, half_d, parts, nwaves, max_meetings, sets;
@@ -168,6 +180,8 @@ struct SymShardArgs {
     uint32_t      pos_step;                   // number of this publication of new positions by a sharded symmetric step (0: they travel in another launch)
     uint32_t      pull_self;                  // loopback timing only: the "peers" are this rank, pull from every slot
     uint32_t      pos_sums;                   // push form: word offset of the checksum rows [publication parity][sender][count / 32] in the flag arrays (0: none)
+    uint32_t      corrupt_row;                // TEST HOOK (MAPN_TEST_HOOKS=1 MAPN_TEST_CORRUPT_ROW=<exchange>): one bit of ONE reaction row this launch sends
+                                              // is flipped after its tag was formed -- the receiver must never accept it (bounded wait, then reported)
     uint32_t      corrupt_push;               // TEST HOOK (MAPN_TEST_HOOKS=1 MAPN_TEST_CORRUPT_PUSH=<publication>): this launch flips one bit of
                                               // ONE pushed position after its checksum was formed -- the peers must report it
     uint64_t      timeout_ticks;

@@ -606,7 +606,9 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
                 fx += h[u].x; fy += h[u].y; fz += h[u].z;
             }
         }
-        store_sys(p.recv_peer[q] + (size_t)p.send_row * p.count + jl, fx, fy, fz, __builtin_bit_cast(float, p.step));
+        const uint32_t tag = p.poll_rows ? sym_row_tag(__builtin_bit_cast(uint32_t, fx), __builtin_bit_cast(uint32_t, fy), __builtin_bit_cast(uint32_t, fz), p.step) : p.step;
+        if (p.corrupt_row && t == (p.rank * p.count + 5u)) fx = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, fx) ^ 1u);   // TEST HOOK: after the tag
+        store_sys(p.recv_peer[q] + (size_t)p.send_row * p.count + jl, fx, fy, fz, __builtin_bit_cast(float, tag));
     }
     if (p.phase == 1u) return;                             // PACK: a collective library moves the rows, another launch reduces
 
@@ -635,12 +637,12 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     stamp(1);                                              // sends issued
     own_rows(bid * B + bl, ax, ay, az);
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(p.poll_rows && p.phase == 0u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (self-validating rows: nothing is published behind the sends, nobody waits for their acknowledgement here)
     if (p.release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // buffer_wbl2 sc0 sc1 + wait: the sends have LEFT this GPU's L2 (see the note at sync 2)
     __syncthreads();
-    stamp(2);                                              // sends acknowledged, own rows summed
-    if (p.phase == 2u) {
-        if (threadIdx.x == 0) ok = 1u;                     // REDUCE: the rows were delivered in stream order
+    stamp(2);                                              // sends acknowledged (flag forms) / issued (self-validating rows), own rows summed
+    if (p.phase == 2u || p.poll_rows) {
+        if (threadIdx.x == 0) ok = 1u;                     // REDUCE: the rows were delivered in stream order; POLL: every row says itself when it is there
     } else if (p.chunk_flags) {
         // ARRIVAL FLAGS PER CHUNK: this workgroup's sends are acknowledged -- it says so itself, per destination and 256-body
         // chunk (one word each in the destination's uncached region: [sender][chunk]), and a receiver waits only for the
@@ -674,13 +676,13 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     }
     __syncthreads();
     if (!ok) return;
-    if (!p.chunk_flags) stamp(3);                          // the peers' rows are here
+    if (!p.chunk_flags && !p.poll_rows) stamp(3);          // the peers' rows are here
 
     for (uint32_t base = bid * B; base < p.count; base += nblk * B) {
         const uint32_t il = base + bl;
         const bool live = il < p.count;
         if (base != bid * B) own_rows(il, ax, ay, az);
-        if (p.chunk_flags && p.phase == 0u && threadIdx.x < 64u) {
+        if (p.chunk_flags && !p.poll_rows && p.phase == 0u && threadIdx.x < 64u) {
             // the senders' flags of THIS chunk (one lane per sender; bounded)
             const uint32_t q = threadIdx.x, nchunks = p.count / 256u;
             const uint32_t all_good = wait_counters(p.flags_mine + p.chunk_flags, q * nchunks + base / 256u, q < p.world && ((p.recv_mask >> q) & 1u), p.step,
@@ -691,7 +693,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         part[g][0][bl] = ax; part[g][1][bl] = ay; part[g][2][bl] = az;
         __syncthreads();
         if (!ok) return;
-        if (p.chunk_flags && base == bid * B) stamp(3);    // the peers' rows of the first chunk are here
+        if (p.chunk_flags && !p.poll_rows && base == bid * B) stamp(3);    // the peers' rows of the first chunk are here
         if (g != 0u || !live) continue;
         ax = ay = az = 0.f;
 #pragma unroll
@@ -699,21 +701,38 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         // the rows received: uncached region, read past this GPU's caches with system-scope loads (global_load_dwordx2
         // sc0 sc1, issued by the compiler so that it places the waits), all in flight, added nearest sender first
         unsigned long long lo[P2P_MAX_RANKS], hi[P2P_MAX_RANKS];
-#pragma unroll
-        for (uint32_t k = 0; k < (uint32_t)P2P_MAX_RANKS; k++) {
-            const uint32_t q = p.rank >= k ? p.rank - k : p.rank + p.world - k;
-            const bool need = k < p.world && ((p.recv_mask >> q) & 1u);
-            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p.recv_mine + (size_t)(need ? q : p.rank) * p.count + il);
-            lo[k] = need ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
-            hi[k] = need ? __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ((unsigned long long)p.step << 32);
-        }
         uint32_t late = 0u;
+        const bool poll = p.poll_rows && p.phase == 0u;
+        const uint64_t poll_t0 = poll ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        for (;;) {
+#pragma unroll
+            for (uint32_t k = 0; k < (uint32_t)P2P_MAX_RANKS; k++) {
+                const uint32_t q = p.rank >= k ? p.rank - k : p.rank + p.world - k;
+                const bool need = k < p.world && ((p.recv_mask >> q) & 1u);
+                const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p.recv_mine + (size_t)(need ? q : p.rank) * p.count + il);
+                lo[k] = need ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+                hi[k] = need ? __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ((unsigned long long)p.step << 32);
+            }
+            late = 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < (uint32_t)P2P_MAX_RANKS; k++) {
+                const uint32_t q = p.rank >= k ? p.rank - k : p.rank + p.world - k;
+                const bool need = k < p.world && ((p.recv_mask >> q) & 1u);
+                // what the row's .w must be: the exchange number (flag forms: the flag said the row is there) -- or, self-validating
+                // rows, the hash of the very words just read
+                const uint32_t want = (p.poll_rows && need) ? sym_row_tag((uint32_t)lo[k], (uint32_t)(lo[k] >> 32), (uint32_t)hi[k], p.step) : p.step;
+                if ((uint32_t)(hi[k] >> 32) != want) late = 0x100u + k;        // not (yet) this exchange's row, or a torn one
+            }
+            if (!late || !poll) break;
+            // self-validating rows: not all there yet -- read them again (bounded: a sender that never sends is reported, with its place)
+            if (__builtin_amdgcn_s_memrealtime() - poll_t0 > p.timeout_ticks) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
 #pragma unroll
         for (uint32_t k = 0; k < (uint32_t)P2P_MAX_RANKS; k++) {
             ax += __builtin_bit_cast(float, (uint32_t)lo[k]);
             ay += __builtin_bit_cast(float, (uint32_t)(lo[k] >> 32));
             az += __builtin_bit_cast(float, (uint32_t)hi[k]);
-            if ((uint32_t)(hi[k] >> 32) != p.step) late = 0x100u + k;        // a row that is not this exchange's: flag before data?
         }
         if (late) __hip_atomic_store(p.status, late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         ax *= p.mass; ay *= p.mass; az *= p.mass;

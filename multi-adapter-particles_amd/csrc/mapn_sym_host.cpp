@@ -368,6 +368,9 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     static const int chunk_mode = [] { const char *e = test_hook("MAPN_SYM_SHARD_CHUNK_FLAGS"); return e ? atoi(e) : 1; }();
     const bool chunked = chunk_mode == 2 || (chunk_mode == 1 && push);
     h.chunk_flags = chunked ? (uint32_t)mapn::sym_region_chunk_flags_word(world, c->count) : 0u;
+    // round 4: no arrival flags at all -- the rows validate themselves (SymShardArgs::poll_rows); MAPN_SYM_SHARD_CHUNK_FLAGS = 0 / 1 / 2 (a
+    // hook): the flag forms of round 3, for the A/B
+    h.poll_rows = test_hook("MAPN_SYM_SHARD_CHUNK_FLAGS") ? 0u : 1u;
     h.pos_sums = push && sym_push_check() ? (uint32_t)mapn::sym_region_pos_sums_word(world, c->count) : 0u;
     h.status = c->async_status;
     h.rank = rank; h.world = world; h.count = c->count;
@@ -375,6 +378,7 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     h.send_mask = c->sym_send_mask; h.recv_mask = c->sym_recv_mask;
     h.step = ++c->sym_shard_step;
     h.pos_step = pull ? ++c->sym_pos_epoch : 0u;
+    { const char *cr = test_hook("MAPN_TEST_CORRUPT_ROW"); if (cr && (uint32_t)strtoul(cr, nullptr, 10) == h.step) h.corrupt_row = 1u; }
     if (push) { const char *cp = test_hook("MAPN_TEST_CORRUPT_PUSH"); if (cp && (uint32_t)strtoul(cp, nullptr, 10) == h.pos_step) h.corrupt_push = 1u; }
     c->step_pulled = pull;
     c->push_pending = push;

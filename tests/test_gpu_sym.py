@@ -380,6 +380,40 @@ def test_pushed_positions_are_checked_against_their_checksums_loopback(monkeypat
             c.Simulate(n, c.GetFenceValue())                   # the context stays failed: nothing is integrated on top of it
 
 
+def test_reaction_rows_validate_themselves_and_a_corrupted_one_is_never_accepted(monkeypatch):
+    """Round 4: the sharded symmetric step's exchange launch has no arrival flags any more.  Every reaction row carries in .w a hash
+    of its three words and the exchange number; the receiver re-reads a body's rows until each carries the tag its contents demand
+    -- one trip through memory instead of three, and a torn or stale row cannot pass whatever the order its bytes arrive in.  Rank 0
+    of an 8-way job, peers mapped to itself: clean steps run; with ONE bit of ONE row flipped after its tag was formed (exchange
+    5) the receiving thread waits out its bound and the failure is reported as MAPN_ERR_COMM -- never integrated as if it were data."""
+    monkeypatch.setenv("MAPN_TEST_HOOKS", "1")
+    monkeypatch.setenv("MAPN_P2P_LOOPBACK", "1")
+    n, world = 65536, 8
+    for algo in (5, 4):
+        with mapn.Compute(n, mass=70000.0 / n, rank=0, world_size=world) as c:
+            blob = c.p2p_export()
+            c.p2p_import([blob] * world)
+            c.set_gather_algorithm(algo)
+            draw(c, 30)
+            c.WaitForGpu()
+            assert c.p2p_status() == 0 and c.kernel_stats().kernel_name.decode() == "force_sym_kernel"
+    monkeypatch.setenv("MAPN_TEST_CORRUPT_ROW", "5")
+    monkeypatch.setenv("MAPN_P2P_LOOPBACK", "2")               # (2: only the rank's own rows are sent -- with 1 the rows for the seven "peers" land on
+    with mapn.Compute(n, mass=70000.0 / n, rank=0, world_size=world) as c:      #  the same addresses and the last, valid one would hide the bad one)
+        blob = c.p2p_export()
+        c.p2p_import([blob] * world)
+        c.set_gather_algorithm(5)
+        c.set_timeouts(p2p_ms=50)
+        draw(c, 4)
+        c.WaitForGpu()
+        assert c.p2p_status() == 0
+        c.Simulate(n, c.GetFenceValue())                       # exchange 5 sends the bad row
+        with pytest.raises(mapn.MapnError) as e:
+            c.WaitForGpu()
+        assert e.value.status == -4 and "never arrived whole" in str(e.value), str(e.value)
+        assert 0x100 <= c.p2p_status() < 0x200
+
+
 def test_rccl_form_of_the_sharded_symmetric_step_one_rank_loopback(oracle, monkeypatch):
     """Gather algorithm 6: pack launch -> one group of ncclSend / ncclRecv -> reduce launch -> ncclAllGather.  RCCL refuses two
     ranks on one device, so what runs here is rank 0 of a 2-rank job on a ONE-rank communicator (MAPN_COMM_LOOPBACK): the pack

@@ -453,6 +453,8 @@ typedef struct mapn_sym_plan_info {
                                     the four FASTEST dies, the others on the four slowest, every part sized by its die (2 table sets + wgmap) */
     uint32_t wgmap_offset, wgmap_entries;   /* class-aware: tables[wgmap_offset + y * blocks + x] = (block of the launch << 16) | part that
                                                workgroup (x, y) of the grid runs; wgmap_entries = blocks * parts (0: none) */
+    uint32_t la_flip;            /* no weights, a sharded launch of one block per die: 1 = workgroup (x, y) runs block x ^ 1, which puts the blocks with the
+                                    half-ring group on the odd dispatch slots -- the faster dies by 2 - 3 % on every box measured */
     uint32_t class_die[8];       /* class-aware: dispatch slots (workgroup number mod 8) of class 0's four dies, then class 1's, fastest first */
     uint32_t a0, nbl;
     uint32_t active_compute_units;  /* sharded: compute units that really take this process's workgroups (probed; a CU mask leaves fewer) */

@@ -77,7 +77,7 @@ class SymPlanInfo(C.Structure):
         ("parts", C.c_uint32), ("taper1", C.c_uint32), ("taper2", C.c_uint32), ("waves", C.c_uint32), ("wave_bias", C.c_uint32 * 2),
         ("brows", C.c_uint32), ("max_meetings", C.c_uint32), ("table_stride", C.c_uint32),
         ("sets", C.c_uint32), ("xcd_weight", C.c_uint32 * 8),
-        ("xcd_mode", C.c_uint32), ("wgmap_offset", C.c_uint32), ("wgmap_entries", C.c_uint32), ("class_die", C.c_uint32 * 8),
+        ("xcd_mode", C.c_uint32), ("wgmap_offset", C.c_uint32), ("wgmap_entries", C.c_uint32), ("la_flip", C.c_uint32), ("class_die", C.c_uint32 * 8),
         ("a0", C.c_uint32), ("nbl", C.c_uint32), ("active_compute_units", C.c_uint32), ("exchange_workgroups", C.c_uint32),
         ("scratch_bytes", C.c_uint64), ("error", C.c_char * 256),
     ]

@@ -361,7 +361,7 @@ class SymPlan:
         self.info, self.windows, self.tables = info, windows, tables
         self.wave_bias = (int(info.wave_bias[0]), int(info.wave_bias[1]))
         for k in ("nb", "groups", "parts", "taper1", "taper2", "waves", "brows", "max_meetings", "table_stride", "sets", "a0", "nbl", "active_compute_units", "exchange_workgroups", "scratch_bytes",
-                  "xcd_mode", "wgmap_offset", "wgmap_entries"):
+                  "xcd_mode", "wgmap_offset", "wgmap_entries", "la_flip"):
             setattr(self, k, int(getattr(info, k)))
         self.nwaves = self.parts * self.waves
         self.xcd_weight = list(info.xcd_weight)

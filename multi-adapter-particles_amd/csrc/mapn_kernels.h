@@ -79,6 +79,7 @@ struct SymArgs {
     uint32_t      nwaves;     // parts * waves per workgroup
     uint32_t      max_meetings;
     uint32_t      sets;       // table sets: 2, or 16 = XCD-weighted parts ("spread"): workgroup (x, y) runs part y of block (x + y) mod blocks, set = class + 2 * (block mod 8)
+    uint32_t      la_flip;    // 1: workgroup (x, y) runs block x ^ 1 (sharded launches without XCD weights: puts the blocks with the half-ring group on the odd dispatch slots)
     const uint32_t *wgmap;    // XCD-weighted parts, class-aware form: workgroup (x, y) runs (block << 16 | part) = wgmap[y * gridDim.x + x] (null: the mappings above)
     uint32_t      g0, g1;     // meeting groups of this launch: 0 the block itself, 1 .. D partner a + g, D + 1 the half-ring partner
     uint32_t      brows;      // rows allocated per J-block (symmetric groups of the widest window)

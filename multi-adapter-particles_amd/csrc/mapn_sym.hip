@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     // (XCD-weighted parts, sets == 16: the parts of a block are spread over the dies -- workgroup (x, y) lands on XCD x mod 8 and
     //  runs part y of block (x + y) mod blocks, so part s of block la runs on die (la - s) mod 8, which its share of the steps was sized for)
     // (class-aware XCD weights: which (block, part) this workgroup runs is a host-built table -- the heavy blocks' parts on the fast dies)
-    uint32_t s = blockIdx.y, la = p.sets > 2u ? (blockIdx.x + blockIdx.y) % gridDim.x : blockIdx.x;
+    uint32_t s = blockIdx.y, la = p.sets > 2u ? (blockIdx.x + blockIdx.y) % gridDim.x : (blockIdx.x ^ p.la_flip);
     if (p.wgmap) { const uint32_t m = p.wgmap[blockIdx.y * gridDim.x + blockIdx.x]; la = m >> 16; s = m & 0xffffu; }
     const uint32_t a = p.a0 + la;                          // a: the I-block in the whole job; la: among this launch's
     const uint32_t nb = p.nb, half = p.half_d;             // half_d = NB/2 when NB is even, else 0

@@ -245,6 +245,7 @@ mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t win
     a.arow = c->sym_arow; a.brow = c->sym_brow; a.brow1 = c->sym_brow1;
     a.tab = c->sym_tab + window * pl.table_stride;
     a.wgmap = pl.wgmap_entries ? c->sym_tab + pl.wgmap_offset : nullptr;
+    a.la_flip = pl.la_flip;
     a.n = c->n; a.n_integrate = c->n; a.nb = pl.nb; a.parts = pl.parts; a.nwaves = pl.nwaves; a.max_meetings = pl.max_meetings; a.sets = pl.sets;
     a.g0 = pl.windows[window].g0; a.g1 = pl.windows[window].g1;
     a.brows = pl.brows; a.half_d = pl.half;
@@ -583,7 +584,7 @@ int mapn_calibrate_sym_xcds(mapn_ctx *c, int steps, uint32_t out[8])
         for (size_t wv = 0; wv < tl.size() / 6; wv++) {
             const unsigned long long *o = &tl[6 * wv];
             const uint32_t wg = (uint32_t)(wv / pl.waves), la = wg / pl.parts, part = wg % pl.parts;
-            uint32_t x = pl.sets > 2u ? (la + nblk * pl.parts - part) % nblk : la;            // blockIdx.x of the workgroup: its number mod 8 is x mod 8
+            uint32_t x = pl.sets > 2u ? (la + nblk * pl.parts - part) % nblk : (la ^ pl.la_flip);   // blockIdx.x of the workgroup: its number mod 8 is x mod 8
             if (pl.wgmap_entries) x = wg_x[(size_t)la * pl.parts + part];                     // (class-aware plan: from the workgroup map)
             const unsigned slot = x & 7u, xcc = (unsigned)((o[4] >> 32) & 15u);
             if (o[5] < 64 || o[2] <= o[1]) continue;
@@ -617,7 +618,7 @@ int mapn_get_sym_plan(mapn_ctx *c, mapn_sym_plan_info *info, uint32_t *windows, 
     info->wave_bias[0] = p.bias_hi; info->wave_bias[1] = p.bias_lo;
     info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
     info->sets = p.sets; for (int k = 0; k < 8; k++) info->xcd_weight[k] = p.xcd_weight[k];
-    info->xcd_mode = p.xcd_mode; info->wgmap_offset = p.wgmap_offset; info->wgmap_entries = p.wgmap_entries;
+    info->xcd_mode = p.xcd_mode; info->wgmap_offset = p.wgmap_offset; info->wgmap_entries = p.wgmap_entries; info->la_flip = p.la_flip;
     for (int k = 0; k < 8; k++) info->class_die[k] = p.class_die[k / 4][k % 4];
     info->a0 = c->sym_sharded ? (uint32_t)c->cfg.rank * (c->count / mapn::SYM_BLOCK) : 0u;
     info->nbl = c->sym_sharded ? c->count / mapn::SYM_BLOCK : 0u;

@@ -175,6 +175,18 @@ bool build_sym_plan(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uin
             }
         }
     }
+    // No weights, and a launch whose blocks each sit on ONE die (a rank's share of a sharded job: 8 blocks, block x on dispatch slot x
+    // mod 8): the blocks with the half-ring group alternate with the others, i.e. they sit either all on the even or all on the odd
+    // slots -- and on every box measured (eight of them, unsharded calibrations of round 4: profiles/r04_xcd_class_aware_ab.txt) the
+    // odd slots are the faster dies by 2 - 3 %.  Ranks whose heavy blocks sat on the even slots ran 6 % behind in their heavy
+    // blocks (3 % more steps x 3 % slower) and were the slower ranks of the job (rank 0 against rank 4: 92.7 against 91.3 us).
+    // The heavy blocks go to the odd slots on every rank; calibrated weights (class-aware mode) supersede this.
+    if (!weighted && p.half && launch_blocks && launch_blocks < nb && B % 8u == 0u) {
+        uint32_t heavy_even = 0, heavy_odd = 0;
+        for (uint32_t la = 0; la < B; la++)
+            if (sym_runs_half(launch_a0 + la, p.half)) ((la & 1u) ? heavy_odd : heavy_even)++;
+        if (heavy_even && !heavy_odd) p.la_flip = 1u;
+    }
     if (class_aware) {
         // which (block, part) workgroup (x, y) of the grid runs: it lands on die x mod 8 -- the k-th die of class c -- and takes,
         // in the order u = x / 8 + (B / 8) y, part 4 (u / (B / 2)) + k of the class's block number u mod (B / 2)
@@ -212,7 +224,7 @@ extern "C" int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, u
     info->parts = p.parts; info->taper1 = p.taper1; info->taper2 = p.taper2; info->waves = p.waves; info->wave_bias[0] = p.bias_hi; info->wave_bias[1] = p.bias_lo;
     info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
     info->sets = p.sets; for (int k = 0; k < 8; k++) info->xcd_weight[k] = p.xcd_weight[k];
-    info->xcd_mode = p.xcd_mode; info->wgmap_offset = p.wgmap_offset; info->wgmap_entries = p.wgmap_entries;
+    info->xcd_mode = p.xcd_mode; info->wgmap_offset = p.wgmap_offset; info->wgmap_entries = p.wgmap_entries; info->la_flip = p.la_flip;
     for (int k = 0; k < 8; k++) info->class_die[k] = p.class_die[k / 4][k % 4];
     info->a0 = 0; info->nbl = 0; info->active_compute_units = 0; info->exchange_workgroups = 0; info->scratch_bytes = 0;
     if (windows && windows_capacity < 4u * p.windows.size()) {

@@ -80,6 +80,8 @@ struct SymPlanHost {
     uint32_t xcd_weight[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // relative speed of the dies the parts were weighted with (xcd_mode != 0)
     uint32_t xcd_mode = 0;                   // 0: no weights, 1: spread (16 sets), 2: class-aware (2 sets + wgmap)
     uint32_t class_die[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // class-aware: the dispatch slots (dies) class 0 / class 1 blocks run on, fastest first
+    uint32_t la_flip = 0;                    // no XCD weights, a launch of ONE block per die (a rank's share): 1 = workgroup (x, y) runs block x ^ 1, which puts
+                                             // the launch's class-0 blocks on the odd dispatch slots (see build_sym_plan)
     uint32_t wgmap_offset = 0, wgmap_entries = 0;        // class-aware: tables[wgmap_offset + y * blocks + x] = (block of the launch << 16) | part for workgroup (x, y)
     uint32_t table_stride = 0;               // uint32 per window: bounds[sets][nwaves + 1], split[sets][max_meetings]
     std::vector<SymWindow> windows;

@@ -211,6 +211,24 @@ def test_class_aware_xcd_weights_put_the_heavy_blocks_on_the_fast_dies(nb, parts
     assert t_class < t_default and t_class <= t_spread * 1.001, (t_class, t_spread, t_default)
 
 
+def test_default_sharded_plan_puts_the_heavy_blocks_on_the_odd_dispatch_slots():
+    """Round 4: a rank's launch holds one block per die (block x on dispatch slot x mod 8) and its blocks with the half-ring group
+    alternate with the others -- all on the even slots for the ranks of the ring's first half, all on the odd ones for the second.
+    The odd slots are the faster dies (2 - 3 % on every box measured), so the first-half ranks ran 6 % behind in their heavy blocks
+    and were the slower ranks.  Without XCD weights the plan now flips block x <-> x ^ 1 where that puts the heavy blocks on the odd
+    slots; unsharded launches (every die holds both classes) and weighted plans (the workgroup map decides) are left alone."""
+    import mapn
+    from mapn import shard
+    for rank in range(8):
+        pl = mapn.describe_sym_plan(64, 0, 32, None, 0, 8, wave_bias=(3, 1), launch_blocks=8, launch_a0=8 * rank)
+        heavy_slots = {(la ^ pl.la_flip) % 8 for la in range(8) if shard.sym_block_class(64, 8 * rank + la) == 0}
+        assert heavy_slots == {1, 3, 5, 7}, (rank, pl.la_flip, heavy_slots)
+        assert pl.la_flip == (1 if rank < 4 else 0)
+    assert mapn.describe_sym_plan(64, 0, 4, None, 0, 8, wave_bias=(10, 3)).la_flip == 0                        # unsharded
+    assert mapn.describe_sym_plan(27, 0, 32, None, 0, 4, launch_blocks=9).la_flip == 0                         # odd block count: no half-ring group, no classes
+    assert mapn.describe_sym_plan(64, 0, 32, None, 0, 8, wave_bias=(2, 1), xcd_weights=XCD_W, launch_blocks=8).la_flip == 0   # weights: the workgroup map decides
+
+
 def test_wave_bias_gives_the_older_waves_of_a_workgroup_the_larger_share():
     """An 8-wave workgroup's waves 0 .. 3 are the older wave of their SIMDs and are issued first (measured); with a wave bias
     hi : lo they carry hi / lo times the steps of waves 4 .. 7, so that the two waves of a SIMD finish together.  Still one

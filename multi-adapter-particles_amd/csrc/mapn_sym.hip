@@ -532,16 +532,19 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 //  (1) SEND: for every rank q this rank produced reactions for and every body of q: the rows of this rank's
 //      I-blocks that met the body's block (a meeting's row, then its head row if it was cut between two workgroups),
 //      added in ascending block order, stored as ONE float4 into rank q's receive region (row [this rank]) with a
-//      system-scope write-through store -- over xGMI when q is another GPU; the unused .w carries the exchange number,
+//      system-scope write-through store -- over xGMI when q is another GPU; the unused .w carries the row's tag (see (3)),
 //      which the receiver checks.  Once acknowledged (vmcnt(0)) the stores are in q's memory: no cache write-back is
 //      owed (a release fence here would write back the whole L2, full of this step's rows: measured 10+ us per step).
 //  (2) OWN ROWS, before anything is waited for: G threads per body (a rank's slice is small -- 8192 bodies at
 //      65 536 / 8 -- so one thread per body would leave the rows' loads latency-bound): thread (body, g) adds the
 //      a-rows of parts [g P/G, (g+1) P/G) in ascending order.
-//  (3) ARRIVAL: every workgroup stores a flag per (destination, 256-body chunk) it sent, in the destination's uncached region;
-//      lanes 0 .. world-1 of a workgroup's first wave wait (bounded) for the senders' flags of the chunk it integrates next.
-//      (chunk_flags == 0, the earlier form: the last workgroup through a ticket stores ONE flag per destination, and every
-//      workgroup waits for the flags of all the ranks that owe this rank rows.)
+//  (3) ARRIVAL.  poll_rows (round 4, the default): there is no arrival step -- every row validates ITSELF: its .w is
+//      sym_row_tag(x, y, z, exchange number), the sender stores it and goes on (no acknowledgement wait, no flag), and in (4) the
+//      receiving thread re-reads its body's rows (bounded) until every one carries the tag its contents demand.  One trip through
+//      memory instead of three; a torn or stale row cannot pass.  The flag forms of round 3, kept for the A/B: chunk_flags != 0 --
+//      every workgroup, its sends acknowledged (vmcnt(0)), stores a flag per (destination, 256-body chunk) it sent and lanes
+//      0 .. world-1 of a workgroup's first wave wait (bounded) for the senders' flags of the chunk it integrates next;
+//      chunk_flags == 0 -- the last workgroup through a ticket stores ONE flag per destination.
 //  (4) INTEGRATE: thread (body, 0) adds the G sums in ascending g, then the rows received, nearest sender first
 //      (this rank, rank - 1, rank - 2, ...), then mass, kick, damp, drift (hlsl:103-108) -- a fixed order throughout,
 //      so the replicas stay bit-identical.  The new position is stored write-through.

@@ -536,10 +536,11 @@ def main():
                       "max_ms": round(float(step_ms.max()), 5)}
     except mapn.MapnError:
         pass
-    # with >= 100 steps, four more repeats of the same K steps (untimed by the contract: `value` stays the first region's)
-    # and the median of the five -- how far one region is from the typical one on this box
+    # SURVEY 8(d) asks for >= 100 steps and a median of five repeats: four more regions of the same K steps follow the timed one (untimed by
+    # the contract: `value` stays the first region's) and the five are listed with their median -- how far one region is from the typical one
+    # on this box.  Done for every K (the driver's own command has K = 20; `meets_survey_8d` says whether K reaches the 100 steps)
     repeats = None
-    if a.steps >= 100:
+    if a.steps >= 1:
         reps = [elapsed / a.steps * 1e3]
         for _ in range(4):
             sync()
@@ -553,7 +554,7 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt_rep = float(t.item())
             reps.append(dt_rep / a.steps * 1e3)
-        repeats = {"ms_per_step": [round(x, 5) for x in reps], "median_ms_per_step": round(sorted(reps)[2], 5),
+        repeats = {"ms_per_step": [round(x, 5) for x in reps], "median_ms_per_step": round(sorted(reps)[2], 5), "meets_survey_8d": a.steps >= 100,
                    "note": "the timed region (first entry: `ms_per_step`, `value`) and four more regions of the same K steps right behind it"}
     first, count = c.shard_range()
     # the clock the chip held under this kernel: stamped diagnostic steps right behind the timed region

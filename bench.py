@@ -192,8 +192,12 @@ def main():
     # XCD-aware parts (1 GPU, symmetric kernel): the LIBRARY calibrates the dies when the context is created (MAPN_FLAG_XCD_CALIBRATE:
     # the plan any C-ABI caller gets with that one config bit); below, an untimed A/B decides whether the weights stay
     xcd_by_library = dist is None and a.mode == "all_pairs" and a.xcd != "off" and kern in (mapn.KERNEL_AUTO, mapn.KERNEL_SYMMETRIC) and not a.plan and not a.graph
+    # (N > 1: the same flag makes every rank's library measure ITS GPU with a temporary unsharded context when the sharded symmetric step
+    #  is prepared -- no collective in it -- and plan the rank's launch with those weights; the A/B below decides here too)
+    if a.mode == "all_pairs" and a.xcd != "off" and kern in (mapn.KERNEL_AUTO, mapn.KERNEL_SYMMETRIC) and not a.plan and not a.graph:
+        flags |= mapn.FLAG_XCD_CALIBRATE
     c = mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed,
-                     rank=rank, world_size=world, flags=flags | (mapn.FLAG_XCD_CALIBRATE if xcd_by_library else 0), kernel=kern)
+                     rank=rank, world_size=world, flags=flags, kernel=kern)
     info = device_info(local_rank)
     transport = "none"
     gather_fn = None
@@ -439,10 +443,11 @@ def main():
     # Untimed: calibrate, then an A/B of the weighted plan against the default one; the weights stay only if they win.
     xcd = {"mode": a.xcd, "weights": None, "used": False, "source": None}
     if dist is not None and world > 1 and "symmetric" in gather_algo and a.xcd != "off" and not a.plan:
-        # SHARDED symmetric step: every rank measures the dies of ITS GPU with a temporary UNSHARDED context of the same size (the
-        # library's creation-time calibration: no collective anywhere in it, and every die holds heavy and light blocks there, so the
-        # measurement is of the dies, not of the blocks' classes) and sizes the parts of its own sharded launch with those weights;
-        # then an untimed A/B, MAX over ranks, decides for all of them.  Loopback at 65 536 / 8: -1.2 ... -1.5 % per step.
+        # SHARDED symmetric step: the library has planned every rank's launch with the die weights of ITS GPU (MAPN_FLAG_XCD_CALIBRATE:
+        # a temporary unsharded context's calibration when the step was prepared -- no collective in it, and every die holds heavy and
+        # light blocks there, so the measurement is of the dies, not of the blocks' classes); an untimed A/B against the unweighted plan,
+        # MAX over ranks, decides for all of them.  Loopback at 65 536 / 8: -1.2 ... -1.5 % per step before the heavy blocks were moved to
+        # the odd dispatch slots by default, less since.
         try:
             def burst_all(k):
                 sync(); t0 = time.perf_counter()
@@ -453,25 +458,22 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 return float(t.item()) / k
             kk = max(20, min(400, int(0.05 / (0.1e-3 * (n / 65536.0) ** 2 * 8 / world))))
-            try:
-                with mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed, flags=mapn.FLAG_XCD_CALIBRATE, kernel=kern) as tmp:
-                    w = list(tmp.sym_plan().xcd_weight)
-                ok = 1 if len(set(w)) > 1 else 0
-            except mapn.MapnError as e:
-                w, ok = None, 0
-                xcd["error"] = str(e)[:200]
-            flag = torch.tensor([ok], device=red_dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # all ranks or none (each has taken the same number of steps either way)
+            pl = c.sym_plan()
+            w = list(pl.xcd_weight)
+            flag = torch.tensor([1 if pl.xcd_mode != 0 else 0], device=red_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # all ranks or none
             if flag.item():
-                t_def = min(burst_all(kk), burst_all(kk))
-                c.set_sym_xcd_weights(w)
                 t_w = min(burst_all(kk), burst_all(kk))
-                xcd.update({"weights": w, "source": "an unsharded context's MAPN_FLAG_XCD_CALIBRATE on every rank's GPU (rank 0's weights shown)", "form": {1: "spread", 2: "class-aware"}.get(c.sym_plan().xcd_mode),
-                            "trial_ms": {"default": t_def * 1e3, "weighted": t_w * 1e3}})
+                c.set_sym_xcd_weights(None)
+                t_def = min(burst_all(kk), burst_all(kk))
+                xcd.update({"weights": w, "source": "library (MAPN_FLAG_XCD_CALIBRATE: a temporary unsharded context on every rank's GPU; rank 0's weights shown)",
+                            "form": {1: "spread", 2: "class-aware"}.get(pl.xcd_mode), "trial_ms": {"default": t_def * 1e3, "weighted": t_w * 1e3}})
                 if a.xcd == "on" or t_w < t_def * 0.998:
+                    c.set_sym_xcd_weights(w)
                     xcd["used"] = c.sym_plan().xcd_mode != 0
-                else:
-                    c.set_sym_xcd_weights(None)
+            else:
+                xcd["note"] = "the library's calibration did not apply on every rank (a rank's share must be a multiple of 8 blocks)"
+                c.set_sym_xcd_weights(None)
         except mapn.MapnError as e:                            # (a failure here leaves the default plan: the run goes on)
             xcd["error"] = str(e)[:200]
             try:

@@ -85,6 +85,7 @@ struct mapn_ctx {
     uint32_t sym_user[7] = {0, 0, 0, 0, 0, 0, 0};   // waves, parts, taper1, taper2, groups per window, wave bias (first half : second half)
     bool sym_xcd_weighted = false;            // mapn_set_sym_xcd_weights: parts spread over the dies, sized by their speed
     uint32_t sym_xcd_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool shard_calibrated = false;            // MAPN_FLAG_XCD_CALIBRATE on a sharded context: the temporary unsharded calibration has been tried
     bool calibrating = false;                 // mapn_calibrate_sym_xcds: stamped launches record the per-wave timeline without MAPN_STAMP_DUMP
     std::string sym_note;                     // why AUTO runs the one-sided kernel instead (allocation failed, ...)
     float4 *sym_arow = nullptr, *sym_brow = nullptr, *sym_brow1 = nullptr, *sym_acc = nullptr;
@@ -224,6 +225,7 @@ int alloc_state(mapn_ctx *c);
 int create_common(const mapn_config *cfg, mapn_ctx **out);
 int observe_steps(mapn_ctx *c);
 int calibrate_at_creation(mapn_ctx *c);   // mapn_sym_host.cpp (MAPN_FLAG_XCD_CALIBRATE)
+int calibrate_for_shard(mapn_ctx *c);     // mapn_sym_host.cpp (the same flag on a sharded context: weights from a temporary unsharded one)
 
 }  // namespace host
 }  // namespace mapn

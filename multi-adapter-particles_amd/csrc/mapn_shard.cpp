@@ -146,7 +146,12 @@ int mapn_set_gather_algorithm(mapn_ctx *c, int algorithm)
     }
     // algorithm 4: plan and scratch of the sharded symmetric step are made HERE (never inside mapn_simulate); if they
     // cannot be had under MAPN_KERNEL_AUTO the step runs as algorithm 2 (one-sided kernel + peer-to-peer pull)
-    if (algorithm >= 4 && algorithm <= 6) { if (!(c->sym_ready && c->sym_sharded)) { if (int rc = prepare_sym(c, true)) return rc; } }
+    if (algorithm >= 4 && algorithm <= 6) {
+        if (!(c->sym_ready && c->sym_sharded)) {
+            if (int rc = calibrate_for_shard(c)) return rc;            // (MAPN_FLAG_XCD_CALIBRATE only: die weights from a temporary unsharded context)
+            if (int rc = prepare_sym(c, true)) return rc;
+        }
+    }
     if (algorithm == 6 && c->sym_ready && !c->sym_send) {
         // send / receive rows of the RCCL form, and who exchanges with whom (mapn_p2p_import computes the same masks for 4 / 5)
         HIP_TRY(hipSetDevice(c->device));

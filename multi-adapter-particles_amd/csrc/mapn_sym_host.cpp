@@ -437,13 +437,36 @@ int enqueue_sym_shard_rccl(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *t
     return MAPN_OK;
 }
 
+// MAPN_FLAG_XCD_CALIBRATE on a SHARDED context: the dies of this rank's GPU are measured by a temporary UNSHARDED context of the same
+// size (its creation-time calibration: no collective anywhere in it, and every die holds blocks of both classes there, so what is
+// measured is the dies -- a sharded launch holds ONE block per die), and the weights are kept for when the sharded symmetric step is
+// prepared (mapn_set_gather_algorithm 4 / 5 / 6).  Never fatal; done once per context.
+int calibrate_for_shard(mapn_ctx *c)
+{
+    if (!(c->cfg.flags & MAPN_FLAG_XCD_CALIBRATE) || c->sym_xcd_weighted || c->shard_calibrated) return MAPN_OK;
+    c->shard_calibrated = true;
+    if (!sym_applies(c, true) || (c->count / mapn::SYM_BLOCK) % 8u != 0u) return MAPN_OK;
+    mapn_config t = c->cfg;
+    t.rank = 0; t.world_size = 1; t.flags = MAPN_FLAG_XCD_CALIBRATE;
+    mapn_ctx *tmp = nullptr;
+    const std::string keep = g_last_error;
+    if (mapn_create(&t, &tmp) == MAPN_OK && tmp->sym_ready && tmp->sym_plan.xcd_mode != 0u) {
+        for (int k = 0; k < 8; k++) c->sym_xcd_w[k] = tmp->sym_plan.xcd_weight[k];
+        c->sym_xcd_weighted = true;
+    }
+    if (tmp) (void)mapn_destroy(tmp);
+    (void)hipSetDevice(c->device);
+    g_last_error = keep;
+    return MAPN_OK;
+}
+
 // MAPN_FLAG_XCD_CALIBRATE: measure the dies under the context's OWN state and give the plan their weights; the state, the fence
 // value and the buffer index come back exactly as they were (nothing has been exported yet at creation, so nobody can have seen
 // the steps in between).  Never fatal: where it does not apply the default plan stays and the note is left in mapn_last_error().
 int calibrate_at_creation(mapn_ctx *c)
 {
-    if (!(c->cfg.flags & MAPN_FLAG_XCD_CALIBRATE)) return MAPN_OK;
-    if (!sym_eligible(c, c->n) || c->sym_plan.nb % 8u != 0u || c->cfg.world_size != 1) {
+    if (!(c->cfg.flags & MAPN_FLAG_XCD_CALIBRATE) || c->cfg.world_size != 1) return MAPN_OK;   // (a sharded context: calibrate_for_shard, when its symmetric step is prepared)
+    if (!sym_eligible(c, c->n) || c->sym_plan.nb % 8u != 0u) {
         g_last_error = "MAPN_FLAG_XCD_CALIBRATE: XCD weights do not apply to this context (they need the unsharded symmetric kernel and a block count that is a multiple of 8); the default plan runs";
         return MAPN_OK;
     }

@@ -284,6 +284,32 @@ def test_xcd_calibration_at_creation_gives_the_weighted_plan_and_leaves_the_stat
         draw(c, 1)
 
 
+def test_xcd_calibration_flag_on_a_sharded_context_plans_the_ranks_launch_with_its_gpus_die_weights(monkeypatch):
+    """MAPN_FLAG_XCD_CALIBRATE on a SHARDED context: when the sharded symmetric step is prepared (mapn_set_gather_algorithm 4 / 5 / 6) the
+    library measures this rank's GPU with a temporary UNSHARDED context of the same size -- no collective in it -- and plans the
+    rank's launch class-aware with those weights: what bench.py relies on for N > 1 (and then A/Bs).  Rank 0 of an 8-way job in
+    loopback; without the flag the default plan (heavy blocks on the odd dispatch slots) runs."""
+    monkeypatch.setenv("MAPN_TEST_HOOKS", "1")
+    monkeypatch.setenv("MAPN_P2P_LOOPBACK", "1")
+    n, world = 65536, 8
+    for flags, want_mode in ((mapn.FLAG_XCD_CALIBRATE, 2), (0, 0)):
+        with mapn.Compute(n, mass=70000.0 / n, rank=0, world_size=world, flags=flags) as c:
+            blob = c.p2p_export()
+            c.p2p_import([blob] * world)
+            c.set_gather_algorithm(5)
+            pl = c.sym_plan()
+            assert pl.xcd_mode == want_mode and pl.nbl == 8 and pl.waves == 8 and pl.parts == 32, (pl.xcd_mode, pl.waves, pl.parts)
+            if want_mode:
+                assert max(pl.xcd_weight) == 1024 and min(pl.xcd_weight) > 850 and pl.wgmap.shape == (32, 8, 2) and pl.la_flip == 0
+            else:
+                assert pl.la_flip == 1 and pl.wgmap is None
+            draw(c, 20)
+            c.WaitForGpu()
+            assert c.p2p_status() == 0 and c.kernel_stats().kernel_name.decode() == "force_sym_kernel"
+            c.set_gather_algorithm(2); c.set_gather_algorithm(4)     # the weights survive the scratch being given back and made again
+            assert c.sym_plan().xcd_mode == want_mode
+
+
 def _loopback_expectation(pos, vel, nb, nbl, mass, soft2, dt):
     """What rank 0 of a sharded job computes when no peer ever answers (float64): its blocks meet what the schedule says; its
     bodies get the forces of those meetings plus the reactions of meetings between two of its own blocks."""

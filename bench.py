@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--overlap", action="store_true", help="sharded mode: own-segment launch overlapped with the all-gather")
     ap.add_argument("--trial-seconds", type=float, default=90.0,
                     help="wall-time budget of the exchange trial (N > 1, --gather auto): once it is spent the candidates not yet tried are skipped")
+    ap.add_argument("--test-inject-push-failure", action="store_true",
+                    help="testing only: rank 1 corrupts ONE pushed position in the timed region (MAPN_TEST_HOOKS): the run must notice and fall back")
     ap.add_argument("--force-comm", action="store_true",
                     help="create the torch.distributed group and the in-library RCCL communicator even for one rank (exercises the sharded code path on a 1-GPU box)")
     return ap.parse_args()
@@ -237,6 +239,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def rebuild(with_p2p):
+        """A context whose device-side wait timed out or whose row / position check failed stays failed: replace it (collective: all ranks)."""
+        nonlocal c
+        c.close()
+        c = mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed, rank=rank, world_size=world, flags=flags,
+                         kernel=kern)               # (the SAME kernel choice and plan as asked for: ADVICE r2)
+        if a.gather not in ("p2p", "flow", "sym", "sympush", "p2pall"):
+            c.comm_init_torch()
+        if with_p2p:
+            c.p2p_setup_torch()
+            c.set_timeouts(p2p_ms=a.p2p_timeout_ms)
+        apply_plan()
+        c.set_timers(timer_interval)
+
     gather_algo = "n/a"
     trial = {}
 
@@ -328,20 +344,6 @@ def main():
             # time every way (same bytes) on untimed steps; every rank must take the same decision -> MAX
             # over ranks.  The peer-to-peer kernel must also PROVE itself here: no timed-out wait (the
             # library now reports one as MAPN_ERR_COMM) and bit-identical replicas on all ranks.
-            def rebuild(with_p2p):
-                """A context whose device-side wait timed out stays failed: replace it."""
-                nonlocal c
-                c.close()
-                c = mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed, rank=rank, world_size=world, flags=flags,
-                                 kernel=kern)               # (the SAME kernel choice and plan as asked for: ADVICE r2)
-                if a.gather not in ("p2p", "flow", "sym", "sympush", "p2pall"):
-                    c.comm_init_torch()
-                if with_p2p:
-                    c.p2p_setup_torch()
-                    c.set_timeouts(p2p_ms=a.p2p_timeout_ms)
-                apply_plan()
-                c.set_timers(timer_interval)
-
             p2p_dead = False
             t_trial0 = time.perf_counter()
             for name, algo, overlap in candidates:
@@ -509,16 +511,62 @@ def main():
                 c.set_sym_xcd_weights(None)
             except mapn.MapnError:
                 pass
-    for _ in range(a.warmup):
-        step()
-    sync()
-    c.set_timers(timer_interval)          # restart the sampling phase: the first timed step carries events
-    c.kernel_stats(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
+    def run_steps(k, recoverable):
+        """k steps, then the barrier + device sync.  With a peer-to-peer form on N > 1 ranks a device-side check or wait that fails on ANY rank
+        (they are all bounded: every rank gets out of its own) comes back as text on EVERY rank -- the closing collective carries the verdict --
+        instead of leaving the others in a barrier for ever."""
+        fail = None
+        try:
+            for _ in range(k):
+                step()
+            c.WaitForGpu()
+        except mapn.MapnError as e:
+            if not recoverable:
+                raise
+            fail = str(e)
+        if torch is not None:
+            torch.cuda.synchronize()
+        if dist is not None:
+            if recoverable:
+                bad = torch.tensor([1 if fail else 0], device=red_dev)
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)      # (this collective IS the barrier)
+                if bad.item() and not fail:
+                    fail = "a device-side check or wait failed on another rank"
+            else:
+                dist.barrier()
+            torch.cuda.synchronize()
+        return fail
+
+    fallback_after_failure = None
+    while True:
+        recoverable = dist is not None and world > 1 and transport.startswith("p2p")
+        fail = run_steps(a.warmup, recoverable)
+        if not fail:
+            if a.test_inject_push_failure and rank == 1 and fallback_after_failure is None:
+                os.environ["MAPN_TEST_HOOKS"] = "1"; os.environ["MAPN_TEST_CORRUPT_PUSH"] = "once"
+            c.set_timers(timer_interval)          # restart the sampling phase: the first timed step carries events
+            c.kernel_stats(reset=True)
+            t0 = time.perf_counter()
+            fail = run_steps(a.steps, recoverable)
+            elapsed = time.perf_counter() - t0
+        if not fail:
+            break
+        # A peer-to-peer form that had passed its trial failed in the run itself (a pushed position that did not match its checksum, a
+        # reaction row that never arrived whole, a wait that gave up).  ONCE, the fastest OTHER form the trial verified takes over: new
+        # contexts on all ranks (a failed one stays failed), the seeded initial state, warm-up and the K timed steps again.
+        others = sorted((k for k in trial if k != gather_algo), key=trial.get)
+        if fallback_after_failure is not None or not others:
+            sys.exit(f"bench: exchange '{gather_algo}' failed during the run ({fail}) and no verified form is left to fall back to")
+        fallback_after_failure = f"'{gather_algo}' failed during the run: {fail[:300]}"
+        if rank == 0:
+            print(f"[bench] {fallback_after_failure} -> falling back to '{others[0]}'", file=sys.stderr, flush=True)
+        gather_algo = others[0]
+        chosen = {x[0]: x for x in candidates}[gather_algo]
+        rebuild(with_p2p=2 <= chosen[1] <= 5)
+        c.set_gather_algorithm(chosen[1])
+        c.set_shard_overlap(chosen[2])
+        transport = "p2p (hipIpc + device flags)" if 2 <= chosen[1] <= 5 else "rccl"
+        xcd["used"] = False
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -616,7 +664,7 @@ def main():
                        "step_ms_by_quarter_of_the_timed_region": quarters, "step_ms_spread": spread if quarters else None,
                        "repeats": repeats,
                        "step_ms_note": "device time (HIP events on the compute stream) of the steps of the timed region that carried events; ms_per_step is the wall clock over all of them",
-                       "p2p_failure": p2p_failure, "sharded_symmetric_deviation_after_run": sym_dev_after,
+                       "p2p_failure": p2p_failure, "fallback_after_failure": fallback_after_failure, "sharded_symmetric_deviation_after_run": sym_dev_after,
                        "xcd_aware_parts": xcd, "symmetric_plan": sym_plan_desc},
         }
         if a.mode == "all_pairs":

@@ -92,6 +92,7 @@ struct SymArgs {
     uint32_t     *wait_status;       // host-visible word: 1 + peer whose slice never arrived
     uint64_t      wait_timeout_ticks;
     uint32_t      wait_need, wait_world, wait_rank, wait_self;   // wait_self: loopback timing only -- the "peers" are this rank
+    uint32_t     *wait_dead;         // this rank's SYM_DEAD_WORD
     // ... and CHECKS what they pushed (verify_sums != null: the pushes of publication `verify_epoch` have not been checked yet): the
     // pusher stored one checksum word per 32 bodies (sym_push_checksum) behind its data; every wave of this launch re-computes the
     // checksums of a few groups from what it reads past the caches and reports a mismatch (status 0x200 + sender) instead of
@@ -114,6 +115,11 @@ hipError_t launch_sym_reduce(const SymArgs &a, hipStream_t st);
 // ranks that owe it rows, integrates its own bodies from its a-rows plus the rows received, publishes its
 // new slice and pulls the peers' slices (sym_shard_exchange_kernel: one launch).
 enum { P2P_MAX_RANKS = 16 };          // ranks of a direct peer-to-peer job (one process per GPU, buffers mapped through hipIpc)
+// word SYM_DEAD_WORD of a rank's own flag array: set (never cleared: the context stays failed) when a bounded device-side wait of this rank
+// gave up or a row / position check failed.  Every LATER bounded wait of the rank reads it once it actually has to wait and gives up at
+// once: the launches still queued behind a failure drain in microseconds instead of one time-out each (bench.py's fall-back after a
+// failure in the timed run waited 30 launches x 3 s before this).
+enum { SYM_DEAD_WORD = 48 };
 enum { SYM_FLAG_BASE = 16,            // reaction-arrival counters follow the P2P_MAX_RANKS publication counters of the one-sided exchange
        SYM_POS_BASE = 32,             // position counters of the sharded symmetric step (algorithms 4 / 5)
        SYM_RECV_OFFSET = 4096 };      // byte offset of the receive region [world][count] float4 inside the flags allocation
@@ -195,7 +201,7 @@ int probe_active_compute_units(hipStream_t st);                             // c
 // stream operation: wait (bounded) until every peer's publication counter has reached `need` (positions pushed by the peers)
 // ... and, when verify_sums is given, check the pushed slices of `replica` against the pushers' checksums (as the force launch does)
 hipError_t launch_p2p_wait(const uint32_t *counters, uint32_t need, uint32_t world, uint32_t rank, uint32_t self, uint64_t timeout_ticks,
-                           uint32_t *status, const float4 *replica, const uint32_t *verify_sums, uint32_t verify_epoch, uint32_t count, hipStream_t st);
+                           uint32_t *status, uint32_t *dead, const float4 *replica, const uint32_t *verify_sums, uint32_t verify_epoch, uint32_t count, hipStream_t st);
 
 bool force_plan_supported(const ForcePlan &plan);
 hipError_t launch_force(const ForcePlan &plan, const StepArgs &a, hipStream_t st);

@@ -187,10 +187,13 @@ __device__ __forceinline__ void flow_wait_block(const StepArgs &p, uint32_t seg,
         for (uint32_t q = q0; q <= q1 && q < p.flow_world; q++) {
             if (q == p.flow_rank) continue;
             const uint64_t ts = __builtin_amdgcn_s_memrealtime();
+            uint32_t *dead = p.flow_peer_flags[p.flow_rank] + SYM_DEAD_WORD;   // (this rank's: set once a wait has given up -- nothing waits again)
             while ((int32_t)(__hip_atomic_load(p.flow_arrived + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.flow_need) < 0) {
+                if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
                 __builtin_amdgcn_s_sleep(32);
                 if (__builtin_amdgcn_s_memrealtime() - ts > p.flow_timeout_ticks) {
                     __hip_atomic_store(p.flow_status, 1u + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
             }
@@ -593,10 +596,16 @@ __global__ __launch_bounds__(1024) void p2p_gather_kernel(const P2PArgs p)
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
         uint32_t good = 1u;
         while ((int32_t)(__hip_atomic_load(p.my_flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - p.step) < 0) {
+            // (SYM_DEAD_WORD: an earlier wait of this rank has given up -- the launches queued behind it do not wait a time-out each)
+            if (__hip_atomic_load(p.my_flags + SYM_DEAD_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { good = 0u; break; }
             __builtin_amdgcn_s_sleep(8);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) { good = 0u; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
+                good = 0u;
+                __hip_atomic_store(p.status, 1u + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(p.my_flags + SYM_DEAD_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
         }
-        if (!good) __hip_atomic_store(p.status, 1u + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");       // system scope: buffer_inv sc0 sc1
         ok = good;
     }
@@ -632,10 +641,16 @@ __global__ __launch_bounds__(512) void flow_pull_kernel(const P2PArgs p, uint32_
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
         uint32_t good = 1u;
         while ((int32_t)(__hip_atomic_load(p.my_flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - p.step) < 0) {
+            // (SYM_DEAD_WORD: an earlier wait of this rank has given up -- the launches queued behind it do not wait a time-out each)
+            if (__hip_atomic_load(p.my_flags + SYM_DEAD_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { good = 0u; break; }
             __builtin_amdgcn_s_sleep(8);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) { good = 0u; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
+                good = 0u;
+                __hip_atomic_store(p.status, 1u + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(p.my_flags + SYM_DEAD_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
         }
-        if (!good) __hip_atomic_store(p.status, 1u + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         ok = good;
     }

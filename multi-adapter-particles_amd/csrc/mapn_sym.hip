@@ -77,18 +77,22 @@ __device__ __forceinline__ void store_sys(float4 *dst, float x, float y, float z
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(o) : "memory");
 }
 
-// lanes 0 .. 63 of the calling wave each wait (bounded) for one counter to reach `need`; returns 1 when all did
+// lanes 0 .. 63 of the calling wave each wait (bounded) for one counter to reach `need`; returns 1 when all did.  `dead`: this rank's
+// SYM_DEAD_WORD -- once a wait of the rank has given up (or a check has failed) no later one waits again: read only when the counter is
+// not there yet, so it costs nothing in a healthy step
 __device__ __forceinline__ uint32_t wait_counters(const uint32_t *counters, uint32_t index, bool need_it, uint32_t need,
-                                                  uint64_t timeout_ticks, uint32_t *status, uint32_t code)
+                                                  uint64_t timeout_ticks, uint32_t *status, uint32_t code, uint32_t *dead)
 {
     uint32_t good = 1u;
     if (need_it) {
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
         while ((int32_t)(__hip_atomic_load(counters + index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - need) < 0) {
+            if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { good = 0u; break; }
             __builtin_amdgcn_s_sleep(4);
             if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
                 good = 0u;
                 __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
         }
@@ -121,7 +125,7 @@ __device__ __forceinline__ uint32_t xor_reduce32(uint32_t h)
 // their counters) and compare them with the words the pushers stored behind the data.  Called by whole waves: half-wave h of wave
 // `wv` (of `nw`) takes the 32-body groups 2 wv + h, 2 wv + h + 2 nw, ... of the (world - 1) x count / 32 pushed groups.
 __device__ __forceinline__ void verify_pushed(const float4 *replica, const uint32_t *sums, uint32_t epoch, uint32_t count, uint32_t world, uint32_t rank,
-                                              uint32_t self, uint32_t wv, uint32_t nw, uint32_t lane, uint32_t *status)
+                                              uint32_t self, uint32_t wv, uint32_t nw, uint32_t lane, uint32_t *status, uint32_t *dead)
 {
     const uint32_t per = count / 32u, ng = (world - 1u) * per;            // (count is a multiple of 1024: ng is even)
     for (uint32_t base = 2u * wv; base < ng; base += 2u * nw) {
@@ -133,8 +137,10 @@ __device__ __forceinline__ void verify_pushed(const float4 *replica, const uint3
         uint32_t h = sym_push_checksum(__builtin_bit_cast(uint32_t, v.x), __builtin_bit_cast(uint32_t, v.y), __builtin_bit_cast(uint32_t, v.z),
                                        __builtin_bit_cast(uint32_t, v.w), body);
         h = xor_reduce32(h);
-        if ((h ^ sym_push_epoch_mix(epoch)) != want)
+        if ((h ^ sym_push_epoch_mix(epoch)) != want) {
             __hip_atomic_store(status, 0x200u + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -252,14 +258,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
             // (the I-block is this rank's own slice; everything else waits for the peers' pushes -- the counters have
             //  normally been there since before this launch started)
             const bool need = lane < p.wait_world && lane != p.wait_rank;
-            (void)wait_counters(p.wait_counters, p.wait_self ? p.wait_rank : lane, need, p.wait_need, p.wait_timeout_ticks, p.wait_status, 1u + lane);
+            (void)wait_counters(p.wait_counters, p.wait_self ? p.wait_rank : lane, need, p.wait_need, p.wait_timeout_ticks, p.wait_status, 1u + lane, p.wait_dead);
         }
         if (t0 < t1) { meeting(t0 >> 6, jb, d, g); pn = body_j(jb * 64u + ((lane + t0) & 63u)); }
         // what the peers pushed is CHECKED here, once per launch, spread over the launch's waves (a few loads per wave, in flight
         // together with the first J-block: the wave waits for that one anyway)
         if (p.verify_sums)
             verify_pushed(pos, p.verify_sums, p.verify_epoch, p.verify_count, p.wait_world, p.wait_rank, p.wait_self,
-                          (la * p.parts + s) * WAVES + w, gridDim.x * gridDim.y * WAVES, lane, p.wait_status);
+                          (la * p.parts + s) * WAVES + w, gridDim.x * gridDim.y * WAVES, lane, p.wait_status, p.wait_dead);
     };
     SymBodies b;
     if (p.stage_iblock) {
@@ -674,7 +680,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         }
         const uint32_t q = threadIdx.x;
         const uint32_t all_good = wait_counters(p.flags_mine + SYM_FLAG_BASE, q, q < p.world && ((p.recv_mask >> q) & 1u), p.step,
-                                                p.timeout_ticks, p.status, 1u + q);
+                                                p.timeout_ticks, p.status, 1u + q, p.flags_mine + SYM_DEAD_WORD);
         if (threadIdx.x == 0) ok = all_good;
     }
     __syncthreads();
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
             // the senders' flags of THIS chunk (one lane per sender; bounded)
             const uint32_t q = threadIdx.x, nchunks = p.count / 256u;
             const uint32_t all_good = wait_counters(p.flags_mine + p.chunk_flags, q * nchunks + base / 256u, q < p.world && ((p.recv_mask >> q) & 1u), p.step,
-                                                    p.timeout_ticks, p.status, 1u + q);
+                                                    p.timeout_ticks, p.status, 1u + q, p.flags_mine + SYM_DEAD_WORD);
             if (threadIdx.x == 0) ok = all_good;
         }
         __syncthreads();                                   // (the previous pass has read `part`)
@@ -727,7 +733,9 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
                 if ((uint32_t)(hi[k] >> 32) != want) late = 0x100u + k;        // not (yet) this exchange's row, or a torn one
             }
             if (!late || !poll) break;
-            // self-validating rows: not all there yet -- read them again (bounded: a sender that never sends is reported, with its place)
+            // self-validating rows: not all there yet -- read them again (bounded: a sender that never sends is reported, with its place;
+            // not at all once an earlier wait or check of this rank has failed)
+            if (__hip_atomic_load(p.flags_mine + SYM_DEAD_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
             if (__builtin_amdgcn_s_memrealtime() - poll_t0 > p.timeout_ticks) break;
             __builtin_amdgcn_s_sleep(2);
         }
@@ -737,7 +745,10 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
             ay += __builtin_bit_cast(float, (uint32_t)(lo[k] >> 32));
             az += __builtin_bit_cast(float, (uint32_t)hi[k]);
         }
-        if (late) __hip_atomic_store(p.status, late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (late) {
+            __hip_atomic_store(p.status, late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (p.phase == 0u) __hip_atomic_store(p.flags_mine + SYM_DEAD_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         ax *= p.mass; ay *= p.mass; az *= p.mass;
         const uint32_t i = p.rank * p.count + il;
         const float4 pos = p.pos_old[i];
@@ -793,7 +804,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         if (p.push) { stamp(6); return; }                  // the peers' NEXT force launch waits for the counter; nothing to pull
         const uint32_t q = threadIdx.x;
         const uint32_t all_good = wait_counters(p.flags_mine + SYM_POS_BASE, p.pull_self ? p.rank : q, q < p.world && q != p.rank, p.pos_step * SYM_COUNT_PER_LAUNCH,
-                                                p.timeout_ticks, p.status, 1u + q);
+                                                p.timeout_ticks, p.status, 1u + q, p.flags_mine + SYM_DEAD_WORD);
         if (threadIdx.x == 0) ok = all_good;
     }
     if (p.push) return;
@@ -828,21 +839,21 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
 // read the replica): one wave waits (bounded) until every peer has pushed its slice
 // ... and (verify_sums != null) checks their slices against the pushers' checksums like the force launch does; grid = waves that share the check
 __global__ __launch_bounds__(64) void p2p_wait_kernel(const uint32_t *counters, uint32_t need, uint32_t world, uint32_t rank, uint32_t self,
-                                                      uint64_t timeout_ticks, uint32_t *status, const float4 *replica, const uint32_t *verify_sums,
+                                                      uint64_t timeout_ticks, uint32_t *status, uint32_t *dead, const float4 *replica, const uint32_t *verify_sums,
                                                       uint32_t verify_epoch, uint32_t count)
 {
     const uint32_t q = threadIdx.x;
-    const uint32_t good = wait_counters(counters, self ? rank : q, q < world && q != rank, need, timeout_ticks, status, 1u + q);
-    if (verify_sums && good) verify_pushed(replica, verify_sums, verify_epoch, count, world, rank, self, blockIdx.x, gridDim.x, threadIdx.x, status);
+    const uint32_t good = wait_counters(counters, self ? rank : q, q < world && q != rank, need, timeout_ticks, status, 1u + q, dead);
+    if (verify_sums && good) verify_pushed(replica, verify_sums, verify_epoch, count, world, rank, self, blockIdx.x, gridDim.x, threadIdx.x, status, dead);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
 hipError_t launch_p2p_wait(const uint32_t *counters, uint32_t need, uint32_t world, uint32_t rank, uint32_t self, uint64_t timeout_ticks,
-                           uint32_t *status, const float4 *replica, const uint32_t *verify_sums, uint32_t verify_epoch, uint32_t count, hipStream_t st)
+                           uint32_t *status, uint32_t *dead, const float4 *replica, const uint32_t *verify_sums, uint32_t verify_epoch, uint32_t count, hipStream_t st)
 {
     const uint32_t groups = verify_sums ? (world - 1u) * (count / 32u) : 0u;
     const uint32_t grid = std::max(1u, std::min(64u, groups / 2u));
-    hipLaunchKernelGGL(p2p_wait_kernel, dim3(grid), dim3(64), 0, st, counters, need, world, rank, self, timeout_ticks, status, replica, verify_sums, verify_epoch, count);
+    hipLaunchKernelGGL(p2p_wait_kernel, dim3(grid), dim3(64), 0, st, counters, need, world, rank, self, timeout_ticks, status, dead, replica, verify_sums, verify_epoch, count);
     return hipGetLastError();
 }
 

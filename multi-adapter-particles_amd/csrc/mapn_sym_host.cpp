@@ -308,7 +308,7 @@ int settle_push(mapn_ctx *c)
     c->push_pending = false;
     // (the latest step wrote buffer 1 - index: that is where the peers pushed; their checksums are verified as the force launch would)
     HIP_TRY(mapn::launch_p2p_wait(c->p2p_flags + mapn::SYM_POS_BASE, c->sym_pos_epoch * mapn::SYM_COUNT_PER_LAUNCH, (uint32_t)c->cfg.world_size, (uint32_t)c->cfg.rank, c->p2p_loopback ? 1u : 0u,
-                                  c->p2p_timeout_ticks, c->async_status, c->pos[1 - c->buffer_index],
+                                  c->p2p_timeout_ticks, c->async_status, c->p2p_flags + mapn::SYM_DEAD_WORD, c->pos[1 - c->buffer_index],
                                   sym_push_check() ? c->p2p_flags + mapn::sym_region_pos_sums_word((uint32_t)c->cfg.world_size, c->count) : nullptr, c->sym_pos_epoch, c->count, c->compute));
     return MAPN_OK;
 }
@@ -337,6 +337,7 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
         // the replica this launch reads was completed by the peers' pushes of the previous step: wait for their counters in the launch
         a.wait_counters = c->p2p_flags + mapn::SYM_POS_BASE; a.wait_status = c->async_status; a.wait_timeout_ticks = c->p2p_timeout_ticks;
         a.wait_need = c->sym_pos_epoch * mapn::SYM_COUNT_PER_LAUNCH; a.wait_world = world; a.wait_rank = rank; a.wait_self = c->p2p_loopback ? 1u : 0u;
+        a.wait_dead = c->p2p_flags + mapn::SYM_DEAD_WORD;
         if (c->push_pending && sym_push_check()) {         // pushes nobody has checked yet (not after an upload: that data is not the peers')
             a.verify_sums = c->p2p_flags + mapn::sym_region_pos_sums_word(world, c->count); a.verify_epoch = c->sym_pos_epoch; a.verify_count = c->count;
         }
@@ -380,7 +381,12 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     h.step = ++c->sym_shard_step;
     h.pos_step = pull ? ++c->sym_pos_epoch : 0u;
     { const char *cr = test_hook("MAPN_TEST_CORRUPT_ROW"); if (cr && (uint32_t)strtoul(cr, nullptr, 10) == h.step) h.corrupt_row = 1u; }
-    if (push) { const char *cp = test_hook("MAPN_TEST_CORRUPT_PUSH"); if (cp && (uint32_t)strtoul(cp, nullptr, 10) == h.pos_step) h.corrupt_push = 1u; }
+    if (push) {                                            // TEST HOOK: "<publication number>", or "once" = the next publication of this process, one time
+        static bool corrupted_once = false;
+        const char *cp = test_hook("MAPN_TEST_CORRUPT_PUSH");
+        if (cp && strcmp(cp, "once") == 0) { if (!corrupted_once) { corrupted_once = true; h.corrupt_push = 1u; } }
+        else if (cp && (uint32_t)strtoul(cp, nullptr, 10) == h.pos_step) h.corrupt_push = 1u;
+    }
     c->step_pulled = pull;
     c->push_pending = push;
     h.pull_self = c->p2p_loopback ? 1u : 0u;

@@ -199,6 +199,25 @@ def test_bench_two_ranks_one_gpu_with_the_sharded_symmetric_step():
 
 
 @pytest.mark.gpu
+def test_bench_falls_back_once_when_a_verified_form_fails_in_the_run_itself():
+    """The 8-GPU run is the first real execution of the cross-GPU forms: a form can pass its trial and still fail later.  Here rank 1
+    corrupts ONE pushed position in the timed region (test hook); rank 0's library reports it (MAPN_ERR_COMM), bench.py -- whose
+    closing collective carries the verdict to every rank instead of leaving them in a barrier -- rebuilds the contexts, falls back
+    to the next verified form, times the K steps again and says so in its line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "3", "--gather", "sympush",
+                        "--dist-backend", "gloo", "--same-device", "--prewarm-ms", "20", "--bodies", "16384", "--test-inject-push-failure",
+                        "--p2p-timeout-ms", "3000"], capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert "p2p+symmetric+push" in cfg["fallback_after_failure"] and "PUSHED" in cfg["fallback_after_failure"], cfg["fallback_after_failure"]
+    assert cfg["exchange"] == "p2p" and d["n_gpus"] == 2 and d["steps"] == 30          # (the other verified form of this trial)
+    assert cfg["replicas_bit_identical_after_run"] is True and cfg["valid"] is True
+
+
+@pytest.mark.gpu
 @pytest.mark.slow
 def test_bench_eight_ranks_one_gpu_trial_over_every_peer_to_peer_form():
     """The exchange TRIAL of bench.py as the driver's 8-GPU run goes through it, with eight ranks sharing device 0 (gloo

@@ -492,8 +492,9 @@ int calibrate_at_creation(mapn_ctx *c)
     if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
         float ms = 0.f;
         (void)hipEventRecord(e0, c->compute);
+        const int per_burst = c->n <= 131072u ? 8 : c->n <= 524288u ? 2 : 1;     // (a step is 0.6 ms at 65 536 bodies, 2.5 s at 4 Mi: never more than one step past the 200 ms)
         for (int burst = 0; burst < 400 && ms < 200.f && !rc; burst++) {
-            for (int k = 0; k < 8 && !rc; k++) rc = mapn_simulate(c, (int)c->n, 0);
+            for (int k = 0; k < per_burst && !rc; k++) rc = mapn_simulate(c, (int)c->n, 0);
             (void)hipEventRecord(e1, c->compute);
             if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) break;
         }

@@ -171,7 +171,13 @@ def main():
     dist = None
     torch = None
     under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    saved_stdout_fd = None
     if world > 1 or (a.force_comm and under_launcher):
+        # stdout carries ONE JSON line (rank 0's) and nothing else: what the collective libraries print on it while they set up (RCCL's
+        # version banner, for one) goes to stderr -- file descriptor 1 points there until the line is printed
+        sys.stdout.flush()
+        saved_stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch            # first: its HIP runtime is then the one libmapn binds to
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -720,6 +726,9 @@ def main():
                                "unit": "GB/s", "frac": HBM_BYTES_PER_BODY * n * a.steps / elapsed / 8e12, "traffic": None}
         if world == 1 and not a.no_cpu_baseline and a.mode == "all_pairs":
             out["cpu_baseline"] = cpu_baseline(n, a.seed, a.cpu_seconds)
+        if saved_stdout_fd is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout_fd, 1)
         print(json.dumps(out), flush=True)
     c.close()
     if dist is not None:

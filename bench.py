@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for barriers / rendezvous (gloo for single-GPU tests)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses device 0 (needs --dist-backend gloo --gather p2p)")
+    ap.add_argument("--no-power-leg", action="store_true", help="skip the untimed 2.5 s of steps behind the run during which the package power sensor is read (single GPU)")
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed clock-ramp phase before the W warm-up steps (the chip needs a few hundred ms of "
                          "load to settle its clock; 0 disables)")
@@ -156,6 +157,77 @@ def pmc_traffic(kernel_name, n, world):
 
 
 pmc_traffic.valu_busy = None    # VALU busy fraction of the same (sha-matched) PMC summary, if it holds one
+
+
+def power_sensor(device_index):
+    """The hwmon directory of the GPU torch calls `device_index` (amdgpu: power1_input / power1_average in microwatts, power1_cap,
+    freq1_input = shader clock in Hz), or None.  Matched by PCI address (hipDeviceGetPCIBusId against the sysfs device directory: the
+    driver's 1-GPU boxes show the sensors of all of the host's GPUs); a box with ONE sensor is taken as that GPU."""
+    import glob
+    cands = []
+    for hw in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+        if any(os.access(os.path.join(hw, f), os.R_OK) for f in ("power1_input", "power1_average")):
+            cands.append(hw)
+    if not cands:
+        return None
+    try:
+        import ctypes
+        hip = None
+        for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):     # (already in the process: libmapn is linked against it)
+            try:
+                hip = ctypes.CDLL(name)
+                break
+            except OSError:
+                continue
+        buf = ctypes.create_string_buffer(64)
+        if hip is not None and hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) == 0:
+            want = buf.value.decode().lower()               # "0000:5a:00.0"
+            for hw in cands:
+                if os.path.basename(os.path.realpath(os.path.join(hw, "..", ".."))).lower() == want:
+                    return hw
+    except (OSError, AttributeError, ValueError):
+        pass
+    return cands[0] if len(cands) == 1 else None
+
+
+def read_sensor(hw, names):
+    for f in names:
+        try:
+            return float(open(os.path.join(hw, f)).read().strip())
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def power_leg(step_batch, hw, seconds=2.5, batch_ms=100.0, ms_per_step=1.0):
+    """What the package draws under the timed kernel: ~`seconds` more of the same steps (untimed, behind everything that is), the
+    sensor read between batches of ~`batch_ms`.  The figures are those of the second half (the sensor's own averaging has settled)."""
+    per = max(1, int(batch_ms / max(ms_per_step, 1e-3)))
+    watts, mhz = [], []
+    t0 = time.perf_counter()
+    t_end, steps = t0 + seconds, 0
+    while time.perf_counter() < t_end:
+        step_batch(per)
+        steps += per
+        w = read_sensor(hw, ("power1_input", "power1_average"))
+        f = read_sensor(hw, ("freq1_input",))
+        if w is not None:
+            watts.append(w / 1e6)
+        if f is not None:
+            mhz.append(f / 1e6)
+    leg_ms = (time.perf_counter() - t0) * 1e3 / max(steps, 1)       # (includes the sensor reads: a few per cent above the timed figure)
+    if len(watts) < 4:
+        return None
+    tail = sorted(watts[len(watts) // 2:])
+    cap = read_sensor(hw, ("power1_cap",))
+    out = {"package_w": round(tail[len(tail) // 2], 1), "package_w_max": round(max(watts), 1), "cap_w": round(cap / 1e6, 1) if cap else None,
+           "samples": len(watts), "seconds": seconds, "ms_per_step_during": round(leg_ms, 5)}
+    if mhz:
+        tm = sorted(mhz[len(mhz) // 2:])
+        out["sensor_sclk_mhz"] = round(tm[len(tm) // 2], 0)
+    if out["cap_w"]:
+        out["at_cap"] = bool(out["package_w"] >= 0.98 * out["cap_w"])
+    return out
 
 
 def main():
@@ -636,6 +708,21 @@ def main():
             reps.append(dt_rep / a.steps * 1e3)
         repeats = {"ms_per_step": [round(x, 5) for x in reps], "median_ms_per_step": round(sorted(reps)[len(reps) // 2], 5), "meets_survey_8d": a.steps >= 100,
                    "note": "the timed region (first entry: `ms_per_step`, `value`) and four more regions of the same K steps behind it (after the run's validity checks)"}
+    # what the package draws under this kernel (single GPU; untimed, behind everything that is timed or checked): the symmetric kernel
+    # runs AT the board's power cap -- the clock it holds (`held_clock_ghz`) is what the cap leaves, which is why `frac` (priced at the
+    # nominal 2.4 GHz) stops near 0.92 while `frac_at_held_clock` is 1.0
+    power = None
+    if world == 1 and dist is None and not a.no_power_leg:
+        try:
+            hw = power_sensor(local_rank)
+            if hw:
+                def step_batch(k):
+                    for _ in range(k):
+                        c.Simulate(n, c.GetFenceValue())
+                    sync()
+                power = power_leg(step_batch, hw, ms_per_step=elapsed / a.steps * 1e3)
+        except (mapn.MapnError, OSError) as e:
+            print(f"[bench] power leg unavailable: {e}", file=sys.stderr, flush=True)
     if rank == 0:
         pairs_per_step = float(n) * float(n) if a.mode == "all_pairs" else float(n)
         value = pairs_per_step * a.steps / elapsed
@@ -698,6 +785,11 @@ def main():
                                    "frac_at_held_clock": (ach / (info.compute_units * held * 1e9 * 256 / 1e12)) if held else None,
                                    "flop_executed_per_pair": executed_per_pair,
                                    "frac_executed": ach / peak * executed_per_pair / FLOP_PER_PAIR,
+                                   "power": power,
+                                   "power_note": ("package power (hwmon power1_input) and sensor clock over ~2.5 s of the same steps run behind the timed region, second half of the "
+                                                  "samples; `at_cap`: the kernel runs at the board's power limit, so the clock it holds -- and with it `frac`, priced at the "
+                                                  "nominal clock -- is set by the energy a pair costs, not by issue cycles (null: no readable sensor / --no-power-leg)"),
+                                   "picojoule_per_interaction": (power["package_w"] * power["ms_per_step_during"] * 1e-3 / pairs_per_step * 1e12) if power else None,
                                    "valu_busy": pmc_traffic.valu_busy,
                                    "valu_busy_note": "4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / cycles of the committed PMC pass of these kernel sources (null: no pass on record for them)",
                                    "instruction_mix_ceiling": ("symmetric kernel: 14 packed ops x 4 cycles + 2 v_rsq_f32 x 8 cycles per 256 ordered interactions per SIMD "

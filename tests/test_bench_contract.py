@@ -77,6 +77,8 @@ def test_bench_json_contract():
     q = d["config"]["step_ms_by_quarter_of_the_timed_region"]       # the spread of the step time over the timed region, from HIP events
     assert len(q) == 4 and all(x is not None and 0.3 < x < 2.0 for x in q) and d["config"]["step_ms_spread"]["steps_timed"] >= 4
     assert "valu_busy" in rf
+    pw = rf["power"]                        # what the package draws under the kernel (hwmon sensor of THIS GPU, read over 2.5 s of steps behind the run); null without a readable sensor
+    assert pw is None or (300.0 < pw["package_w"] <= 1.05 * pw["cap_w"] and pw["samples"] >= 4 and 50.0 < rf["picojoule_per_interaction"] < 1000.0)
     x = d["config"]["xcd_aware_parts"]                              # calibrated BY THE LIBRARY at mapn_create (MAPN_FLAG_XCD_CALIBRATE), kept only if an untimed A/B wins
     assert x["mode"] == "auto" and (x.get("error") or (len(x["weights"]) == 8 and max(x["weights"]) == 1024 and isinstance(x["used"], bool)))
     assert x.get("error") or x["source"].startswith("library")      # (the bench's plan is the library's plan)

@@ -16,6 +16,7 @@
 #   parity1000                   tests/parity_report.py at 65 536 bodies, 1000 steps, all legs -> JSON
 #   ubench                       BASELINE configs[4]: the MFMA-against-packed-VALU A/B (tools/ubench --ab) under rocprofv3 --kernel-trace --stats + the gpu test's report
 #   soak MODE                    several real processes on one GPU, long runs: MODE = flow | sym | sympush (against p2p)
+#   power                        rocm-smi package power / shader clock / temperature while each force kernel runs flat out for 14 s (tools/power_probe.sh)
 set -u
 R=$PWD; W=${1:-suite}; shift || true
 O=$R/gpurun_out/ev_$W; mkdir -p $O
@@ -26,6 +27,8 @@ suite)
   sel=${1:-fast}; [ $sel = fast ] && M="gpu and not slow" || M="gpu"
   python -m pytest tests -m "$M" -q > $O/pytest_$sel.txt 2>&1; tail -4 $O/pytest_$sel.txt
   python bench.py > $O/bench_default.json 2> $O/bench_default.err; line default < $O/bench_default.json ;;
+power)
+  bash tools/power_probe.sh > $O/power_probe.txt 2>&1; cat $O/power_probe.txt ;;
 bench)
   python bench.py "$@" > $O/bench.json 2> $O/bench.err; line "bench $*" < $O/bench.json ;;
 stats)

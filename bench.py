@@ -159,13 +159,13 @@ def pmc_traffic(kernel_name, n, world):
 pmc_traffic.valu_busy = None    # VALU busy fraction of the same (sha-matched) PMC summary, if it holds one
 
 
-def power_sensor(device_index):
-    """The hwmon directory of the GPU torch calls `device_index` (amdgpu: power1_input / power1_average in microwatts, power1_cap,
+def power_sensor(device_index, root="/sys/class/drm"):
+    """The hwmon directory of the GPU the HIP runtime calls `device_index` (amdgpu: power1_input / power1_average in microwatts, power1_cap,
     freq1_input = shader clock in Hz), or None.  Matched by PCI address (hipDeviceGetPCIBusId against the sysfs device directory: the
     driver's 1-GPU boxes show the sensors of all of the host's GPUs); a box with ONE sensor is taken as that GPU."""
     import glob
     cands = []
-    for hw in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+    for hw in sorted(glob.glob(os.path.join(root, "card*", "device", "hwmon", "hwmon*"))):
         if any(os.access(os.path.join(hw, f), os.R_OK) for f in ("power1_input", "power1_average")):
             cands.append(hw)
     if not cands:

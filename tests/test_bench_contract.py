@@ -36,6 +36,33 @@ def test_bench_launches_its_own_ranks_and_relays_their_failure_without_a_gpu():
     assert not any(line.startswith("{") for line in r.stdout.splitlines())
 
 
+def test_power_leg_reads_the_sensor_between_batches_and_reports_the_settled_half(tmp_path):
+    """bench.py's `roofline.power`: the hwmon sensor is found (one candidate: taken; several and no PCI match: none), read between
+    batches of steps, and the figures are those of the second half of the samples."""
+    sys.path.insert(0, ROOT)
+    import bench
+    hw = tmp_path / "card3" / "device" / "hwmon" / "hwmon7"
+    hw.mkdir(parents=True)
+    (hw / "power1_cap").write_text("1400000000\n")
+    (hw / "freq1_input").write_text("2200000000\n")
+    (hw / "power1_input").write_text("300000000\n")
+    (tmp_path / "card4" / "device").mkdir(parents=True)                      # a card without a sensor (the boxes list dozens)
+    assert bench.power_sensor(0, root=str(tmp_path)) == str(hw)
+    calls = []
+
+    def step_batch(k):                                                      # the "kernel": the sensor climbs to the limit while it runs
+        calls.append(k)
+        (hw / "power1_input").write_text(str(min(1400, 300 + 200 * len(calls)) * 1000000))
+    out = bench.power_leg(step_batch, str(hw), seconds=0.05, batch_ms=1.0, ms_per_step=0.5)
+    assert out is not None and calls and all(k == 2 for k in calls) and out["samples"] == len(calls) >= 4
+    assert out["cap_w"] == 1400.0 and out["package_w_max"] == 1400.0 and out["package_w"] == 1400.0 and out["at_cap"] is True and out["sensor_sclk_mhz"] == 2200.0
+    hw2 = tmp_path / "card5" / "device" / "hwmon" / "hwmon9"               # a second GPU's sensor and no way to tell them apart here: no guess
+    hw2.mkdir(parents=True)
+    (hw2 / "power1_input").write_text("100000000\n")
+    assert bench.power_sensor(0, root=str(tmp_path)) is None
+    assert bench.power_leg(lambda k: None, str(tmp_path / "nowhere"), seconds=0.01, batch_ms=1.0, ms_per_step=0.5) is None
+
+
 def test_committed_pmc_summaries_belong_to_the_current_kernel_sources():
     """bench.py attaches `roofline.traffic` only while the committed PMC summary was measured on the kernel
     sources being run (their sha is stored in it): a kernel edit without a fresh `--pmc` pass must show up

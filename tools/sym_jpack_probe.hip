@@ -6,7 +6,7 @@
 //   B  the two lanes of a packed operation given to TWO travelling bodies and one resident one: 16 resident bodies per lane,
 //      unpacked; a step = 16 packed evaluations (32 pairs per lane) + 12 ds_bpermute_b32 -- a third fewer moves per pair
 // Prints pairs per second, wall time per launch and the clock held (s_memtime / s_memrealtime), after >= 2 s of launches.
-// Build: hipcc --offload-arch=gfx950 -O3 -o tools/sym_jpack_probe tools/sym_jpack_probe.hip      Run: tools/sym_jpack_probe [steps]
+// Build: hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-sched-strategy=max-ilp -o tools/sym_jpack_probe tools/sym_jpack_probe.hip   (the schedule the product has)      Run: tools/sym_jpack_probe [steps]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -21,7 +21,7 @@ __device__ __forceinline__ float lane_next(float v, int addr)
 }
 
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void probe(const float4 *bodies, float4 *out, unsigned long long *clk, int steps, float soft)
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void probe(const float4 *bodies, float4 *out, unsigned long long *clk, int steps, float soft)
 {
     const uint32_t lane = threadIdx.x & 63u, gw = (blockIdx.x * 512u + threadIdx.x) >> 6;
     const int next = (int)((lane + 1u) & 63u) * 4;

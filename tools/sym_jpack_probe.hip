@@ -21,12 +21,16 @@ __device__ __forceinline__ float lane_next(float v, int addr)
 }
 
 template <int MODE>
-__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void probe(const float4 *bodies, float4 *out, unsigned long long *clk, int steps, float soft)
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void probe(const float4 *bodies, float4 *out, unsigned long long *clk, int steps, float soft, int bias)
 {
     const uint32_t lane = threadIdx.x & 63u, gw = (blockIdx.x * 512u + threadIdx.x) >> 6;
     const int next = (int)((lane + 1u) & 63u) * 4;
     const v2f soft2 = v2f{soft, soft};
     const float4 *mine = bodies + (size_t)gw * 64u * 20u + lane;
+    // the product's wave bias: the older wave of every SIMD (the first half of the workgroup's waves) takes 10 : 3 of the steps, so that
+    // the two end together (issue goes oldest-first: run with equal shares the older wave ends early and the younger one runs on alone)
+    if (bias) steps = (threadIdx.x >> 6) < 4u ? steps * 20 / 13 : steps * 6 / 13;
+    steps &= ~1;
     unsigned long long c0 = 0, r0 = 0;
     float ox = 0.f, oy = 0.f, oz = 0.f;
     if constexpr (MODE == 0) {
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int MODE>
-static int run(const char *name, const float4 *bodies, float4 *out, unsigned long long *clk, int steps, int pairs_per_step, int waves)
+static int run(const char *name, const float4 *bodies, float4 *out, unsigned long long *clk, int steps, int pairs_per_step, int waves, int bias)
 {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -195,18 +199,18 @@ static int run(const char *name, const float4 *bodies, float4 *out, unsigned lon
     // settle: >= 2 s of launches, then time 20
     CK(hipEventRecord(e0));
     do {
-        for (int i = 0; i < 8; i++) hipLaunchKernelGGL(probe<MODE>, dim3(waves / 8), dim3(512), 0, 0, bodies, out, clk, steps, 25.0f);
+        for (int i = 0; i < 8; i++) hipLaunchKernelGGL(probe<MODE>, dim3(waves / 8), dim3(512), 0, 0, bodies, out, clk, steps, 25.0f, bias);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
     } while (ms < 2000.f);
     CK(hipEventRecord(e0));
-    for (launches = 0; launches < 20; launches++) hipLaunchKernelGGL(probe<MODE>, dim3(waves / 8), dim3(512), 0, 0, bodies, out, clk, steps, 25.0f);
+    for (launches = 0; launches < 20; launches++) hipLaunchKernelGGL(probe<MODE>, dim3(waves / 8), dim3(512), 0, 0, bodies, out, clk, steps, 25.0f, bias);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
     std::vector<unsigned long long> h(2 * (size_t)waves);
     CK(hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost));
     std::vector<double> ghz;
     for (int w = 0; w < waves; w++) if (h[2 * w + 1]) ghz.push_back((double)h[2 * w] / (double)h[2 * w + 1] * 0.1);
     std::sort(ghz.begin(), ghz.end());
-    const double per_launch = ms / launches, pairs = (double)waves * 64.0 * steps * pairs_per_step;
+    const double per_launch = ms / launches, pairs = (double)waves * 64.0 * (bias ? ((steps * 20 / 13) & ~1) * 0.5 + ((steps * 6 / 13) & ~1) * 0.5 : (double)(steps & ~1)) * pairs_per_step;
     printf("%-44s %8.3f ms per launch  %.4e ordered interactions/s (2 per evaluated pair)  clock %.3f GHz\n", name, per_launch, 2.0 * pairs / (per_launch * 1e-3),
            ghz.empty() ? 0.0 : ghz[ghz.size() / 2]);
     return 0;
@@ -225,11 +229,14 @@ int main(int argc, char **argv)
     unsigned long long *clk;
     CK(hipMalloc(&bodies, h.size() * sizeof(float4))); CK(hipMalloc(&out, (size_t)waves * 64 * sizeof(float4))); CK(hipMalloc(&clk, 2 * (size_t)waves * 8));
     CK(hipMemcpy(bodies, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice));
-    for (int rep = 0; rep < 2; rep++) {
-        if (run<0>("A: 8 packed pairs resident, 1 travelling", bodies, out, clk, steps, 16, waves)) return 1;
-        if (run<1>("B: 16 resident, 2 travelling (J-packed)", bodies, out, clk, steps / 2, 32, waves)) return 1;
-        if (run<2>("A2: as A, two steps per trip (the product)", bodies, out, clk, steps, 16, waves)) return 1;
-        if (run<3>("B2: as B, two steps per trip", bodies, out, clk, steps / 2, 32, waves)) return 1;
+    for (int bias = 0; bias < 2; bias++) {
+        printf("== %s\n", bias ? "steps shared 10 : 3 between the older and the younger wave of a SIMD (the product's plan)" : "equal steps for every wave");
+        for (int rep = 0; rep < 2; rep++) {
+            if (run<0>("A: 8 packed pairs resident, 1 travelling", bodies, out, clk, steps, 16, waves, bias)) return 1;
+            if (run<1>("B: 16 resident, 2 travelling (J-packed)", bodies, out, clk, steps / 2, 32, waves, bias)) return 1;
+            if (run<2>("A2: as A, two steps per trip (the product)", bodies, out, clk, steps, 16, waves, bias)) return 1;
+            if (run<3>("B2: as B, two steps per trip", bodies, out, clk, steps / 2, 32, waves, bias)) return 1;
+        }
     }
     return 0;
 }

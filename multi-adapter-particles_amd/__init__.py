@@ -12,10 +12,9 @@ from ._lib import (  # noqa: F401
     build_library, library_path, load_library,
 )
 from .compute import Compute, IpcView, SymPlan, describe_sym_plan, generate_initial_state  # noqa: F401
-from .shard import ShardPlan, shard_range, remote_segments  # noqa: F401
 
 __all__ = [
-    "Compute", "IpcView", "Config", "MapnError", "ShardPlan", "shard_range", "remote_segments",
+    "Compute", "IpcView", "Config", "MapnError",
     "generate_initial_state", "SymPlan", "describe_sym_plan", "build_library", "load_library", "library_path",
     "FORCE_ALL_PAIRS", "FORCE_CENTRAL_WELL", "KERNEL_AUTO", "KERNEL_LDS", "KERNEL_SCALAR", "KERNEL_SYMMETRIC",
     "FLAG_NO_INIT", "FLAG_USE_GRAPH", "FLAG_SHARD_OVERLAP", "FLAG_STRICT_CONSUMER", "FLAG_XCD_CALIBRATE", "INIT_LCG", "INIT_SSE", "INIT_MT",

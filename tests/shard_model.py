@@ -1,4 +1,5 @@
-"""Body sharding across ranks (one process per GPU).
+"""Body sharding across ranks (one process per GPU) -- a Python MODEL of the host logic, TEST INFRASTRUCTURE only: the product's
+arithmetic is C++ (csrc/mapn_context.cpp, mapn_sym_plan.cpp, mapn_shard.cpp); the tests hold it against this restatement.
 
 Rank p of P owns the contiguous slice [p*N/P, (p+1)*N/P) of positions and velocities; every
 rank keeps a full replica of the position buffer and the new float4 slices are all-gathered

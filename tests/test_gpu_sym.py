@@ -313,7 +313,7 @@ def test_xcd_calibration_flag_on_a_sharded_context_plans_the_ranks_launch_with_i
 def _loopback_expectation(pos, vel, nb, nbl, mass, soft2, dt):
     """What rank 0 of a sharded job computes when no peer ever answers (float64): its blocks meet what the schedule says; its
     bodies get the forces of those meetings plus the reactions of meetings between two of its own blocks."""
-    from mapn import shard
+    import shard_model as shard
     x = pos[:, :3].astype(np.float64)
     acc = np.zeros((nbl * 1024, 3))
     for a, b, d, symmetric in shard.sym_meetings(nb):
@@ -446,7 +446,7 @@ def test_rccl_form_of_the_sharded_symmetric_step_one_rank_loopback(oracle, monke
     and reduce launches, the own reactions travelling through the receive rows, the exchange-number tags, the collective calls.
     Rank 1's reactions never arrive, so the expectation is built accordingly (float64): rank 0's blocks meet what the schedule
     says, its bodies get the forces from those meetings plus the reactions of meetings between two of rank 0's own blocks."""
-    from mapn import shard
+    import shard_model as shard
     monkeypatch.setenv("MAPN_TEST_HOOKS", "1")           # (hooks are honoured only with this set)
     monkeypatch.setenv("MAPN_COMM_LOOPBACK", "1")
     n, world = 8192, 2

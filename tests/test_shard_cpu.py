@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import mapn
-from mapn.shard import ShardPlan, active_bodies, remote_segments, shard_range
+from shard_model import ShardPlan, active_bodies, remote_segments, shard_range
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -1,5 +1,5 @@
 """CPU checks of the combinatorics behind two device-side index maps (host mirrors in
-multi-adapter-particles_amd/shard.py; the device arithmetic is in csrc/mapn_sym.hip and
+tests/shard_model.py; the device arithmetic is in csrc/mapn_sym.hip and
 csrc/mapn_kernels.hip): the symmetric kernel's meeting schedule must cover every unordered pair of
 blocks exactly once, its reduce kernel must read exactly the rows that were written, and flow
 mode's row rotation must start on the rank's own slice without changing which chunk a row names."""
@@ -9,7 +9,7 @@ import numpy as np
 
 import pytest
 
-from mapn import shard
+import shard_model as shard
 
 
 @pytest.mark.parametrize("nb", list(range(1, 20)) + [128, 129, 512])
@@ -166,7 +166,7 @@ def test_class_aware_xcd_weights_put_the_heavy_blocks_on_the_fast_dies(nb, parts
     block's parts per die, each sized by its die's speed.  The workgroup map is a bijection onto (block, part); workgroup (x, y)
     lands on die x mod 8; the tables stay per class."""
     import mapn
-    from mapn import shard
+    import shard_model as shard
     plan = mapn.describe_sym_plan(nb, 0, parts, None, 0, waves, xcd_weights=XCD_W, wave_bias=bias, launch_blocks=blocks, launch_a0=a0)
     B = blocks or nb
     assert plan.xcd_mode == 2 and plan.sets == 2 and plan.wgmap.shape == (parts, B, 2)
@@ -218,7 +218,7 @@ def test_default_sharded_plan_puts_the_heavy_blocks_on_the_odd_dispatch_slots():
     and were the slower ranks.  Without XCD weights the plan now flips block x <-> x ^ 1 where that puts the heavy blocks on the odd
     slots; unsharded launches (every die holds both classes) and weighted plans (the workgroup map decides) are left alone."""
     import mapn
-    from mapn import shard
+    import shard_model as shard
     for rank in range(8):
         pl = mapn.describe_sym_plan(64, 0, 32, None, 0, 8, wave_bias=(3, 1), launch_blocks=8, launch_a0=8 * rank)
         heavy_slots = {(la ^ pl.la_flip) % 8 for la in range(8) if shard.sym_block_class(64, 8 * rank + la) == 0}

@@ -278,6 +278,7 @@ def main():
         flags |= mapn.FLAG_XCD_CALIBRATE
     c = mapn.Compute(n, device=local_rank, force_mode=mode, mass=70000.0 / n, seed=a.seed,
                      rank=rank, world_size=world, flags=flags, kernel=kern)
+    created_note = mapn.load_library().mapn_last_error().decode(errors="replace")    # (what mapn_create left behind: why a calibration did not stay)
     info = device_info(local_rank)
     transport = "none"
     gather_fn = None
@@ -582,7 +583,8 @@ def main():
                     c.set_sym_xcd_weights(w)
                     xcd["used"] = c.sym_plan().xcd_mode != 0
             else:
-                xcd["note"] = "the library's calibration did not apply (block count not a multiple of 8, or the one-sided kernel runs)"
+                xcd["note"] = ("the library runs the default plan: its calibration did not apply (block count not a multiple of 8, or the one-sided kernel "
+                               "runs) or the calibrated plan did not win the A/B mapn_create runs behind it: " + created_note[:200])
         except mapn.MapnError as e:
             xcd["error"] = str(e)[:200]
             try:

@@ -92,13 +92,17 @@ typedef enum mapn_init_variant {
                                           which is put back bit for bit together with the fence value and the buffer index) and
                                           size every part of the launch plan by the die it runs on (mapn_set_sym_xcd_weights) --
                                           the plan bench.py's headline number is measured with, for any C-ABI caller
-                                          (compat/Compute.hpp: one config bit).  A hint: where XCD weights do not apply
+                                          (compat/Compute.hpp: one config bit).  Up to 262 144 bodies the weighted plan is then VERIFIED
+                                          (another 0.2 s): plain steps under it and under the default plan, interleaved, best of two
+                                          bursts each -- it stays only if it wins by 0.2 %, otherwise the default plan runs and
+                                          mapn_last_error() says so (the calibration reads lone stamped launches and can catch a
+                                          transient).  A hint: where XCD weights do not apply
                                           (one-sided kernel, block count not a multiple of 8, a partitioned
                                           device) creation succeeds with the default plan and mapn_last_error() says why.  On a SHARDED
                                           context the flag acts when the sharded symmetric step is prepared (mapn_set_gather_algorithm
                                           4 / 5 / 6): a temporary UNSHARDED context of the same size measures this rank's GPU (no
                                           collective in it) and the rank's launch is planned with those weights;
-                                          mapn_get_sym_plan(...)->sets == 16 tells whether the weights are in use. */
+                                          mapn_get_sym_plan(...)->xcd_mode != 0 tells whether the weights are in use. */
 
 /*
  * Everything `Compute::Compute(numParticles, adapter, useIntelExt, old)` (Compute.h:36-39)

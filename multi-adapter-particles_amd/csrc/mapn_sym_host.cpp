@@ -505,8 +505,48 @@ int calibrate_at_creation(mapn_ctx *c)
     uint32_t w[8];
     if (!rc) rc = mapn_calibrate_sym_xcds(c, c->n <= 262144u ? 4 : 1, w);
     if (!rc) rc = mapn_set_sym_xcd_weights(c, w);
-    const std::string note = rc ? "MAPN_FLAG_XCD_CALIBRATE: " + g_last_error + "; the default plan runs" : std::string();
+    std::string note = rc ? "MAPN_FLAG_XCD_CALIBRATE: " + g_last_error + "; the default plan runs" : std::string();
     if (rc) (void)mapn_set_sym_xcd_weights(c, nullptr);
+    // ... and VERIFIED: the calibration reads lone stamped launches, and now and then what it reads is a transient (a die measured
+    // 6 - 13 % slow for a few launches: weights like that cost 2 - 4 % per step).  The weighted plan stays only if it wins an A/B of
+    // plain steps against the default plan -- best of two bursts each, interleaved, 0.2 % margin: the decision bench.py has always
+    // made for itself, now the library's.  (Up to 262 144 bodies: beyond, four bursts would cost seconds and a launch is long enough
+    // to average the transients out.  MAPN_XCD_VERIFY=0 with MAPN_TEST_HOOKS=1: no A/B, for the tests that need the weighted plan.)
+    const char *vf = test_hook("MAPN_XCD_VERIFY");
+    if (!rc && c->n <= 262144u && !(vf && vf[0] == '0')) {
+        const double est = 0.6e-3 * ((double)c->n / 65536.0) * ((double)c->n / 65536.0);
+        const int kk = std::max(2, std::min(64, (int)(0.04 / est)));
+        hipEvent_t a0 = nullptr, a1 = nullptr;
+        float best_w = 1e30f, best_d = 1e30f;
+        if (hipEventCreate(&a0) == hipSuccess && hipEventCreate(&a1) == hipSuccess) {
+            for (int leg = 0; leg < 4 && !rc; leg++) {
+                const bool weighted = (leg & 1) == 0;
+                if (leg) rc = mapn_set_sym_xcd_weights(c, weighted ? w : nullptr);
+                for (int k = 0; k < 4 && !rc; k++) rc = mapn_simulate(c, (int)c->n, 0);        // (the re-plan left the queue idle)
+                if (rc) break;
+                (void)hipEventRecord(a0, c->compute);
+                for (int k = 0; k < kk && !rc; k++) rc = mapn_simulate(c, (int)c->n, 0);
+                (void)hipEventRecord(a1, c->compute);
+                float ms = 0.f;
+                if (rc || hipEventSynchronize(a1) != hipSuccess || hipEventElapsedTime(&ms, a0, a1) != hipSuccess) { best_w = best_d = 1e30f; break; }
+                (weighted ? best_w : best_d) = std::min(weighted ? best_w : best_d, ms / (float)kk);
+            }
+        }
+        if (a0) (void)hipEventDestroy(a0);
+        if (a1) (void)hipEventDestroy(a1);
+        (void)hipGetLastError();
+        if (!rc) {
+            const bool keep = best_w < 1e29f && best_w < best_d * 0.998f;
+            rc = mapn_set_sym_xcd_weights(c, keep ? w : nullptr);
+            if (!rc && !keep) {
+                char msg[256];
+                snprintf(msg, sizeof msg, "MAPN_FLAG_XCD_CALIBRATE: the calibrated plan did not win its A/B against the default plan (%.4f against %.4f ms per step); the default plan runs",
+                         (double)best_w, (double)best_d);
+                note = msg;
+            }
+        }
+        if (rc) { note = "MAPN_FLAG_XCD_CALIBRATE: " + g_last_error + "; the default plan runs"; (void)mapn_set_sym_xcd_weights(c, nullptr); }
+    }
     // put everything back
     rc = mapn_wait_idle(c);
     for (uint32_t b = 0; b < 2 && !rc; b++) {

@@ -95,7 +95,8 @@ int main(int argc, char **argv)
         CHECK(pBig->GetFenceValue() == 4);
         mapn_sym_plan_info info;
         CHECK(mapn_get_sym_plan(pBig->Handle(), &info, nullptr, 0, nullptr, 0) == MAPN_OK);
-        CHECK(info.xcd_mode == 2u && info.wgmap_entries == 64u * info.parts);            // class-aware weights at 65 536 bodies
+        // class-aware weights at 65 536 bodies -- or, where the calibrated plan did not win the A/B mapn_create runs behind the calibration, the default plan
+        CHECK((info.xcd_mode == 2u && info.wgmap_entries == 64u * info.parts) || (info.xcd_mode == 0u && info.wgmap_entries == 0u));
         for (int frame = 0; frame < 3; frame++) pBig->Simulate(65536, pBig->GetFenceValue());
         pBig->WaitForGpu();
         CHECK(pBig->GetFenceValue() == 4 + 3 + 1);

@@ -107,8 +107,9 @@ def test_bench_json_contract():
     pw = rf["power"]                        # what the package draws under the kernel (hwmon sensor of THIS GPU, read over 2.5 s of steps behind the run); null without a readable sensor
     assert pw is None or (300.0 < pw["package_w"] <= 1.05 * pw["cap_w"] and pw["samples"] >= 4 and 50.0 < rf["picojoule_per_interaction"] < 1000.0)
     x = d["config"]["xcd_aware_parts"]                              # calibrated BY THE LIBRARY at mapn_create (MAPN_FLAG_XCD_CALIBRATE), kept only if an untimed A/B wins
-    assert x["mode"] == "auto" and (x.get("error") or (len(x["weights"]) == 8 and max(x["weights"]) == 1024 and isinstance(x["used"], bool)))
-    assert x.get("error") or x["source"].startswith("library")      # (the bench's plan is the library's plan)
+    # (the library keeps its calibrated plan only if it wins an A/B at mapn_create: where it did not, the note says so and the default plan runs)
+    assert x["mode"] == "auto" and (x.get("error") or x.get("note") or (len(x["weights"]) == 8 and max(x["weights"]) == 1024 and isinstance(x["used"], bool)))
+    assert x.get("error") or x.get("note") or x["source"].startswith("library")      # (the bench's plan is the library's plan)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e8 and "sample" in cb
     rep = d["config"]["repeats"]            # five regions of K steps, listed with their median, for every K; SURVEY 8(d)'s count needs K >= 100

@@ -316,12 +316,12 @@ def test_xcd_calibration_at_creation_keeps_the_weighted_plan_only_if_it_wins_its
                 c.Simulate(n, c.GetFenceValue())
             c.WaitForGpu()
             return (time.perf_counter() - t0) / k * 1e3
-        if pl.xcd_mode == 2:                               # the plan that stayed is not the slower one (1 % for the noise of two more bursts)
+        if pl.xcd_mode == 2:                               # the plan that stayed is not the slower one (2 % for the noise of two more bursts around a win that may be 0.2 %)
             t_kept = min(burst(), burst())
             c.set_sym_xcd_weights(None)
             t_other = min(burst(), burst())
             print(f"kept (weighted) {t_kept:.4f} ms per step, default {t_other:.4f}")
-            assert t_kept < t_other * 1.01
+            assert t_kept < t_other * 1.02
 
 
 def test_xcd_calibration_flag_on_a_sharded_context_plans_the_ranks_launch_with_its_gpus_die_weights(monkeypatch):

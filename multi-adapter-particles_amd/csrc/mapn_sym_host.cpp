@@ -503,7 +503,7 @@ int calibrate_at_creation(mapn_ctx *c)
     if (e1) (void)hipEventDestroy(e1);
     (void)hipGetLastError();
     uint32_t w[8];
-    if (!rc) rc = mapn_calibrate_sym_xcds(c, c->n <= 262144u ? 4 : 1, w);
+    if (!rc) rc = mapn_calibrate_sym_xcds(c, c->n <= 131072u ? 8 : c->n <= 262144u ? 4 : 1, w);
     if (!rc) rc = mapn_set_sym_xcd_weights(c, w);
     std::string note = rc ? "MAPN_FLAG_XCD_CALIBRATE: " + g_last_error + "; the default plan runs" : std::string();
     if (rc) (void)mapn_set_sym_xcd_weights(c, nullptr);
@@ -645,12 +645,13 @@ int mapn_calibrate_sym_xcds(mapn_ctx *c, int steps, uint32_t out[8])
         const uint32_t m = pl.tables[pl.wgmap_offset + e];
         wg_x[(size_t)(m >> 16) * pl.parts + (m & 0xffffu)] = e % nblk;
     }
-    std::vector<double> per[8];
+    std::vector<double> per[8], launch_median[8];
     int slot_xcc[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
     // (Every wave's time per step is read, the older and the younger wave of a SIMD alike.  Reading the older waves only -- the SIMD
     //  serves them first, so their time is the die's own -- was tried: same gain unsharded, and a LOSS sharded, 1.001 - 1.005 against
     //  0.987 - 0.990 of the default step on one box: profiles/r04_xcd_class_aware_ab.txt.)
-    for (const std::vector<unsigned long long> &tl : stamps)
+    for (const std::vector<unsigned long long> &tl : stamps) {
+        for (int x = 0; x < 8; x++) per[x].clear();
         for (size_t wv = 0; wv < tl.size() / 6; wv++) {
             const unsigned long long *o = &tl[6 * wv];
             const uint32_t wg = (uint32_t)(wv / pl.waves), la = wg / pl.parts, part = wg % pl.parts;
@@ -663,11 +664,20 @@ int mapn_calibrate_sym_xcds(mapn_ctx *c, int steps, uint32_t out[8])
                 return fail(MAPN_ERR_STATE, "calibrate_sym_xcds: workgroups of dispatch slot %u ran on XCC %d and %u: not dealt round-robin to the dies", slot, slot_xcc[slot], xcc);
             per[slot].push_back((double)(o[2] - o[1]) / (double)o[5]);   // 100 MHz ticks per step
         }
+        // (one figure per die and LAUNCH -- the median over its waves -- and then the median over the launches: the launches are lone
+        //  ones out of an idle queue, and a die that is slow for one or two of them, which happens, does not move the result)
+        for (int x = 0; x < 8; x++) {
+            if (per[x].empty()) continue;
+            std::nth_element(per[x].begin(), per[x].begin() + per[x].size() / 2, per[x].end());
+            launch_median[x].push_back(per[x][per[x].size() / 2]);
+        }
+    }
     double speed[8], best = 0.0;
     for (int x = 0; x < 8; x++) {
-        if (per[x].empty()) return fail(MAPN_ERR_STATE, "calibrate_sym_xcds: no wave was seen in dispatch slot %d (a partitioned or masked device?)", x);
-        std::nth_element(per[x].begin(), per[x].begin() + per[x].size() / 2, per[x].end());
-        speed[x] = 1.0 / per[x][per[x].size() / 2];
+        std::vector<double> &lm = launch_median[x];
+        if (lm.empty()) return fail(MAPN_ERR_STATE, "calibrate_sym_xcds: no wave was seen in dispatch slot %d (a partitioned or masked device?)", x);
+        std::sort(lm.begin(), lm.end());
+        speed[x] = 1.0 / (lm.size() & 1u ? lm[lm.size() / 2] : 0.5 * (lm[lm.size() / 2 - 1] + lm[lm.size() / 2]));
         best = std::max(best, speed[x]);
     }
     for (int x = 0; x < 8; x++) out[x] = (uint32_t)(1024.0 * speed[x] / best + 0.5);

@@ -606,6 +606,7 @@ def main():
             fail = str(e)
         if torch is not None:
             torch.cuda.synchronize()
+        run_steps.idle_at = time.perf_counter()               # THIS rank's device is idle: its k steps are done (the closing collective is still to come)
         if dist is not None:
             if recoverable:
                 bad = torch.tensor([1 if fail else 0], device=red_dev)
@@ -629,6 +630,7 @@ def main():
             t0 = time.perf_counter()
             fail = run_steps(a.steps, recoverable)
             elapsed = time.perf_counter() - t0
+            elapsed_idle = run_steps.idle_at - t0              # (N > 1: without the closing collective -- reported beside the contract's figure, never instead of it)
         if not fail:
             break
         # A peer-to-peer form that had passed its trial failed in the run itself (a pushed position that did not match its checksum, a
@@ -648,9 +650,9 @@ def main():
         transport = "p2p (hipIpc + device flags)" if 2 <= chosen[1] <= 5 else "rccl"
         xcd["used"] = False
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        t = torch.tensor([elapsed, elapsed_idle], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed_idle = float(t[0].item()), float(t[1].item())
 
     st = c.kernel_stats()
     # how the step time is spread over the timed region: the steps that carried HIP events (every timer_interval-th), by quarter
@@ -743,6 +745,7 @@ def main():
             "unit": "interactions/s" if a.mode == "all_pairs" else "bodies/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
+            "ms_per_step_before_closing_barrier": (elapsed_idle / a.steps * 1e3) if dist is not None else None,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

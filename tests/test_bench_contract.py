@@ -162,6 +162,24 @@ def test_bench_one_sided_kernel_line():
 
 
 @pytest.mark.gpu
+def test_bench_one_rank_over_the_rccl_backend_and_the_in_library_communicator():
+    """What a 1-GPU box can run of the RCCL path of bench.py: one rank under torch.distributed.run with --force-comm -- the "nccl"
+    process group bound to the device, stdout handed to stderr while the collective libraries set up (their banners must not reach
+    the ONE JSON line), the unique id broadcast and mapn_comm_init, the all-gather exchange behind every step, the barrier-bracketed
+    timing through RCCL collectives.  (Every N > 1 test here shares one device and has to use gloo: RCCL refuses that.)"""
+    port = 29900 + (os.getpid() % 90)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "30", "--warmup", "3", "--force-comm", "--no-cpu-baseline", "--prewarm-ms", "50"],
+                       capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert r.returncode == 0 and len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["transport"] == "rccl" and d["config"]["exchange"] == "allgather" and d["config"]["valid"] is True
+    assert 0.0 < d["ms_per_step_before_closing_barrier"] <= d["ms_per_step"] and d["value"] > 3.0e12
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_one_gpu_with_the_direct_exchange():
     """The N > 1 flow of bench.py (rendezvous, sharded contexts, exchange set-up, barrier-bracketed
     timing, MAX over ranks, replica consistency check) with two ranks sharing device 0: gloo for

@@ -302,6 +302,9 @@ def main():
     apply_plan()
     # each hipEventRecord costs ~4 us of queue time: at most one event PAIR per 4 steps, also for short runs
     timer_interval = a.timer_interval if a.timer_interval >= 0 else (8 if a.steps >= 32 else 4)
+    if a.timer_interval < 0 and world > 1:
+        # a sharded step is 0.09 ms at 65 536 / 8, an event pair 8 us of it: two sampled steps in a short region, every 16th in a long one
+        timer_interval = 16 if a.steps >= 32 else max(4, a.steps // 2)
     c.set_timers(timer_interval)
 
     def step():

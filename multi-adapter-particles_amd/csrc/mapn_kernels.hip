@@ -98,11 +98,16 @@ __device__ __forceinline__ void pair_term2_pairs(Acc2 &a, v2f xi, v2f yi, v2f zi
 }
 
 // nBodyGravityCS.hlsl:103-108: kick, damp, drift; w = |accel|
+// (STREAM: the velocity is read and the new state written with the non-temporal hint -- a state far larger than the 256 MiB
+//  Infinity Cache passes through once per step, nothing of it is there again when the next step comes: central_well_kernel)
+template <bool STREAM = false>
 __device__ __forceinline__ void integrate_store(const StepArgs &p, uint32_t i, float4 pos,
                                                 float ax, float ay, float az)
 {
     const float *v = p.vel_old + 3 * (size_t)i;
-    float vx = v[0], vy = v[1], vz = v[2];
+    float vx, vy, vz;
+    if constexpr (STREAM) { vx = __builtin_nontemporal_load(v); vy = __builtin_nontemporal_load(v + 1); vz = __builtin_nontemporal_load(v + 2); }
+    else { vx = v[0]; vy = v[1]; vz = v[2]; }
     vx = __builtin_fmaf(ax, p.dt, vx) * p.damping;
     vy = __builtin_fmaf(ay, p.dt, vy) * p.damping;
     vz = __builtin_fmaf(az, p.dt, vz) * p.damping;
@@ -111,16 +116,22 @@ __device__ __forceinline__ void integrate_store(const StepArgs &p, uint32_t i, f
     o.y = __builtin_fmaf(vy, p.dt, pos.y);
     o.z = __builtin_fmaf(vz, p.dt, pos.z);
     o.w = __builtin_sqrtf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)));
+    typedef float f4s __attribute__((ext_vector_type(4)));
+    float *vo = p.vel_new + 3 * (size_t)i;
+    if constexpr (STREAM) {
+        const f4s w = {o.x, o.y, o.z, o.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<f4s *>(p.pos_new + i));
+        __builtin_nontemporal_store(vx, vo); __builtin_nontemporal_store(vy, vo + 1); __builtin_nontemporal_store(vz, vo + 2);
+        return;
+    }
     if (p.flow_arrived) {
         // flow mode: peers pull this slice over xGMI while the launch is still running -- the new
         // position goes write-through to memory at system scope (one global_store_dwordx4 sc0 sc1)
-        typedef float f4s __attribute__((ext_vector_type(4)));
         const f4s v = {o.x, o.y, o.z, o.w};
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p.pos_new + i), "v"(v) : "memory");
     } else {
         p.pos_new[i] = o;
     }
-    float *vo = p.vel_new + 3 * (size_t)i;
     vo[0] = vx; vo[1] = vy; vo[2] = vz;
 }
 
@@ -557,18 +568,31 @@ __global__ __launch_bounds__(256) void reduce_integrate_kernel(const StepArgs p,
 // ---------------------------------------------------------------------------------------------
 // CSMain exactly as shipped (nBodyGravityCS.hlsl:86-109): one gravity well at the origin.
 // HBM-bound, 56 B per body.  One thread per body like the reference.
+// STREAM (chosen by the host where a step's 56 B per body exceed 320 MiB, i.e. from 6 Mi bodies on): non-temporal loads and stores.
+// Measured (round 4, a probe of this kernel: profiles/r04_central_well_stream.txt): inside the Infinity Cache -- the reference's default
+// 4 Mi bodies, 235 MB per step -- the plain form runs at 6.9 TB/s and the hint costs 12 %; from 6 Mi bodies on the plain form falls to
+// 5.6 - 6.1 TB/s (with the placement of the buffers: +- 4 %) and the hint gives 6.1 - 6.45 at every size and placement tried
+// (the guide's float4-copy rate: 6.29).  More bodies per thread change nothing.
+template <bool STREAM>
 __global__ __launch_bounds__(256) void central_well_kernel(const StepArgs p)
 {
     const uint32_t li = blockIdx.x * 256u + threadIdx.x;
     if (li >= p.i_count) return;
     const uint32_t i = p.i_first + li;
-    const float4 pos = p.pos_old[i];
+    float4 pos;
+    if constexpr (STREAM) {
+        typedef float f4s __attribute__((ext_vector_type(4)));
+        const f4s v = __builtin_nontemporal_load(reinterpret_cast<const f4s *>(p.pos_old + i));
+        pos = make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        pos = p.pos_old[i];
+    }
     float d = __builtin_fmaf(pos.x, pos.x, p.soft2);     // :94-95
     d = __builtin_fmaf(pos.y, pos.y, d);
     d = __builtin_fmaf(pos.z, pos.z, d);
     const float inv = -__builtin_amdgcn_rsqf(d);         // :97
     const float s = p.mass * (inv * inv * inv);          // :98-99
-    integrate_store(p, i, pos, pos.x * s, pos.y * s, pos.z * s);
+    integrate_store<STREAM>(p, i, pos, pos.x * s, pos.y * s, pos.z * s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -836,7 +860,10 @@ hipError_t launch_reduce_integrate(const StepArgs &a, uint32_t slots, hipStream_
 
 hipError_t launch_central_well(const StepArgs &a, hipStream_t st)
 {
-    hipLaunchKernelGGL(central_well_kernel, dim3((a.i_count + 255u) / 256u), dim3(256), 0, st, a);
+    // (the new positions of flow mode go write-through at system scope: never the streaming form there)
+    const bool stream = !a.flow_arrived && (uint64_t)a.i_count * 56u > (320ull << 20);
+    if (stream) hipLaunchKernelGGL(central_well_kernel<true>, dim3((a.i_count + 255u) / 256u), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(central_well_kernel<false>, dim3((a.i_count + 255u) / 256u), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

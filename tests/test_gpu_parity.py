@@ -316,6 +316,31 @@ def test_full_size_subset_and_invariants(oracle, n):
         assert np.isfinite(v5).all()
 
 
+def test_central_well_beyond_the_infinity_cache_takes_the_streaming_form_with_identical_results(oracle):
+    """From 6 Mi bodies on (56 B per body and step > 320 MiB: nothing of a step's state is still in the 256 MiB Infinity Cache when
+    the next one comes) the central-well launch is the NON-TEMPORAL form of the same kernel (+5 - 7 % of bandwidth there; inside the
+    cache the hint costs 12 %, so the reference's default 4 Mi bodies keep the plain form).  Same arithmetic: 8 Mi bodies, three steps,
+    against the oracle on all bodies -- and bit-identical to what the plain form gives for the same bodies inside a smaller state."""
+    n = 8 * 1024 * 1024
+    pos, vel = oracle.initial_state(n, seed=3)
+    sim = OracleSim(oracle, pos, vel, mode=MODE_CENTRAL_WELL)
+    for _ in range(3):
+        sim.simulate()
+    with mapn.Compute(n, force_mode=mapn.FORCE_CENTRAL_WELL, seed=3) as c:
+        np.testing.assert_array_equal(c.download_state()[0], pos)
+        draw(c, 3)
+        p, v = c.download_state()
+    assert errs(p[:, :3], sim.latest[0][:, :3], 700.0)[0] < 4e-6
+    assert errs(v, sim.latest[1], SPEED)[0] < 4e-5
+    # the plain form on the first 65 536 of the same bodies (a body's step depends on nothing but the body): bit for bit the same
+    m = 65536
+    with mapn.Compute(m, force_mode=mapn.FORCE_CENTRAL_WELL) as c:
+        c.upload_state(pos[:m], vel[:m])
+        draw(c, 3)
+        q, w = c.download_state()
+    np.testing.assert_array_equal(q, p[:m]); np.testing.assert_array_equal(w, v[:m])
+
+
 def test_maximum_size_4mi_bodies(oracle):
     """MAX_NUM_PARTICLES = 4 Mi (defines.h:45), the reference's default N: the shipped
     central-well step on all bodies (full comparison) and one all-pairs step (1.76e13 pairs)

@@ -823,7 +823,11 @@ def main():
             if st.launches == 0:
                 pass
             out["roofline"] = {"bound": "hbm", "achieved": HBM_BYTES_PER_BODY * n * a.steps / elapsed / 1e9, "peak": 8000.0,
-                               "unit": "GB/s", "frac": HBM_BYTES_PER_BODY * n * a.steps / elapsed / 8e12, "traffic": None}
+                               "unit": "GB/s", "frac": HBM_BYTES_PER_BODY * n * a.steps / elapsed / 8e12, "traffic": None,
+                               "reachable_GBps": 6290.0, "frac_of_reachable": HBM_BYTES_PER_BODY * n * a.steps / elapsed / 6.29e12,
+                               "note": ("central-well step, 56 B per body: `achieved` is wall-clock over the K steps; `peak` the 8.0 TB/s specification, `reachable_GBps` what a "
+                                        "float4 copy measures on this part (MI355X guide); up to ~4.5 Mi bodies a step's state is resident in the 256 MiB Infinity Cache (a cache "
+                                        "rate, not an HBM one); from 6 Mi bodies on the launch is the non-temporal form of the kernel")}
         if world == 1 and not a.no_cpu_baseline and a.mode == "all_pairs":
             out["cpu_baseline"] = cpu_baseline(n, a.seed, a.cpu_seconds)
         if saved_stdout_fd is not None:

@@ -88,7 +88,8 @@ struct mapn_ctx {
     bool shard_calibrated = false;            // MAPN_FLAG_XCD_CALIBRATE on a sharded context: the temporary unsharded calibration has been tried
     bool calibrating = false;                 // mapn_calibrate_sym_xcds: stamped launches record the per-wave timeline without MAPN_STAMP_DUMP
     std::string sym_note;                     // why AUTO runs the one-sided kernel instead (allocation failed, ...)
-    float4 *sym_arow = nullptr, *sym_brow = nullptr, *sym_brow1 = nullptr, *sym_acc = nullptr;
+    mapn::SymRow *sym_arow = nullptr, *sym_brow = nullptr, *sym_brow1 = nullptr;
+    float4 *sym_acc = nullptr;
     uint32_t *sym_tab = nullptr;              // device copy of sym_plan.tables
     size_t sym_scratch_bytes = 0;
     uint32_t sym_parts = 0, sym_waves = 0;

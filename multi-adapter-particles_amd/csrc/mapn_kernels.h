@@ -62,14 +62,19 @@ struct ForcePlan {
 enum { SYM_K2 = 8,                     // packed pairs of bodies i per lane
        SYM_BLOCK = 128 * SYM_K2,       // bodies per I-block (one wave)
        SYM_JPI = SYM_BLOCK / 64 };     // 64-body J-blocks per I-block
+// One element of a force row: x, y, z -- 12 bytes, packed like the velocities (round 4; until then a float4 whose .w was never
+// read: a quarter of the N^2/128 bytes a step writes and reads back were padding).
+struct SymRow { float x, y, z; };
+static_assert(sizeof(SymRow) == 12, "rows are packed");
+
 struct SymArgs {
     const float4 *pos_old;
     const float  *vel_old;
     float4       *pos_new;
     float        *vel_new;
-    float4       *arow;       // [blocks of the launch][parts][SYM_BLOCK]  force on the bodies of an I-block, one row per workgroup
-    float4       *brow;       // [n / 64][brows][64] reaction on the bodies of a J-block, one row per meeting (sharded: [n / 64][shard_nbl][64])
-    float4       *brow1;      // [blocks of the launch][parts][64] head rows: the last steps of a meeting that was cut between two workgroups
+    SymRow       *arow;       // [blocks of the launch][parts][SYM_BLOCK]  force on the bodies of an I-block, one row per workgroup
+    SymRow       *brow;       // [n / 64][brows][64] reaction on the bodies of a J-block, one row per meeting (sharded: [n / 64][shard_nbl][64])
+    SymRow       *brow1;      // [blocks of the launch][parts][64] head rows: the last steps of a meeting that was cut between two workgroups
     const float4 *acc_in;     // reduce launch: forces summed by the earlier windows of this step (null: none)
     float4       *acc_out;    // reduce launch: where this window's running sum goes (null: last window -- integrate)
     const uint32_t *tab;      // this window's tables: bounds[2][nwaves + 1], split[2][max_meetings] (SymPlanHost)
@@ -155,9 +160,9 @@ struct SymShardArgs {
     const float  *vel_old;
     float4       *pos_new;
     float        *vel_new;
-    const float4 *arow;                       // [nbl][parts][SYM_BLOCK]
-    const float4 *brow;                       // [n / 64][nbl][64]
-    const float4 *brow1;                      // [nbl][parts][64]
+    const SymRow *arow;                       // [nbl][parts][SYM_BLOCK]
+    const SymRow *brow;                       // [n / 64][nbl][64]
+    const SymRow *brow1;                      // [nbl][parts][64]
     const uint32_t *tab;                      // the (single) window's tables
     float4       *recv_peer[P2P_MAX_RANKS];   // rank q's receive region as mapped here: row [sender][body of q]
     uint32_t     *flags_peer[P2P_MAX_RANKS];  // rank q's flag array as mapped here

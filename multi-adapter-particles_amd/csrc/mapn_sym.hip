@@ -60,13 +60,14 @@ __device__ __forceinline__ float lane_next(float v, int addr)
 // keeping them dirty in this XCD's L2 until the end-of-kernel write-back only lengthens the launch's tail; wt != 0 stores
 // them write-through (sc1) as they are produced.
 typedef float f4r __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_row(float4 *dst, float x, float y, float z, uint32_t wt)
+typedef float f3r __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void store_row(SymRow *dst, float x, float y, float z, uint32_t wt)
 {
     if (wt) {
-        const f4r o = {x, y, z, 0.f};
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(o) : "memory");
+        const f3r o = {x, y, z};
+        asm volatile("global_store_dwordx3 %0, %1, off sc1" : : "v"(dst), "v"(o) : "memory");
     } else {
-        *dst = make_float4(x, y, z, 0.f);
+        *dst = SymRow{x, y, z};
     }
 }
 
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
         comb[w][2][e0] = b.az[k].x; comb[w][2][e1] = b.az[k].y;
     }
     __syncthreads();
-    float4 *row = p.arow + ((size_t)la * p.parts + s) * SYM_IB;
+    SymRow *row = p.arow + ((size_t)la * p.parts + s) * SYM_IB;
     for (uint32_t e = threadIdx.x; e < SYM_IB; e += 64u * WAVES) {
         float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
@@ -453,30 +454,30 @@ __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs
     const uint32_t a = i / SYM_IB, jb = i >> 6;
     float ax = 0.f, ay = 0.f, az = 0.f;
     if (p.acc_in) { const float4 v = p.acc_in[i]; ax = v.x; ay = v.y; az = v.z; }
-    const float4 *ar = p.arow + (size_t)a * p.parts * SYM_IB + (i - a * SYM_IB);
+    const SymRow *ar = p.arow + (size_t)a * p.parts * SYM_IB + (i - a * SYM_IB);
     uint32_t s = 0;
     for (; s + 8u <= p.parts; s += 8u) {                   // 8 loads in flight (one wave per SIMD: nothing else hides the latency), summed in ascending order
-        float4 v[8];
+        SymRow v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) v[u] = ar[(size_t)(s + u) * SYM_IB];
 #pragma unroll
         for (int u = 0; u < 8; u++) { ax += v[u].x; ay += v[u].y; az += v[u].z; }
     }
     for (; s < p.parts; s++) {
-        const float4 v = ar[(size_t)s * SYM_IB];
+        const SymRow v = ar[(size_t)s * SYM_IB];
         ax += v.x; ay += v.y; az += v.z;
     }
     // the symmetric groups of this window; group g's row exists when some block meets this one under g: always for
     // g <= D, for the half-ring group D + 1 only if this block's half-ring PARTNER runs the pair's meetings (sym_runs_half)
     const uint32_t D = (p.nb - 1u) / 2u, gs0 = p.g0 ? p.g0 : 1u;
     const uint32_t gend = (p.g1 == D + 2u && sym_runs_half(a, p.half_d)) ? D + 1u : p.g1;
-    const float4 *br = p.brow + (size_t)jb * p.brows * 64u + (i & 63u);
+    const SymRow *br = p.brow + (size_t)jb * p.brows * 64u + (i & 63u);
     // split table of the block that ran a meeting: set = class (+ 2 * (block mod 8) with XCD-weighted parts)
     const uint32_t *splits = p.tab + p.sets * (p.nwaves + 1u);
     auto split_of = [&](uint32_t blk) { return splits + (size_t)((sym_runs_half(blk, p.half_d) ? 0u : 1u) + (p.sets > 2u ? 2u * (blk & 7u) : 0u)) * p.max_meetings; };
     const uint32_t t = jb % SYM_JPI;
     for (uint32_t g = gs0; g < gend; g += 8u) {            // 8 meetings in flight, summed in ascending order
-        float4 v[8], h[8];
+        SymRow v[8], h[8];
         uint32_t sp[8], apv[8];
         // first ALL the table lookups of the batch, then all its row loads (the waits count in order)
 #pragma unroll
@@ -492,15 +493,15 @@ __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs
             // (no branch around a load: a lane without a row / without a head row re-reads a row that IS there and drops it --
             //  eight branches per batch serialised the loads: the launch took 18.7 instead of 13.9 us at 65 536 bodies)
             const bool live = g + u < gend;
-            const float4 *vsrc = br + (size_t)((live ? g + u : gs0) - gs0) * 64u;
-            const float4 *hsrc = sp[u] != 0xffffffffu ? p.brow1 + ((size_t)apv[u] * p.parts + sp[u]) * 64u + (i & 63u) : vsrc;
+            const SymRow *vsrc = br + (size_t)((live ? g + u : gs0) - gs0) * 64u;
+            const SymRow *hsrc = sp[u] != 0xffffffffu ? p.brow1 + ((size_t)apv[u] * p.parts + sp[u]) * 64u + (i & 63u) : vsrc;
             v[u] = *vsrc;
             h[u] = *hsrc;
         }
 #pragma unroll
         for (uint32_t u = 0; u < 8u; u++) {
-            if (!(g + u < gend)) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sp[u] == 0xffffffffu) h[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(g + u < gend)) v[u] = SymRow{0.f, 0.f, 0.f};
+            if (sp[u] == 0xffffffffu) h[u] = SymRow{0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (uint32_t u = 0; u < 8u; u++) {
@@ -580,10 +581,10 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         const uint32_t q = t / p.count, jl = t - q * p.count;
         if (!((p.send_mask >> q) & 1u)) continue;
         const uint32_t b = t / SYM_BLOCK, jb = t >> 6, tt = jb % SYM_JPI;     // t is the body's index in the whole job
-        const float4 *rows = p.brow + (size_t)jb * p.nbl * 64u + (t & 63u);
+        const SymRow *rows = p.brow + (size_t)jb * p.nbl * 64u + (t & 63u);
         float fx = 0.f, fy = 0.f, fz = 0.f;
         for (uint32_t la = 0; la < p.nbl; la += 8u) {      // eight meetings in flight, added in ascending block order
-            float4 v[8], h[8];
+            SymRow v[8], h[8];
             uint32_t gg[8], sp[8];
             // first ALL the table lookups of the batch, then all its row loads: the waits count in order, so a lookup issued
             // behind a row load would wait for that row too
@@ -598,16 +599,16 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
                 // no branch around a load (eight branches per batch serialise the loads):
                 // a lane without a row / without a head row re-reads a row that is there and drops it
                 const bool cut = gg[u] && sp[u] != 0xffffffffu;
-                const float4 *vsrc = rows + (size_t)(gg[u] ? la + u : 0u) * 64u;
-                const float4 *hsrc = cut ? p.brow1 + ((size_t)(la + u) * p.parts + sp[u]) * 64u + (t & 63u) : vsrc;
+                const SymRow *vsrc = rows + (size_t)(gg[u] ? la + u : 0u) * 64u;
+                const SymRow *hsrc = cut ? p.brow1 + ((size_t)(la + u) * p.parts + sp[u]) * 64u + (t & 63u) : vsrc;
                 v[u] = *vsrc;
                 h[u] = *hsrc;
             }
 #pragma unroll
             for (uint32_t u = 0; u < 8u; u++) {
                 const bool cut = gg[u] && sp[u] != 0xffffffffu;
-                if (!gg[u]) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!cut) h[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!gg[u]) v[u] = SymRow{0.f, 0.f, 0.f};
+                if (!cut) h[u] = SymRow{0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (uint32_t u = 0; u < 8u; u++) {
@@ -627,18 +628,18 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         ax = ay = az = 0.f;
         if (il >= p.count) return;
         const uint32_t la = il / SYM_BLOCK;
-        const float4 *ar = p.arow + (size_t)la * p.parts * SYM_BLOCK + (il - la * SYM_BLOCK);
+        const SymRow *ar = p.arow + (size_t)la * p.parts * SYM_BLOCK + (il - la * SYM_BLOCK);
         const uint32_t s0 = (uint32_t)(((uint64_t)p.parts * g) / G), s1 = (uint32_t)(((uint64_t)p.parts * (g + 1u)) / G);
         uint32_t s = s0;
         for (; s + 8u <= s1; s += 8u) {
-            float4 v[8];
+            SymRow v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) v[u] = ar[(size_t)(s + u) * SYM_BLOCK];
 #pragma unroll
             for (int u = 0; u < 8; u++) { ax += v[u].x; ay += v[u].y; az += v[u].z; }
         }
         for (; s < s1; s++) {
-            const float4 v = ar[(size_t)s * SYM_BLOCK];
+            const SymRow v = ar[(size_t)s * SYM_BLOCK];
             ax += v.x; ay += v.y; az += v.z;
         }
     };

@@ -18,7 +18,7 @@ void release_sym(mapn_ctx *c)
     if (c->sym_send) (void)hipFree(c->sym_send);
     if (c->sym_recv) (void)hipFree(c->sym_recv);
     c->sym_send = c->sym_recv = nullptr;
-    c->sym_arow = c->sym_brow = c->sym_brow1 = c->sym_acc = nullptr;
+    c->sym_arow = c->sym_brow = c->sym_brow1 = nullptr; c->sym_acc = nullptr;
     c->sym_tab = nullptr;
     c->sym_scratch_bytes = 0;
     c->sym_ready = false;
@@ -69,16 +69,16 @@ int prepare_sym(mapn_ctx *c, bool sharded)
     const uint32_t gsym = (nb - 1u) / 2u + ((nb & 1u) ? 0u : 1u);
     const char *e = getenv("MAPN_SYM_MAX_MB");
     const bool simulate_failure = test_hook("MAPN_SYM_FAIL_ALLOC") != nullptr;     // tests: behave as if hipMalloc had failed
-    // unsharded: 1 GiB of b-rows by default (1 048 576 bodies: 9 windows, 4 194 304 bodies: 129); sharded: one window, up to 16 GiB
+    // unsharded: 1 GiB of b-rows by default (12 B per body and group: 1 048 576 bodies 7 windows, 4 194 304 bodies 97); sharded: one window, up to 16 GiB
     const uint64_t cap = (e ? strtoull(e, nullptr, 10) : (sharded ? 16384ull : 1024ull)) << 20;
     uint32_t gpw = 0;                                                           // symmetric groups per window (0: all in one)
     if (sharded) {
-        if ((uint64_t)c->n * nbl * 16ull > cap) {
+        if ((uint64_t)c->n * nbl * sizeof(mapn::SymRow) > cap) {
             c->sym_note = "symmetric kernel (sharded): reaction rows exceed MAPN_SYM_MAX_MB";
             return must ? fail(MAPN_ERR_INVALID_ARGUMENT, "%s", c->sym_note.c_str()) : MAPN_OK;
         }
     } else {
-        const uint64_t per_group = (uint64_t)nb * mapn::SYM_BLOCK * 16ull;
+        const uint64_t per_group = (uint64_t)nb * mapn::SYM_BLOCK * sizeof(mapn::SymRow);
         const uint64_t fit = std::max<uint64_t>(1, cap / per_group);
         if (fit < gsym) gpw = (uint32_t)fit;
     }
@@ -155,9 +155,9 @@ int prepare_sym(mapn_ctx *c, bool sharded)
         return must ? fail(MAPN_ERR_INVALID_ARGUMENT, "%s", err.c_str()) : MAPN_OK;
     }
     const mapn::SymPlanHost &pl = c->sym_plan;
-    const size_t ab = (size_t)nbl * pl.parts * mapn::SYM_BLOCK * sizeof(float4);
-    const size_t bb = sharded ? (size_t)c->n * nbl * sizeof(float4) : (size_t)nb * mapn::SYM_BLOCK * pl.brows * sizeof(float4);
-    const size_t hb = (size_t)nbl * pl.parts * 64 * sizeof(float4);
+    const size_t ab = (size_t)nbl * pl.parts * mapn::SYM_BLOCK * sizeof(mapn::SymRow);
+    const size_t bb = sharded ? (size_t)c->n * nbl * sizeof(mapn::SymRow) : (size_t)nb * mapn::SYM_BLOCK * pl.brows * sizeof(mapn::SymRow);
+    const size_t hb = (size_t)nbl * pl.parts * 64 * sizeof(mapn::SymRow);
     const size_t cb = pl.windows.size() > 1 ? (size_t)nb * mapn::SYM_BLOCK * sizeof(float4) : 0;
     const size_t tb = pl.tables.size() * sizeof(uint32_t);
     hipError_t he = simulate_failure ? hipErrorOutOfMemory : hipSuccess;

@@ -363,7 +363,7 @@ def test_maximum_size_4mi_bodies(oracle):
         # 4 Mi bodies: the SYMMETRIC kernel, its step made in windows of partner distance so that the reaction rows stay
         # within MAPN_SYM_MAX_MB (1 GiB): O(N) scratch instead of N^2 / 128 bytes = 137 GB
         st, plan = c.kernel_stats(), c.sym_plan()
-        assert st.kernel_name.decode() == "force_sym_kernel" and st.force_launches_per_step == len(plan.windows) > 100
+        assert st.kernel_name.decode() == "force_sym_kernel" and st.force_launches_per_step == len(plan.windows) > 90
         assert plan.scratch_bytes < 2 * 1024 ** 3
         print(f"4 Mi bodies: {len(plan.windows)} windows, {plan.parts} parts, scratch {plan.scratch_bytes / 2**20:.0f} MiB")
     assert errs(p[first:first + 2048, :3], rp[:, :3], SPREAD)[0] < 1e-6

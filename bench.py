@@ -806,9 +806,9 @@ def main():
                                                                "which 12 are executed (`frac_executed`)") if sym else
                                                               "11 packed ops x 4 cycles + 2 v_rsq_f32 x 8 cycles per 128 pairs per SIMD = 66.7 % of peak at any clock",
                                    "traffic": traffic, "traffic_unit": "HBM bytes per force launch (2*FETCH_SIZE+WRITE_SIZE, PMC)",
-                                   "traffic_note": ("positions (16 N) read once per XCD L2 + the force rows written once: one 16 KiB row per workgroup for its 1024 bodies i and one "
-                                                    "1 KiB row per meeting for the 64 travelling bodies j (no float atomics: a fixed-order reduce launch adds them) -- "
-                                                    "N^2/128 + 16 N x parts bytes, ~0.13 TB/s, 1.6 % of the HBM roofline: the kernel is compute-bound") if sym else
+                                   "traffic_note": ("positions (16 N) read once per XCD L2 + the force rows written once, 12 bytes per body: one 12 KiB row per workgroup for its 1024 bodies i and one "
+                                                    "768 B row per meeting for the 64 travelling bodies j (no float atomics: a fixed-order reduce launch adds them) -- "
+                                                    "3 N^2/512 + 12 N x parts bytes, ~0.1 TB/s, 1.3 % of the HBM roofline: the kernel is compute-bound") if sym else
                                                    "positions read once per XCD L2 + the partial rows of the j-split written and read back once by the last-arriver epilogue",
                                    "traffic_source": traffic_src, "kernel_source_sha16": kernel_source_sha16(),
                                    "kernel": st.kernel_name.decode(), "launches_timed": int(st.launches),

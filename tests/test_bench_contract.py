@@ -128,7 +128,7 @@ def test_bench_reports_a_median_of_five_repeats_from_100_steps_on():
     rep = d["config"]["repeats"]
     assert len(rep["ms_per_step"]) == 5 and rep["meets_survey_8d"] is True and abs(rep["ms_per_step"][0] - d["ms_per_step"]) < 1e-4
     assert sorted(rep["ms_per_step"])[2] == rep["median_ms_per_step"] and 0.4 < rep["median_ms_per_step"] < 1.0
-    assert max(rep["ms_per_step"]) / min(rep["ms_per_step"]) < 1.08, rep      # one box, one clock state: the regions agree
+    assert max(rep["ms_per_step"]) / min(rep["ms_per_step"]) < 1.15, rep      # one box, one clock state: the regions agree (2 - 3 % typically)
 
 
 @pytest.mark.gpu

@@ -9,6 +9,7 @@ from identical seeded initial conditions, free-running, statistics after 1, 10, 
            sums, fma, mass after the sum) -- what is left against the device is v_rsq_f32 alone;
   matched_sym  the same for the SYMMETRIC kernel (the default one), restated from the launch plan the context
            runs (mapn_get_sym_plan): waves' step ranges, reaction chains, cut meetings, rows, windows;
+  matched_symw the same for the "device_weighted" leg: the symmetric kernel under an XCD-weighted (class-aware) plan;
   f64      the whole step in double on double state: the discrete map itself.
 
 Comparing device|ref|matched with acc64 / f64 attributes a device-vs-ref difference: if the device
@@ -40,7 +41,10 @@ def stats(a_pos, b_pos):
             "max_over_spread400": float(dx.max() / 400.0)}
 
 
-def run_report(n=65536, marks=(1, 10, 100, 1000), seed=1, with_f64=True, f64_max_steps=None, log=print):
+WEIGHTED_LEG_XCD_WEIGHTS = (1024, 900, 1000, 950, 1024, 880, 990, 1010)     # relative die speeds of the "device_weighted" leg (1024 = the fastest)
+
+
+def run_report(n=65536, marks=(1, 10, 100, 1000), seed=1, with_f64=True, f64_max_steps=None, log=print, weighted_leg=True):
     import mapn
     from oracle import Oracle, OracleSim, OracleSim64, Params, SumSpec, SUM_FP64_ACC, SUM_ORDER_MATCHED
 
@@ -53,9 +57,27 @@ def run_report(n=65536, marks=(1, 10, 100, 1000), seed=1, with_f64=True, f64_max
     sym_plan = None
     # two device legs: "device" = the default kernel (MAPN_KERNEL_AUTO: the symmetric kernel where it applies),
     # "device1s" = the one-sided scalar-cache kernel, whose summation order the `matched` oracle restates
-    for leg, kern in (("device", mapn.KERNEL_AUTO), ("device1s", mapn.KERNEL_SCALAR)):
+    # "device_weighted" = the symmetric kernel under an XCD-WEIGHTED plan (fixed, deliberately lopsided weights: class-aware where it
+    # applies) -- the KIND of plan bench.py's headline number runs (there the weights are the box's calibrated ones), through the same
+    # 100 / 1000 steps and the same statements as the default plan
+    legs = [("device", mapn.KERNEL_AUTO, None), ("device1s", mapn.KERNEL_SCALAR, None)]
+    if weighted_leg:
+        legs.append(("device_weighted", mapn.KERNEL_AUTO, list(WEIGHTED_LEG_XCD_WEIGHTS)))
+    symw_plan = None
+    for leg, kern, xcd_w in legs:
         with mapn.Compute(n, mass=70000.0 / n, seed=seed, kernel=kern) as c:
             assert np.array_equal(c.download_state()[0], pos)
+            if xcd_w is not None:
+                try:
+                    if c.sym_plan().nb % 8:
+                        continue                               # (XCD weights need a block count that is a multiple of 8)
+                except mapn.MapnError:
+                    continue                                   # (the symmetric kernel does not run at this size)
+                c.set_sym_xcd_weights(xcd_w)
+                symw_plan = c.sym_plan()
+                assert symw_plan.xcd_mode != 0 and symw_plan.xcd_weight == xcd_w
+                out["device_weighted_sym_plan"] = {"waves": symw_plan.waves, "parts": symw_plan.parts, "xcd_mode": symw_plan.xcd_mode,
+                                                   "xcd_weight": list(symw_plan.xcd_weight), "windows": len(symw_plan.windows)}
             done, t0 = 0, time.perf_counter()
             for m in marks:
                 for _ in range(m - done):
@@ -68,7 +90,7 @@ def run_report(n=65536, marks=(1, 10, 100, 1000), seed=1, with_f64=True, f64_max
                                   "bodies_per_lane": st.bodies_per_lane, "epilogue": st.epilogue}
             if leg == "device1s":
                 waves, sb = st.block_x // 64, st.grid_y
-            elif st.kernel_name.decode() == "force_sym_kernel":
+            elif st.kernel_name.decode() == "force_sym_kernel" and xcd_w is None:
                 sym_plan = c.sym_plan()
                 out["device_sym_plan"] = {"waves": sym_plan.waves, "parts": sym_plan.parts, "taper": [sym_plan.taper1, sym_plan.taper2],
                                           "windows": len(sym_plan.windows)}
@@ -80,6 +102,8 @@ def run_report(n=65536, marks=(1, 10, 100, 1000), seed=1, with_f64=True, f64_max
             "matched": OracleSim(o, pos, vel, params=prm, sum_spec=SumSpec(SUM_ORDER_MATCHED, waves, sb))}
     if sym_plan is not None:
         sims["matched_sym"] = OracleSim(o, pos, vel, params=prm, sym_plan=sym_plan)
+    if symw_plan is not None:
+        sims["matched_symw"] = OracleSim(o, pos, vel, params=prm, sym_plan=symw_plan)
     if with_f64:
         sims["f64"] = OracleSim64(o, pos, vel, params=prm)
     have = set()
@@ -99,8 +123,12 @@ def run_report(n=65536, marks=(1, 10, 100, 1000), seed=1, with_f64=True, f64_max
              ("device", "device1s"), ("ref", "acc64"), ("matched", "acc64")]
     if sym_plan is not None:
         pairs += [("device", "matched_sym"), ("matched_sym", "acc64")]
+    if symw_plan is not None:
+        pairs += [("device_weighted", "ref"), ("device_weighted", "acc64"), ("device_weighted", "matched_symw"), ("device_weighted", "device")]
     if with_f64:
         pairs += [("device", "f64"), ("device1s", "f64"), ("ref", "f64"), ("matched", "f64"), ("acc64", "f64")]
+        if symw_plan is not None:
+            pairs += [("device_weighted", "f64")]
     for m in marks:
         for a, b in pairs:
             if (b, m) not in have and not b.startswith("device"):

@@ -10,6 +10,7 @@ import pytest
 import mapn
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.timing     # subprocess benches and time windows: ordered behind every parity test (tests/conftest.py)
 
 
 def test_bench_fails_loudly_without_a_gpu():
@@ -142,9 +143,9 @@ def test_bench_two_ranks_on_two_real_gpus_when_the_box_has_them():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "5"],
                        capture_output=True, text=True, timeout=1200, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    if r.returncode != 0 or len(lines) != 1:
-        # the FIRST real execution of the cross-GPU path anywhere: reported (xfail, with what happened), not a gate that stops `pytest -x`
-        pytest.xfail("bench.py --gpus 2 on two real GPUs did not produce its line: " + (r.stdout[-1000:] + r.stderr[-3000:]))
+    # a broken hop is a RED test with bench's own words in the message (the file is ordered behind every parity test, so
+    # `pytest -x` hides nothing by stopping here)
+    assert r.returncode == 0 and len(lines) == 1, "bench.py --gpus 2 on two real GPUs did not produce its line: " + r.stdout[-1000:] + r.stderr[-3000:]
     d = json.loads(lines[0])
     print(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["valid"] is True and d["config"]["replicas_bit_identical_after_run"] is True

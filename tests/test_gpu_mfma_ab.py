@@ -28,6 +28,7 @@ import pytest
 import mapn
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.timing     # cycle-count windows of a microbenchmark: ordered behind every parity test (tests/conftest.py)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 MFMA_PAIR_VARIANTS = ("pair packed, accumulate on mfma 4x4x1", "pair packed, accumulate on mfma16x16x4",

@@ -471,6 +471,34 @@ def test_create_from_copies_state_and_continues_identically():
             np.testing.assert_array_equal(a.download_state()[0], b.download_state()[0])
 
 
+def test_create_from_across_two_devices_when_the_box_has_them():
+    """The adapter switch of Particles.cpp:511-522 -- `new Compute(n, otherAdapter, ext, old)` -> CopyState across adapters
+    (Compute.cpp:303-410): device 0 -> device 1 and back, both position buffers, both velocity buffers and the buffer index
+    bit-identical after every hop (incl. a frozen tail in BOTH buffers), and the migrated context continues exactly like
+    the source.  Needs two GPUs; a broken hop is a red test (VERDICT r4 #2), on one GPU it skips."""
+    if mapn.compute.device_count() < 2:
+        pytest.skip("one GPU on this box: the cross-device CopyState cannot run here")
+    n = 65536 + 64
+    with mapn.Compute(n, device=0, mass=70000.0 / n) as a:
+        draw(a, 2)
+        a.Simulate(n // 2, a.GetFenceValue())                  # a frozen tail: the two buffers now differ beyond n / 2
+        with mapn.Compute(n, device=1, mass=70000.0 / n, old=a) as b:
+            assert b.buffer_index == a.buffer_index
+            for i in (0, 1):
+                for x, y in zip(a.download_buffer(i), b.download_buffer(i)):
+                    np.testing.assert_array_equal(x, y)
+            draw(a, 3); draw(b, 3)
+            pa, va = a.download_state(); pb, vb = b.download_state()
+            np.testing.assert_array_equal(pa, pb); np.testing.assert_array_equal(va, vb)
+            with mapn.Compute(n, device=0, mass=70000.0 / n, old=b) as c:       # ... and back (the user switches adapters again)
+                assert c.buffer_index == b.buffer_index
+                for i in (0, 1):
+                    for x, y in zip(b.download_buffer(i), c.download_buffer(i)):
+                        np.testing.assert_array_equal(x, y)
+                draw(b, 2); draw(c, 2)
+                np.testing.assert_array_equal(b.download_state()[0], c.download_state()[0])
+
+
 def test_consumer_fence_protocol():
     """Compute.cpp:1012: Simulate(n, v) may not overwrite a buffer before the consumer signalled
     v-1.  Like the reference it QUEUES the GPU-side wait whether or not the consumer has signalled

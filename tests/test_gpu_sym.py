@@ -286,6 +286,7 @@ def test_xcd_calibration_at_creation_gives_the_weighted_plan_and_leaves_the_stat
         draw(c, 1)
 
 
+@pytest.mark.timing
 def test_xcd_calibration_at_creation_keeps_the_weighted_plan_only_if_it_wins_its_a_b(oracle):
     """The calibration reads lone stamped launches and can catch a transient (a die read 6 - 13 % slow: such weights cost 2 - 4 % per
     step), so mapn_create VERIFIES: plain steps under the weighted and under the default plan, interleaved, best of two each; the

@@ -9,8 +9,11 @@ double on double state).  Statements asserted, all on ||dx_i|| / ||x_i|| over th
 
   T1  device vs ref after 1000 steps: median <= 1e-5, RMS <= 5e-5, >= 99.9 % of the bodies within
       1e-4.  The MAXIMUM over bodies is NOT within 1e-4 (a handful of bodies that passed close to
-      another one amplify a 1-ulp difference: SURVEY F4's chaos): bounded at 1e-3 (measured 4.1e-4 .. 4.2e-4), and at
-      most 12 bodies lie beyond 1e-4 (measured 7 .. 9).
+      another one amplify a 1-ulp difference: SURVEY F4's chaos).  What bounds it is measured IN THE SAME RUN, not a constant
+      tuned to earlier observations: the reference-order oracle against its own double-accumulated twin --
+      n_over_1e-4(device, ref) <= n_over_1e-4(ref, acc64) + 4 and max(device, ref) <= 1.5 x max(ref, acc64): the bodies beyond
+      1e-4 are the ones `ref`'s single fp32 running sum over 65 536 terms puts there (rounds 2 - 4 measured: device vs ref
+      7 .. 11 bodies, max 4.1e-4 .. 4.2e-4; ref vs acc64 9 bodies, max 4.3e-4).
   T2  device vs ref after 100 steps: max <= 2e-6 (every body far inside 1e-4).
   T3  attribution: the device is no farther from either yardstick than the reference-order oracle is --
       err(device, acc64) <= 1.5 x err(ref, acc64) for median, RMS AND max at 100 and 1000 steps, and
@@ -20,10 +23,12 @@ double on double state).  Statements asserted, all on ||dx_i|| / ||x_i|| over th
       over 65 536 terms), amplified by the dynamics -- not a kernel defect.  Measured: device vs acc64
       after 1000 steps max 9.7e-5 (NO body beyond 1e-4), ref vs acc64 max 4.3e-4 (9 bodies beyond).
   T4  each device kernel vs ITS order-matched oracle (only v_rsq_f32 differs): "device1s" vs `matched`, "device" (the symmetric
-      kernel) vs `matched_sym` -- tighter than T1/T2 by the bounds written below.
+      kernel) vs `matched_sym`, "device_weighted" vs `matched_symw` -- tighter than T1/T2 by the bounds written below.
 
 T1-T3 are asserted for BOTH device kernels: "device" = MAPN_KERNEL_AUTO (the symmetric kernel at this size,
-csrc/mapn_sym.hip) and "device1s" = the one-sided scalar-cache kernel whose summation order `matched` restates.
+csrc/mapn_sym.hip) and "device1s" = the one-sided scalar-cache kernel whose summation order `matched` restates -- and for
+"device_weighted": the symmetric kernel under an XCD-WEIGHTED launch plan (fixed lopsided die weights, class-aware), the kind of
+plan bench.py's headline number runs (until round 4 only the unweighted plan went through the long legs).
 
 The oracle legs take ~4 minutes on the GPU box's host cores (ref 42 s, matched 37 s, acc64 122 s, f64 to 100 steps 43 s).
 """
@@ -54,20 +59,26 @@ def _row(rep, steps, a, b):
     return row(rep, steps, a, b)
 
 
-@pytest.mark.parametrize("leg", ["device", "device1s"])
+LEGS = ["device", "device1s", "device_weighted"]     # default plan (symmetric kernel), one-sided kernel, symmetric kernel under an XCD-weighted plan
+
+
+@pytest.mark.parametrize("leg", LEGS)
 def test_t1_device_vs_reference_order_oracle_after_1000_steps(report, leg):
     """leg "device" = the default kernel (the symmetric one at this size), "device1s" = the one-sided one."""
     r = _row(report, 1000, leg, "ref")
-    print(leg, "vs ref @1000:", r, report[leg + "_plan"])
+    print(leg, "vs ref @1000:", r, report[leg + "_plan"], report.get(leg + "_sym_plan"))
     assert r["median"] <= 1e-5
     assert r["rms"] <= 5e-5
     assert r["frac_within_1e-4"] >= 0.999
-    assert r["max"] <= 1e-3            # NOT <= 1e-4: see the module docstring and BASELINE.md section 4 (measured 4.2e-4)
-    assert r["n_over_1e-4"] <= 12      # measured 7 (symmetric kernel) and 9 (one-sided)
+    # NOT max <= 1e-4: see the module docstring and BASELINE.md section 4.  The yardstick is the oracle's OWN summation error, same run:
+    own = _row(report, 1000, "ref", "acc64")
+    print("ref vs acc64 @1000:", own)
+    assert r["n_over_1e-4"] <= own["n_over_1e-4"] + 4, (r, own)
+    assert r["max"] <= 1.5 * own["max"], (r, own)
     assert report[leg + "_momentum_drift_rel"] < 1e-7
 
 
-@pytest.mark.parametrize("leg", ["device", "device1s"])
+@pytest.mark.parametrize("leg", LEGS)
 def test_t2_device_vs_reference_order_oracle_after_100_steps(report, leg):
     for steps, bound in ((1, 5e-7), (10, 5e-7), (100, 2e-6)):
         r = _row(report, steps, leg, "ref")
@@ -75,7 +86,7 @@ def test_t2_device_vs_reference_order_oracle_after_100_steps(report, leg):
         assert r["frac_within_1e-4"] == 1.0
 
 
-@pytest.mark.parametrize("leg", ["device", "device1s"])
+@pytest.mark.parametrize("leg", LEGS)
 @pytest.mark.parametrize("yardstick", ["acc64", "f64"])
 def test_t3_device_is_no_farther_from_the_yardsticks_than_the_oracle_is(report, yardstick, leg):
     for steps in ((100, 1000) if yardstick == "acc64" else (100,)):     # the double leg stops at 100 steps (cost)
@@ -89,10 +100,10 @@ def test_t3_device_is_no_farther_from_the_yardsticks_than_the_oracle_is(report, 
             # reference-order oracle vs its own double-accumulated twin: the 4.2e-4 of T1 is the ORACLE's summation error
             assert dev["max"] <= 1.5 * ref["max"], (steps, dev, ref)
             if steps == 1000:
-                assert dev["max"] <= 3e-4 and dev["n_over_1e-4"] <= 3, dev
+                assert dev["n_over_1e-4"] <= ref["n_over_1e-4"], (dev, ref)     # (measured rounds 2 - 4: 0 against 9)
 
 
-@pytest.mark.parametrize("leg,yardstick", [("device1s", "matched"), ("device", "matched_sym")])
+@pytest.mark.parametrize("leg,yardstick", [("device1s", "matched"), ("device", "matched_sym"), ("device_weighted", "matched_symw")])
 def test_t4_device_vs_order_matched_oracle_differs_by_rsq_only(report, leg, yardstick):
     r1, r100, r1000 = (_row(report, s, leg, yardstick) for s in (1, 100, 1000))
     print(leg, "vs", yardstick, ":", r1, r100, r1000, report.get("device_sym_plan"))

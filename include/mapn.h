@@ -399,7 +399,9 @@ typedef struct mapn_kernel_stats {
                                     2 last-arriver ticket (rows summed by the last workgroup of the i-tile),
                                     3 the symmetric kernel's rows + sym_reduce_integrate launch */
     uint32_t force_launches_per_step;
-    uint32_t reserved;
+    uint32_t split_active;       /* != 0: the step enqueued last was a PARTIALLY ACTIVE one in its split form -- these many bodies met each other under
+                                    the symmetric kernel (a plan of the active blocks alone), the frozen ones acted on them through one one-sided
+                                    launch in front (kernel_name "force_sym_kernel", grid of the symmetric launch) */
 } mapn_kernel_stats;
 int mapn_get_kernel_stats(mapn_ctx *ctx, int reset, mapn_kernel_stats *out);
 /* The individual samples behind those means: for every step since the last reset that carried timer events (every T-th,
@@ -479,6 +481,24 @@ int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, uint32_t par
 int mapn_get_sym_plan(mapn_ctx *ctx, mapn_sym_plan_info *info, uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity);
 int mapn_set_sym_plan(mapn_ctx *ctx, uint32_t waves, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t groups_per_window,
                       uint32_t wave_bias_hi, uint32_t wave_bias_lo);
+/*
+ * The plan of a PARTIALLY ACTIVE step in its split form (mapn_kernel_stats.split_active != 0): the `active` = roundup64(num_active)
+ * bodies meet each other under the symmetric kernel with the plan returned in info / windows / tables (a job of `active` bodies: nb =
+ * ceil(active / 1024) blocks, the default shape for that size, the context's XCD weights where they apply), and the `frozen` bodies
+ * [active, N) act on them through ONE launch of the one-sided kernel in front whose partial rows the first window's reduce launch
+ * adds before its own.  What an order-matched checker must reproduce: per active body first the frozen rows -- the j-range
+ * [active, N) cut and summed exactly as mapn_set_force_plan describes for (frozen_waves, frozen_sb), rows added in ascending order to
+ * zero -- then the symmetric plan's order over the bodies [0, active) as for mapn_get_sym_plan; the mass multiplies the total.
+ * MAPN_ERR_STATE until such a step has run.  Same two-call pattern and capacity checks as mapn_get_sym_plan.
+ */
+typedef struct mapn_split_info {
+    uint32_t active, frozen;
+    uint32_t frozen_kernel;          /* mapn_kernel of the launch over the frozen bodies (MAPN_KERNEL_SCALAR / MAPN_KERNEL_LDS) */
+    uint32_t frozen_bodies_per_lane, frozen_waves, frozen_sb;
+    uint32_t reserved[2];
+} mapn_split_info;
+int mapn_get_split_plan(mapn_ctx *ctx, mapn_split_info *split, mapn_sym_plan_info *info, uint32_t *windows, uint64_t windows_capacity,
+                        uint32_t *tables, uint64_t tables_capacity);
 /*
  * XCD-aware parts.  The eight XCDs of an MI355X do not run at one speed under this kernel (measured 0.538 - 0.570 us per
  * step, the same dies slow on every launch of a box) while a launch gives every die the same work, so it ends with the

@@ -67,7 +67,7 @@ class KernelStats(C.Structure):
         ("kernel_name", C.c_char * 64), ("launches", C.c_uint64), ("avg_seconds", C.c_double),
         ("grid_x", C.c_uint32), ("grid_y", C.c_uint32), ("block_x", C.c_uint32),
         ("bodies_per_lane", C.c_uint32), ("j_splits", C.c_uint32), ("fused", C.c_uint32),
-        ("grid_z", C.c_uint32), ("epilogue", C.c_uint32), ("force_launches_per_step", C.c_uint32), ("reserved", C.c_uint32),
+        ("grid_z", C.c_uint32), ("epilogue", C.c_uint32), ("force_launches_per_step", C.c_uint32), ("split_active", C.c_uint32),
     ]
 
 
@@ -81,6 +81,11 @@ class SymPlanInfo(C.Structure):
         ("a0", C.c_uint32), ("nbl", C.c_uint32), ("active_compute_units", C.c_uint32), ("exchange_workgroups", C.c_uint32),
         ("scratch_bytes", C.c_uint64), ("error", C.c_char * 256),
     ]
+
+
+class SplitInfo(C.Structure):
+    _fields_ = [("active", C.c_uint32), ("frozen", C.c_uint32), ("frozen_kernel", C.c_uint32), ("frozen_bodies_per_lane", C.c_uint32),
+                ("frozen_waves", C.c_uint32), ("frozen_sb", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
 # every symbol include/mapn.h declares: (name, restype, argtypes)
@@ -147,6 +152,7 @@ SIGNATURES = {
     "mapn_sym_plan_describe": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32 * 8), C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.POINTER(SymPlanInfo), C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32), C.c_uint64]),
     "mapn_get_sym_plan": (C.c_int, [_ctx, C.POINTER(SymPlanInfo), C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32), C.c_uint64]),
+    "mapn_get_split_plan": (C.c_int, [_ctx, C.POINTER(SplitInfo), C.POINTER(SymPlanInfo), C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32), C.c_uint64]),
     "mapn_set_sym_plan": (C.c_int, [_ctx, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "mapn_measure_clock": (C.c_int, [_ctx, C.c_int, C.POINTER(ClockInfo)]),
     "mapn_set_timers": (C.c_int, [_ctx, C.c_int]),

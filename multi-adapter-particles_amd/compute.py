@@ -279,6 +279,18 @@ class Compute:
         check(self._lib.mapn_get_sym_plan(self._ctx, C.byref(info), win.ctypes.data_as(u32p), win.size, tab.ctypes.data_as(u32p), tab.size))
         return SymPlan(info, win, tab)
 
+    def split_plan(self):
+        """(split, plan) of the latest PARTIALLY ACTIVE step in its split form: `split` names the active / frozen counts and the shape
+        of the one-sided launch over the frozen bodies, `plan` is the symmetric plan of the active bodies (raises MapnError before
+        such a step has run)."""
+        info, split = _lib.SymPlanInfo(), _lib.SplitInfo()
+        check(self._lib.mapn_get_split_plan(self._ctx, C.byref(split), C.byref(info), None, 0, None, 0))
+        win = np.zeros((info.windows, 4), np.uint32)
+        tab = np.zeros(info.windows * info.table_stride + info.wgmap_entries, np.uint32)
+        u32p = C.POINTER(C.c_uint32)
+        check(self._lib.mapn_get_split_plan(self._ctx, C.byref(split), C.byref(info), win.ctypes.data_as(u32p), win.size, tab.ctypes.data_as(u32p), tab.size))
+        return split, SymPlan(info, win, tab)
+
     def set_shard_overlap(self, enabled: bool):
         check(self._lib.mapn_set_shard_overlap(self._ctx, int(bool(enabled))))
 

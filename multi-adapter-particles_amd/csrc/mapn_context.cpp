@@ -301,6 +301,17 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
     if (c->push_pending && !(i_count > 0 && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS && sym_shard_eligible(c, active) && c->gather_algo == 5))
         if (int rc = settle_push(c)) return rc;            // this step's launch does not wait for the peers' pushes itself
 
+    // an unsharded all-pairs step: full symmetric, split (active x active symmetric + active x frozen one-sided) or one-sided
+    StepForm form = FORM_ONE_SIDED;
+    if (i_count > 0 && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS && !flow) {
+        form = sym_step_form(c, active);
+        if (form == FORM_SYM_SPLIT) {
+            if (int rc = prepare_sym_active(c, active)) return rc;    // (the first step with this num_active makes the plan; afterwards a no-op)
+            if (c->act.active != active) form = sym_step_form(c, active);   // it could not be made (act_failed): the chooser now names another form
+        }
+    }
+    c->last_split_active = 0;
+
     if (timer) HIP_TRY(hipEventRecord(timer->start, c->compute));
 
     if (i_count > 0 && c->cfg.force_mode == MAPN_FORCE_CENTRAL_WELL) {
@@ -311,8 +322,10 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
     } else if (i_count == 0 && flow) {
         // nothing of this rank's slice advances in this step: it still owes its peers the flag
         HIP_TRY(mapn::launch_flow_publish(c->p2p_flag_table, a.flow_rank, a.flow_world, a.flow_publish, c->compute));
-    } else if (i_count > 0 && sym_eligible(c, active)) {
+    } else if (i_count > 0 && form == FORM_SYM_FULL) {
         if (int rc = enqueue_sym(c, a, timer)) return rc;
+    } else if (i_count > 0 && form == FORM_SYM_SPLIT) {
+        if (int rc = enqueue_sym_split(c, a, timer)) return rc;
     } else if (i_count > 0 && sym_shard_eligible(c, active)) {
         if (int rc = c->gather_algo == 6 ? enqueue_sym_shard_rccl(c, a, timer) : enqueue_sym_shard(c, a, timer)) return rc;
     } else if (i_count > 0 && !overlap) {
@@ -408,10 +421,17 @@ int enqueue_step_graph(mapn_ctx *c, uint32_t active)
     if (!c->graph_exec[w] || c->graph_active[w] != (int)active) {
         if (c->graph_exec[w]) { (void)hipGraphExecDestroy(c->graph_exec[w]); c->graph_exec[w] = nullptr; }
         const uint32_t lo = c->first, hi = std::min(c->first + c->count, active);
-        if (hi > lo && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS && !sym_eligible(c, active)) {
-            mapn::ForcePlan plan = choose_plan(c, hi - lo, c->n, 1, true);
-            if (plan.epi != mapn::EPI_FUSED)
-                if (int rc = ensure_partial(c, plan.sb, ((hi - lo) + 63u) & ~63u)) return rc;
+        if (hi > lo && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS) {
+            StepForm form = sym_step_form(c, active);
+            if (form == FORM_SYM_SPLIT) {                   // its plan and scratch, outside the capture
+                if (int rc = prepare_sym_active(c, active)) return rc;
+                form = sym_step_form(c, active);
+            }
+            if (form == FORM_ONE_SIDED) {
+                mapn::ForcePlan plan = choose_plan(c, hi - lo, c->n, 1, true);
+                if (plan.epi != mapn::EPI_FUSED)
+                    if (int rc = ensure_partial(c, plan.sb, ((hi - lo) + 63u) & ~63u)) return rc;
+            }
         }
         hipGraph_t graph = nullptr;
         HIP_TRY(hipStreamBeginCapture(c->compute, hipStreamCaptureModeThreadLocal));
@@ -649,6 +669,7 @@ int mapn_destroy(mapn_ctx *c)
     if (c->timeline_buf) (void)hipFree(c->timeline_buf);
     if (c->xtimeline_buf) (void)hipFree(c->xtimeline_buf);
     release_sym(c);
+    release_sym_active(c);
     for (int k = 0; k < kTimerRing; k++) {
         if (c->fence_events[k]) (void)hipEventDestroy(c->fence_events[k]);
         if (c->timers[k].start) (void)hipEventDestroy(c->timers[k].start);
@@ -977,6 +998,7 @@ int mapn_get_kernel_stats(mapn_ctx *c, int reset, mapn_kernel_stats *out)
         out->force_launches_per_step = std::max(1u, c->last_launches / 2u);   // every force launch (one per window of partner distance) is followed by a reduce launch (fused = 0); sharded: by the exchange launch
         out->grid_x = (i_count + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK; out->grid_y = p.sb; out->j_splits = p.sb * p.waves; out->fused = 0; out->epilogue = 3;   // grid (I-blocks, parts)
     }
+    out->split_active = c->last_split_active;
     if (reset) { c->force_launches = 0; c->force_seconds_sum = 0.0; c->steps_since_reset = 0; c->samples.clear(); }
     return MAPN_OK;
 }

@@ -93,6 +93,20 @@ struct mapn_ctx {
     uint32_t *sym_tab = nullptr;              // device copy of sym_plan.tables
     size_t sym_scratch_bytes = 0;
     uint32_t sym_parts = 0, sym_waves = 0;
+    // A PARTIALLY ACTIVE step (num_active < N: Particles.cpp:391-394's slider, Compute.cpp:1041): the active bodies [0, A) meet each
+    // other under the symmetric kernel with a plan of THEIR blocks, the frozen bodies [A, N) act on them through the one-sided kernel
+    // (enqueue_sym_split).  The plan and its scratch are made by the first step with a new A (and kept: capacity only grows), not per step.
+    struct SymActive {
+        uint32_t active = 0;                  // the A this set was prepared for (0: none)
+        mapn::SymPlanHost plan;
+        mapn::SymRow *arow = nullptr, *brow = nullptr, *brow1 = nullptr;
+        float4 *acc = nullptr;
+        uint32_t *tab = nullptr;
+        size_t cap_arow = 0, cap_brow = 0, cap_brow1 = 0, cap_acc = 0, cap_tab = 0;   // bytes allocated
+        mapn::ForcePlan frozen{};             // the one-sided launch over the frozen j-segment (EPI_ROWS)
+    } act;
+    uint32_t act_failed = 0;                  // the split form could not be prepared for this many active bodies (plan / memory): not tried again
+    uint32_t last_split_active = 0;           // the step enqueued last ran the split form for this many active bodies (0: it did not)
     bool p2p_shared_device = false;          // a peer rank runs on THIS GPU (several processes on one device: tests)
     uint32_t p2p_ranks_on_device = 1;        // ranks of the job that run on this GPU, this one included
     uint32_t sym_exchange_cap = 0;            // workgroups of sym_shard_exchange_kernel the device holds at once
@@ -201,6 +215,11 @@ int timeline_prepare(mapn_ctx *c, size_t nw, mapn::SymArgs &a);
 int stamps_prepare(mapn_ctx *c, size_t nw, mapn::SymArgs &a);
 mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t window);
 int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer);
+enum StepForm { FORM_ONE_SIDED = 0, FORM_SYM_FULL = 1, FORM_SYM_SPLIT = 2 };
+StepForm sym_step_form(const mapn_ctx *c, uint32_t active);   // which of the three forms an unsharded all-pairs step of `active` bodies runs
+int prepare_sym_active(mapn_ctx *c, uint32_t active);         // plan + scratch of the split form (no-op when already made for this A)
+void release_sym_active(mapn_ctx *c);
+int enqueue_sym_split(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer);
 bool sym_shard_eligible(const mapn_ctx *c, uint32_t active);
 bool sym_push_check();
 int settle_push(mapn_ctx *c);

@@ -77,6 +77,8 @@ struct SymArgs {
     SymRow       *brow1;      // [blocks of the launch][parts][64] head rows: the last steps of a meeting that was cut between two workgroups
     const float4 *acc_in;     // reduce launch: forces summed by the earlier windows of this step (null: none)
     float4       *acc_out;    // reduce launch: where this window's running sum goes (null: last window -- integrate)
+    const float4 *extra;      // reduce launch of a PARTIALLY ACTIVE step's first window: [extra_rows][extra_stride] partial force rows of the one-sided
+    uint32_t      extra_rows, extra_stride;   // launch over the frozen bodies (force_*_kernel, EPI_ROWS), added in ascending row order before this launch's own rows (null: none)
     const uint32_t *tab;      // this window's tables: bounds[2][nwaves + 1], split[2][max_meetings] (SymPlanHost)
     uint32_t      n, nb;      // bodies, I-blocks of SYM_BLOCK (the last may be padded)
     uint32_t      n_integrate;// bodies [0, n_integrate) are advanced by the reduce launch (roundup64(num_active)); the rest only exert force

@@ -443,7 +443,7 @@ __device__ __forceinline__ uint32_t sym_group(uint32_t a, uint32_t b, uint32_t n
 }
 }  // namespace
 
-// One thread per body: what the earlier windows of this step summed (if any), the rows of its I-block (role i) in
+// One thread per body: what the earlier windows of this step summed (if any), the frozen bodies' rows (a partially active step's first window), the rows of its I-block (role i) in
 // ascending part order, then the rows of its J-block (role j) in ascending group order -- a meeting's row, then its
 // head row when the meeting was cut between two workgroups -- and, in the step's last window, mass, kick, damp,
 // drift (hlsl:103-108).
@@ -454,6 +454,23 @@ __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs
     const uint32_t a = i / SYM_IB, jb = i >> 6;
     float ax = 0.f, ay = 0.f, az = 0.f;
     if (p.acc_in) { const float4 v = p.acc_in[i]; ax = v.x; ay = v.y; az = v.z; }
+    if (p.extra) {
+        // a partially active step: what the FROZEN bodies do to this one -- the partial rows of the one-sided launch in front of
+        // this step's symmetric launches, in ascending row order (eight loads in flight)
+        const float4 *xr = p.extra + i;
+        uint32_t s = 0;
+        for (; s + 8u <= p.extra_rows; s += 8u) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = xr[(size_t)(s + u) * p.extra_stride];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { ax += v[u].x; ay += v[u].y; az += v[u].z; }
+        }
+        for (; s < p.extra_rows; s++) {
+            const float4 v = xr[(size_t)s * p.extra_stride];
+            ax += v.x; ay += v.y; az += v.z;
+        }
+    }
     const SymRow *ar = p.arow + (size_t)a * p.parts * SYM_IB + (i - a * SYM_IB);
     uint32_t s = 0;
     for (; s + 8u <= p.parts; s += 8u) {                   // 8 loads in flight (one wave per SIMD: nothing else hides the latency), summed in ascending order

@@ -53,35 +53,16 @@ bool sym_applies(const mapn_ctx *c, bool sharded)
     return c->cfg.world_size == 1 && c->n >= mapn::SYM_BLOCK;   // (a smaller job does not fill one block: one-sided)
 }
 
-// Build the launch plan and allocate ALL of the symmetric step's scratch: a-rows [blocks][parts][1024], b-rows
-// (unsharded: [N/64][groups of the widest window][64], bounded by MAPN_SYM_MAX_MB -- a step is made in as many windows
-// of partner distance as that takes, so the scratch is O(N); sharded: [N/64][blocks of this rank][64]), head rows,
-// the running sum between windows, the plan tables.  Returns MAPN_OK with sym_ready false (and the reason in sym_note)
-// when the kernel does not apply or -- MAPN_KERNEL_AUTO only -- the memory is not to be had: the one-sided kernel
-// then runs every step.  An explicit MAPN_KERNEL_SYMMETRIC / mapn_set_sym_plan that cannot be honoured is an error.
-int prepare_sym(mapn_ctx *c, bool sharded)
+namespace {
+struct Shape { uint32_t parts, t1, t2, waves, hi, lo; };
+
+// The launch shapes prepare_sym tries, in order, for a job of nb blocks (nbl of them in one launch; gsym symmetric groups; gpw: groups
+// per window, may be narrowed by a hook / the user's plan).  tunable: honour mapn_set_sym_plan and the MAPN_SYM_* hooks (the
+// context's own plan); false: the default shapes only (the plan of the ACTIVE bodies of a partially active step).
+std::vector<Shape> candidate_shapes(const mapn_ctx *c, bool sharded, uint32_t nb, uint32_t nbl, uint32_t gsym, uint32_t &gpw, bool tunable)
 {
-    release_sym(c);
-    c->sym_note.clear();
-    if (!sym_applies(c, sharded)) return MAPN_OK;
-    const bool must = c->cfg.kernel == MAPN_KERNEL_SYMMETRIC || c->sym_user_plan;
-    const uint32_t nb = (c->n + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK, nbl = sharded ? c->count / mapn::SYM_BLOCK : nb;
-    const uint32_t gsym = (nb - 1u) / 2u + ((nb & 1u) ? 0u : 1u);
-    const char *e = getenv("MAPN_SYM_MAX_MB");
-    const bool simulate_failure = test_hook("MAPN_SYM_FAIL_ALLOC") != nullptr;     // tests: behave as if hipMalloc had failed
-    // unsharded: 1 GiB of b-rows by default (12 B per body and group: 1 048 576 bodies 7 windows, 4 194 304 bodies 97); sharded: one window, up to 16 GiB
-    const uint64_t cap = (e ? strtoull(e, nullptr, 10) : (sharded ? 16384ull : 1024ull)) << 20;
-    uint32_t gpw = 0;                                                           // symmetric groups per window (0: all in one)
-    if (sharded) {
-        if ((uint64_t)c->n * nbl * sizeof(mapn::SymRow) > cap) {
-            c->sym_note = "symmetric kernel (sharded): reaction rows exceed MAPN_SYM_MAX_MB";
-            return must ? fail(MAPN_ERR_INVALID_ARGUMENT, "%s", c->sym_note.c_str()) : MAPN_OK;
-        }
-    } else {
-        const uint64_t per_group = (uint64_t)nb * mapn::SYM_BLOCK * sizeof(mapn::SymRow);
-        const uint64_t fit = std::max<uint64_t>(1, cap / per_group);
-        if (fit < gsym) gpw = (uint32_t)fit;
-    }
+    auto hook = [&](const char *name) -> const char * { return tunable ? test_hook(name) : nullptr; };
+    const bool user_plan = tunable && c->sym_user_plan;
     // shape: 4-wave workgroups (2 waves per SIMD are resident: 248 VGPRs).  Unsharded: about 8192 workgroups per launch
     // but at most 32 per I-block (65 536 bodies: parts 24 / 32 / 48 / 64 -> 0.663 / 0.647 / 0.669 / 0.675 ms; 262 144: 8 / 32 /
     // 64 / 128 -> 9.95 / 9.60 / 9.60 / 9.89 ms; 1 048 576: 2 / 8 / 32 / 64 equal within 1 %); few rounds of workgroups
@@ -92,19 +73,18 @@ int prepare_sym(mapn_ctx *c, bool sharded)
     // older wave of every SIMD, which the SIMD issues first -- carry 3 (2) times the steps of the last four, so that the two
     // waves of a SIMD finish together (build_sym_plan; rank 0 of 65 536 / 8: force launch 83.7 against 87.9 us).
     uint32_t waves = 4, parts = sharded ? std::max(32u, (512u + nbl - 1u) / nbl) : std::min(32u, std::max(1u, (8192u + nb - 1u) / nb));
-    struct Shape { uint32_t parts, t1, t2, waves, hi, lo; };
     std::vector<Shape> tries;
     {
         unsigned ew = 0, ep = 0, tp = 0, t1 = 0, t2 = 0, eg = 0, bh = 1, bl = 1;
-        const char *pl = test_hook(sharded ? "MAPN_SYM_SHARD_PLAN" : "MAPN_SYM_PLAN");     // "waves,parts" tuning override
+        const char *pl = hook(sharded ? "MAPN_SYM_SHARD_PLAN" : "MAPN_SYM_PLAN");     // "waves,parts" tuning override
         if (pl && sscanf(pl, "%u,%u", &ew, &ep) == 2 && (ew == 4 || ew == 8) && ep >= 1) { waves = ew; parts = ep; }
-        const char *wb = test_hook(sharded ? "MAPN_SYM_SHARD_WAVE_BIAS" : "MAPN_SYM_WAVE_BIAS");   // "hi,lo": first half : second half of a workgroup's waves
+        const char *wb = hook(sharded ? "MAPN_SYM_SHARD_WAVE_BIAS" : "MAPN_SYM_WAVE_BIAS");   // "hi,lo": first half : second half of a workgroup's waves
         const bool bias_env = wb && sscanf(wb, "%u,%u", &bh, &bl) == 2 && bh >= 1 && bl >= 1;
         if (!bias_env) bh = bl = 1;
-        const char *tw = test_hook("MAPN_SYM_WINDOW");                                    // groups per window (unsharded)
+        const char *tw = hook("MAPN_SYM_WINDOW");                                    // groups per window (unsharded)
         if (tw && !sharded && sscanf(tw, "%u", &eg) == 1 && eg >= 1) gpw = eg >= gsym ? 0u : eg;
-        const char *t = test_hook(sharded ? "MAPN_SYM_SHARD_TAPER" : "MAPN_SYM_TAPER");     // "parts,taper1,taper2"; "0" = equal parts
-        if (c->sym_user_plan) {
+        const char *t = hook(sharded ? "MAPN_SYM_SHARD_TAPER" : "MAPN_SYM_TAPER");     // "parts,taper1,taper2"; "0" = equal parts
+        if (user_plan) {
             waves = c->sym_user[0]; parts = c->sym_user[1];
             tries.push_back({parts, c->sym_user[2] + c->sym_user[3] ? c->sym_user[2] : parts, c->sym_user[3], waves, c->sym_user[5], c->sym_user[6]});
             if (!sharded && c->sym_user[4]) gpw = c->sym_user[4] >= gsym ? 0u : c->sym_user[4];
@@ -140,9 +120,44 @@ int prepare_sym(mapn_ctx *c, bool sharded)
             }
             tries.push_back({p8, p8, 0, 8, 10, 3}); tries.push_back({p8, p8, 0, 8, 3, 1}); tries.push_back({p8, p8, 0, 8, 2, 1});
         }
-        if (!c->sym_user_plan)
+        if (!user_plan)
             for (uint32_t q = parts; q >= 1u; q = q > 1u ? q / 2u : 0u) tries.push_back({q, q, 0, waves, bh, bl});   // equal parts, halved until every wave has 64 steps
     }
+    return tries;
+}
+}  // namespace
+
+// Build the launch plan and allocate ALL of the symmetric step's scratch: a-rows [blocks][parts][1024], b-rows
+// (unsharded: [N/64][groups of the widest window][64], bounded by MAPN_SYM_MAX_MB -- a step is made in as many windows
+// of partner distance as that takes, so the scratch is O(N); sharded: [N/64][blocks of this rank][64]), head rows,
+// the running sum between windows, the plan tables.  Returns MAPN_OK with sym_ready false (and the reason in sym_note)
+// when the kernel does not apply or -- MAPN_KERNEL_AUTO only -- the memory is not to be had: the one-sided kernel
+// then runs every step.  An explicit MAPN_KERNEL_SYMMETRIC / mapn_set_sym_plan that cannot be honoured is an error.
+int prepare_sym(mapn_ctx *c, bool sharded)
+{
+    release_sym(c);
+    c->sym_note.clear();
+    c->act.active = 0; c->act_failed = 0;                  // (the split form's plan follows this one's weights: made again by the next partially active step)
+    if (!sym_applies(c, sharded)) return MAPN_OK;
+    const bool must = c->cfg.kernel == MAPN_KERNEL_SYMMETRIC || c->sym_user_plan;
+    const uint32_t nb = (c->n + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK, nbl = sharded ? c->count / mapn::SYM_BLOCK : nb;
+    const uint32_t gsym = (nb - 1u) / 2u + ((nb & 1u) ? 0u : 1u);
+    const char *e = getenv("MAPN_SYM_MAX_MB");
+    const bool simulate_failure = test_hook("MAPN_SYM_FAIL_ALLOC") != nullptr;     // tests: behave as if hipMalloc had failed
+    // unsharded: 1 GiB of b-rows by default (12 B per body and group: 1 048 576 bodies 7 windows, 4 194 304 bodies 97); sharded: one window, up to 16 GiB
+    const uint64_t cap = (e ? strtoull(e, nullptr, 10) : (sharded ? 16384ull : 1024ull)) << 20;
+    uint32_t gpw = 0;                                                           // symmetric groups per window (0: all in one)
+    if (sharded) {
+        if ((uint64_t)c->n * nbl * sizeof(mapn::SymRow) > cap) {
+            c->sym_note = "symmetric kernel (sharded): reaction rows exceed MAPN_SYM_MAX_MB";
+            return must ? fail(MAPN_ERR_INVALID_ARGUMENT, "%s", c->sym_note.c_str()) : MAPN_OK;
+        }
+    } else {
+        const uint64_t per_group = (uint64_t)nb * mapn::SYM_BLOCK * sizeof(mapn::SymRow);
+        const uint64_t fit = std::max<uint64_t>(1, cap / per_group);
+        if (fit < gsym) gpw = (uint32_t)fit;
+    }
+    const std::vector<Shape> tries = candidate_shapes(c, sharded, nb, nbl, gsym, gpw, true);
     std::string err;
     bool built = false;
     // XCD weights: class-aware where it applies (heavy blocks on the fast dies), else spread; MAPN_SYM_XCD_MODE=spread: the A/B of the earlier form
@@ -194,16 +209,37 @@ int prepare_sym(mapn_ctx *c, bool sharded)
     return MAPN_OK;
 }
 
-// this STEP: the unsharded symmetric kernel runs the whole-N step with all bodies active
-bool sym_eligible(const mapn_ctx *c, uint32_t active)
+// Which form an unsharded all-pairs step with `active` = roundup64(num_active) bodies runs (a pure function of the context's shape and
+// `active`: a given (N, num_active) always runs the same form, i.e. the same summation order):
+//   FORM_SYM_FULL   the symmetric kernel over all N bodies; the reduce launch stops at `active` (the frozen bodies still exert force)
+//   FORM_SYM_SPLIT  active x active under the symmetric kernel with a plan of the ACTIVE blocks only, active x frozen one-sided
+//                   (enqueue_sym_split) -- every evaluation that feeds only frozen bodies is dropped
+//   FORM_ONE_SIDED  active x N through the scalar-cache kernel
+// Costs in pair evaluations at the symmetric kernel's rate (measured, flat over 65 536 .. 4 194 304 bodies: 7.1e12 ordered pairs / s
+// against 4.9e12 for the one-sided kernel: profiles/r04_sizes_sym_vs_onesided.txt): full N^2; one-sided 1.45 A N; split
+// roundup1024(A)^2 + 1.45 A (N - A) + the extra launch and the frozen rows' pass through the reduce launch (about 17 us).
+StepForm sym_step_form(const mapn_ctx *c, uint32_t active)
 {
-    if (!c->sym_ready || c->sym_sharded || c->plan_forced) return false;
-    if (c->comm || c->external_gather || c->p2p_ready) return false;   // a context wired for an exchange runs the sharded step
-    // Some bodies frozen (num_active < N): they still exert force, so the force launches are the same and only the reduce launch
-    // stops early.  The one-sided kernel evaluates active x N ordered pairs at 4.9e12 / s, this one always N x N at 7e12 / s:
-    // it stays the faster one down to about 0.7 N active bodies.
-    return active > 0 && (uint64_t)active * 4u >= (uint64_t)c->n * 3u;
+    if (!c->sym_ready || c->sym_sharded || c->plan_forced || active == 0) return FORM_ONE_SIDED;
+    if (c->comm || c->external_gather || c->p2p_ready) return FORM_ONE_SIDED;   // a context wired for an exchange runs the sharded step
+    if (active >= c->n) return FORM_SYM_FULL;
+    // (the full form stays the faster one against the one-sided kernel down to about 0.7 N active bodies)
+    const bool full_ok = (uint64_t)active * 4u >= (uint64_t)c->n * 3u;
+    if (const char *f = test_hook("MAPN_PARTIAL_FORM")) {                       // A/B: "one", "full", "split"
+        if (f[0] == 'o') return FORM_ONE_SIDED;
+        if (f[0] == 'f') return FORM_SYM_FULL;
+        if (f[0] == 's' && active >= 2u * mapn::SYM_BLOCK) return FORM_SYM_SPLIT;
+    }
+    const double ratio = 7.1 / 4.9, N = (double)c->n, A = (double)active;
+    const double Ap = (double)(((uint64_t)active + mapn::SYM_BLOCK - 1u) / mapn::SYM_BLOCK * mapn::SYM_BLOCK);
+    const double one = ratio * A * N, full = N * N, split = Ap * Ap + ratio * A * (N - A) + 1.2e8;
+    const double other = full_ok ? full : one;
+    if (active >= 8u * mapn::SYM_BLOCK && c->act_failed != active && split < other) return FORM_SYM_SPLIT;   // (fewer than 8 blocks do not fill the device under the symmetric kernel)
+    return full_ok ? FORM_SYM_FULL : FORM_ONE_SIDED;
 }
+
+// this STEP runs the symmetric kernel over the whole job (all bodies active, or so many that the frozen ones are not worth a split)
+bool sym_eligible(const mapn_ctx *c, uint32_t active) { return sym_step_form(c, active) == FORM_SYM_FULL; }
 
 // MAPN_STAMP_DUMP=<file> (development tool): a stamped diagnostic launch of the symmetric kernel also records, per wave,
 // its entry / loop start / loop end / exit times (100 MHz) and where it ran; mapn_measure_clock writes them to the file.
@@ -237,16 +273,17 @@ int stamps_prepare(mapn_ctx *c, size_t nw, mapn::SymArgs &a)
     return timeline_prepare(c, nw, a);
 }
 
-mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t window)
+namespace {
+mapn::SymArgs sym_args_of(const mapn::SymPlanHost &pl, mapn::SymRow *arow, mapn::SymRow *brow, mapn::SymRow *brow1, const uint32_t *tab, uint32_t n,
+                          const mapn::StepArgs &base, size_t window)
 {
-    const mapn::SymPlanHost &pl = c->sym_plan;
     mapn::SymArgs a{};
     a.pos_old = base.pos_old; a.vel_old = base.vel_old; a.pos_new = base.pos_new; a.vel_new = base.vel_new;
-    a.arow = c->sym_arow; a.brow = c->sym_brow; a.brow1 = c->sym_brow1;
-    a.tab = c->sym_tab + window * pl.table_stride;
-    a.wgmap = pl.wgmap_entries ? c->sym_tab + pl.wgmap_offset : nullptr;
+    a.arow = arow; a.brow = brow; a.brow1 = brow1;
+    a.tab = tab + window * pl.table_stride;
+    a.wgmap = pl.wgmap_entries ? tab + pl.wgmap_offset : nullptr;
     a.la_flip = pl.la_flip;
-    a.n = c->n; a.n_integrate = c->n; a.nb = pl.nb; a.parts = pl.parts; a.nwaves = pl.nwaves; a.max_meetings = pl.max_meetings; a.sets = pl.sets;
+    a.n = n; a.n_integrate = n; a.nb = pl.nb; a.parts = pl.parts; a.nwaves = pl.nwaves; a.max_meetings = pl.max_meetings; a.sets = pl.sets;
     a.g0 = pl.windows[window].g0; a.g1 = pl.windows[window].g1;
     a.brows = pl.brows; a.half_d = pl.half;
     a.mass = base.mass; a.soft2 = base.soft2; a.dt = base.dt; a.damping = base.damping;
@@ -259,6 +296,12 @@ mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t win
     static const uint32_t stage = [] { const char *e = test_hook("MAPN_SYM_STAGE"); return e ? (uint32_t)atoi(e) : 1u; }();
     a.stage_iblock = stage;
     return a;
+}
+}  // namespace
+
+mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t window)
+{
+    return sym_args_of(c->sym_plan, c->sym_arow, c->sym_brow, c->sym_brow1, c->sym_tab, c->n, base, window);
 }
 
 // One step = one force launch + one reduce launch per window of partner distance; the reduce launches carry the
@@ -280,6 +323,117 @@ int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     mapn::ForcePlan p{};
     p.kind = mapn::KERNEL_SYM; p.k = 2 * mapn::SYM_K2; p.waves = pl.waves; p.sb = pl.parts; p.nseg = 1; p.epi = mapn::EPI_ROWS;
     c->last_plan = p; c->last_i_count = c->n; c->last_launches = 2 * (uint32_t)nwin;   // (the force launches always cover all N bodies)
+    return MAPN_OK;
+}
+
+// ---- the PARTIALLY ACTIVE step, split form ----------------------------------------------------------
+// The reference lets the user simulate any count of the bodies (Particles.cpp:391-394 -> Compute.cpp:1041: bodies
+// [0, roundup64(num_active)) advance, the rest stay frozen but still exert force).  Until round 4 every such step with fewer than
+// 0.75 N active bodies ran the one-sided kernel over active x N ordered pairs.  Of those only active x FROZEN has to be one-sided:
+// the active bodies meet EACH OTHER under the symmetric kernel -- a plan of the active blocks alone (the bodies past A are the
+// kernel's far-away stand-ins), its own scratch -- and the one-sided launch over the frozen j-segment [A, N) leaves partial force
+// rows (EPI_ROWS) that the first window's reduce launch adds, in ascending row order, in front of its own rows.  Summation order
+// (what the order-matched checker restates): frozen rows as in mapn_set_force_plan's comment with the j-range [A, N), then the
+// symmetric plan's order over the bodies [0, A); the mass multiplies the total.
+void release_sym_active(mapn_ctx *c)
+{
+    mapn_ctx::SymActive &s = c->act;
+    if (s.arow) (void)hipFree(s.arow);
+    if (s.brow) (void)hipFree(s.brow);
+    if (s.brow1) (void)hipFree(s.brow1);
+    if (s.acc) (void)hipFree(s.acc);
+    if (s.tab) (void)hipFree(s.tab);
+    s = mapn_ctx::SymActive{};
+}
+
+// Plan and scratch for `active` bodies (a no-op when they are the ones of the last call).  Runs on the FIRST step with a new
+// num_active -- a host-side plan, a table upload and, when the scratch has to grow, allocations behind a drained stream -- never on
+// the steps after it.  Failure is not an error: act.active stays 0, act_failed remembers the count, and the caller takes another form.
+int prepare_sym_active(mapn_ctx *c, uint32_t active)
+{
+    mapn_ctx::SymActive &s = c->act;
+    if (s.active == active) return MAPN_OK;
+    HIP_TRY(hipStreamSynchronize(c->compute));             // steps still in flight read the tables and rows this replaces
+    drop_graphs(c);
+    s.active = 0;
+    const uint32_t nb = (active + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK;
+    const uint32_t gsym = (nb - 1u) / 2u + ((nb & 1u) ? 0u : 1u);
+    const char *e = getenv("MAPN_SYM_MAX_MB");
+    const uint64_t cap = (e ? strtoull(e, nullptr, 10) : 1024ull) << 20;
+    uint32_t gpw = 0;
+    const uint64_t per_group = (uint64_t)nb * mapn::SYM_BLOCK * sizeof(mapn::SymRow), fit = std::max<uint64_t>(1, cap / per_group);
+    if (fit < gsym) gpw = (uint32_t)fit;
+    std::string err;
+    bool built = false;
+    for (const Shape &sh : candidate_shapes(c, false, nb, nb, gsym, gpw, false))
+        if ((built = mapn::build_sym_plan(nb, gpw, sh.parts, sh.t1, sh.t2, sh.waves, sh.hi, sh.lo, c->sym_xcd_weighted ? c->sym_xcd_w : nullptr, nb, 0u, 0u, s.plan, err))) break;
+    if (!built) { c->act_failed = active; g_last_error = "partially active step: " + err + "; another form runs"; return MAPN_OK; }
+    const mapn::SymPlanHost &pl = s.plan;
+    // the one-sided launch over the frozen bodies: the default plan of an active x (N - active) launch, partial rows instead of the integrator
+    s.frozen = choose_plan(c, active, c->n - active, 1, false);
+    s.frozen.epi = mapn::EPI_ROWS;
+    auto grow = [](void **p, size_t &have, size_t need) -> hipError_t {
+        if (need <= have) return hipSuccess;
+        if (*p) (void)hipFree(*p);
+        *p = nullptr; have = 0;
+        const hipError_t e2 = hipMalloc(p, need);
+        if (e2 == hipSuccess) have = need;
+        return e2;
+    };
+    const size_t ab = (size_t)nb * pl.parts * mapn::SYM_BLOCK * sizeof(mapn::SymRow);
+    const size_t bb = (size_t)nb * mapn::SYM_BLOCK * pl.brows * sizeof(mapn::SymRow);
+    const size_t hb = (size_t)nb * pl.parts * 64 * sizeof(mapn::SymRow);
+    const size_t cb = pl.windows.size() > 1 ? (size_t)nb * mapn::SYM_BLOCK * sizeof(float4) : 0;
+    const size_t tb = pl.tables.size() * sizeof(uint32_t);
+    hipError_t he = test_hook("MAPN_SYM_FAIL_ALLOC") ? hipErrorOutOfMemory : hipSuccess;
+    if (he == hipSuccess) he = grow(reinterpret_cast<void **>(&s.arow), s.cap_arow, ab);
+    if (he == hipSuccess) he = grow(reinterpret_cast<void **>(&s.brow), s.cap_brow, bb);
+    if (he == hipSuccess) he = grow(reinterpret_cast<void **>(&s.brow1), s.cap_brow1, hb);
+    if (he == hipSuccess && cb) he = grow(reinterpret_cast<void **>(&s.acc), s.cap_acc, cb);
+    if (he == hipSuccess) he = grow(reinterpret_cast<void **>(&s.tab), s.cap_tab, tb);
+    if (he == hipSuccess) he = hipMemcpy(s.tab, pl.tables.data(), tb, hipMemcpyHostToDevice);
+    if (he == hipSuccess && ensure_partial(c, s.frozen.sb, ((size_t)active + 63u) & ~(size_t)63u) != MAPN_OK) he = hipErrorOutOfMemory;
+    if (he != hipSuccess) {
+        (void)hipGetLastError();
+        c->act_failed = active;
+        char msg[256];
+        snprintf(msg, sizeof msg, "partially active step: %.1f MiB of scratch for %u active bodies could not be allocated (%s); another form runs",
+                 (double)(ab + bb + hb + cb + tb) / 1048576.0, active, hipGetErrorString(he));
+        g_last_error = msg;
+        return MAPN_OK;
+    }
+    s.active = active;
+    return MAPN_OK;
+}
+
+int enqueue_sym_split(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
+{
+    const mapn_ctx::SymActive &s = c->act;
+    const mapn::SymPlanHost &pl = s.plan;
+    const uint32_t A = s.active;
+    // (1) what the frozen bodies [A, N) do to the active ones: partial rows, one per block row of the launch
+    mapn::StepArgs f = base;
+    f.i_first = 0; f.i_count = A;
+    fill_segment(f, 0, A, c->n - A, 0, s.frozen.sb * s.frozen.waves);
+    f.partial_stride = (A + 63u) & ~63u;
+    if (int rc = ensure_partial(c, s.frozen.sb, f.partial_stride)) return rc;     // (made by prepare_sym_active: a no-op here)
+    f.partial = c->partial; f.ticket = c->ticket; f.ticket_total = s.frozen.sb;
+    HIP_TRY(mapn::launch_force(s.frozen, f, c->compute));
+    // (2) the active bodies among themselves, window by window; the first reduce launch takes the frozen rows in
+    const size_t nwin = pl.windows.size();
+    for (size_t k = 0; k < nwin; k++) {
+        mapn::SymArgs a = sym_args_of(pl, s.arow, s.brow, s.brow1, s.tab, A, base, k);
+        a.acc_in = k ? s.acc : nullptr;
+        a.acc_out = k + 1 < nwin ? s.acc : nullptr;
+        if (k == 0) { a.extra = c->partial; a.extra_rows = s.frozen.sb; a.extra_stride = f.partial_stride; }
+        HIP_TRY(mapn::launch_force_sym(a, pl.waves, c->compute));
+        if (timer && nwin == 1) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }   // (the frozen launch and the symmetric one)
+        HIP_TRY(mapn::launch_sym_reduce(a, c->compute));
+    }
+    mapn::ForcePlan p{};
+    p.kind = mapn::KERNEL_SYM; p.k = 2 * mapn::SYM_K2; p.waves = pl.waves; p.sb = pl.parts; p.nseg = 1; p.epi = mapn::EPI_ROWS;
+    c->last_plan = p; c->last_i_count = A; c->last_launches = 2 * (uint32_t)nwin + 1u;
+    c->last_split_active = A;
     return MAPN_OK;
 }
 
@@ -684,6 +838,32 @@ int mapn_calibrate_sym_xcds(mapn_ctx *c, int steps, uint32_t out[8])
     return MAPN_OK;
 }
 
+namespace {
+// a plan as the C ABI describes it (info + the two arrays, capacities checked)
+int export_plan(const mapn::SymPlanHost &p, const char *who, mapn_sym_plan_info *info, uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity)
+{
+    info->nb = p.nb; info->groups = p.groups; info->windows = (uint32_t)p.windows.size();
+    info->parts = p.parts; info->taper1 = p.taper1; info->taper2 = p.taper2; info->waves = p.waves;
+    info->wave_bias[0] = p.bias_hi; info->wave_bias[1] = p.bias_lo;
+    info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
+    info->sets = p.sets; for (int k = 0; k < 8; k++) info->xcd_weight[k] = p.xcd_weight[k];
+    info->xcd_mode = p.xcd_mode; info->wgmap_offset = p.wgmap_offset; info->wgmap_entries = p.wgmap_entries; info->la_flip = p.la_flip;
+    for (int k = 0; k < 8; k++) info->class_die[k] = p.class_die[k / 4][k % 4];
+    if (windows && windows_capacity < 4u * p.windows.size())
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "%s: windows_capacity %llu < %zu (the plan has changed since the arrays were sized: query again)", who, (unsigned long long)windows_capacity, 4u * p.windows.size());
+    if (windows)
+        for (size_t k = 0; k < p.windows.size(); k++) {
+            windows[4 * k + 0] = p.windows[k].g0; windows[4 * k + 1] = p.windows[k].g1;
+            windows[4 * k + 2] = p.windows[k].meetings[0]; windows[4 * k + 3] = p.windows[k].meetings[1];
+        }
+    if (tables) {
+        if (tables_capacity < p.tables.size()) return fail(MAPN_ERR_INVALID_ARGUMENT, "%s: tables_capacity %llu < %zu", who, (unsigned long long)tables_capacity, p.tables.size());
+        std::copy(p.tables.begin(), p.tables.end(), tables);
+    }
+    return MAPN_OK;
+}
+}  // namespace
+
 int mapn_get_sym_plan(mapn_ctx *c, mapn_sym_plan_info *info, uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity)
 {
     if (!c || !info) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
@@ -692,31 +872,29 @@ int mapn_get_sym_plan(mapn_ctx *c, mapn_sym_plan_info *info, uint32_t *windows, 
         snprintf(info->error, sizeof info->error, "%s", c->sym_note.empty() ? "the symmetric kernel does not apply to this context" : c->sym_note.c_str());
         return fail(MAPN_ERR_STATE, "get_sym_plan: %s", info->error);
     }
-    const mapn::SymPlanHost &p = c->sym_plan;
-    info->nb = p.nb; info->groups = p.groups; info->windows = (uint32_t)p.windows.size();
-    info->parts = p.parts; info->taper1 = p.taper1; info->taper2 = p.taper2; info->waves = p.waves;
-    info->wave_bias[0] = p.bias_hi; info->wave_bias[1] = p.bias_lo;
-    info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
-    info->sets = p.sets; for (int k = 0; k < 8; k++) info->xcd_weight[k] = p.xcd_weight[k];
-    info->xcd_mode = p.xcd_mode; info->wgmap_offset = p.wgmap_offset; info->wgmap_entries = p.wgmap_entries; info->la_flip = p.la_flip;
-    for (int k = 0; k < 8; k++) info->class_die[k] = p.class_die[k / 4][k % 4];
     info->a0 = c->sym_sharded ? (uint32_t)c->cfg.rank * (c->count / mapn::SYM_BLOCK) : 0u;
     info->nbl = c->sym_sharded ? c->count / mapn::SYM_BLOCK : 0u;
     info->scratch_bytes = c->sym_scratch_bytes;
     info->active_compute_units = c->sym_sharded ? (uint32_t)c->cus_active : 0u;
     info->exchange_workgroups = c->sym_sharded ? c->sym_exchange_cap : 0u;
-    if (windows && windows_capacity < 4u * p.windows.size())
-        return fail(MAPN_ERR_INVALID_ARGUMENT, "get_sym_plan: windows_capacity %llu < %zu (the plan has changed since the arrays were sized: query again)", (unsigned long long)windows_capacity, 4u * p.windows.size());
-    if (windows)
-        for (size_t k = 0; k < p.windows.size(); k++) {
-            windows[4 * k + 0] = p.windows[k].g0; windows[4 * k + 1] = p.windows[k].g1;
-            windows[4 * k + 2] = p.windows[k].meetings[0]; windows[4 * k + 3] = p.windows[k].meetings[1];
-        }
-    if (tables) {
-        if (tables_capacity < p.tables.size()) return fail(MAPN_ERR_INVALID_ARGUMENT, "get_sym_plan: tables_capacity %llu < %zu", (unsigned long long)tables_capacity, p.tables.size());
-        std::copy(p.tables.begin(), p.tables.end(), tables);
+    return export_plan(c->sym_plan, "get_sym_plan", info, windows, windows_capacity, tables, tables_capacity);
+}
+
+int mapn_get_split_plan(mapn_ctx *c, mapn_split_info *split, mapn_sym_plan_info *info, uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity)
+{
+    if (!c || !split || !info) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
+    memset(info, 0, sizeof *info);
+    memset(split, 0, sizeof *split);
+    if (!c->act.active) {
+        snprintf(info->error, sizeof info->error, "no partially active step has run in its split form yet");
+        return fail(MAPN_ERR_STATE, "get_split_plan: %s", info->error);
     }
-    return MAPN_OK;
+    const mapn_ctx::SymActive &s = c->act;
+    split->active = s.active; split->frozen = c->n - s.active;
+    split->frozen_kernel = s.frozen.kind == mapn::KERNEL_LDS ? MAPN_KERNEL_LDS : MAPN_KERNEL_SCALAR;
+    split->frozen_bodies_per_lane = s.frozen.k; split->frozen_waves = s.frozen.waves; split->frozen_sb = s.frozen.sb;
+    info->scratch_bytes = s.cap_arow + s.cap_brow + s.cap_brow1 + s.cap_acc + s.cap_tab;
+    return export_plan(s.plan, "get_split_plan", info, windows, windows_capacity, tables, tables_capacity);
 }
 
 }  // extern "C"

@@ -89,6 +89,9 @@ class Oracle:
         _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
         lib.mapn_oracle_step_all_pairs_sym.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.POINTER(Params), C.c_int, C.POINTER(SymShape), _u32p, _u32p]
         lib.mapn_oracle_step_all_pairs_sym.restype = C.c_int
+        lib.mapn_oracle_step_all_pairs_sym_split.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int,
+                                                             C.POINTER(SymShape), _u32p, _u32p, C.c_uint32, C.c_uint32]
+        lib.mapn_oracle_step_all_pairs_sym_split.restype = C.c_int
         lib.mapn_oracle_step_all_pairs_f64.argtypes = [_f64p, _f64p, _f64p, _f64p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int]
         lib.mapn_oracle_step_all_pairs_f64.restype = C.c_int
         lib.mapn_oracle_accel_all_pairs.argtypes = [_f32p, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
@@ -189,8 +192,11 @@ class OracleSim:
     """Host-array twin of the reference's ``Compute`` object: two ping-pong buffer pairs, a
     buffer index and ``simulate(num_active)`` with Compute.cpp:1009-1055 semantics."""
 
-    def __init__(self, oracle: Oracle, pos, vel, mode=MODE_ALL_PAIRS, params=None, threads=0, sum_spec=None, sym_plan=None):
+    def __init__(self, oracle: Oracle, pos, vel, mode=MODE_ALL_PAIRS, params=None, threads=0, sum_spec=None, sym_plan=None, split_plan=None):
         self.o = oracle
+        # the device's PARTIALLY ACTIVE step in its split form (ORDER_MATCHED_SPLIT): (split, plan) as the product's binding returns them
+        # (duck-typed: split.active / .frozen_waves / .frozen_sb; plan as for sym_plan); steps with that num_active take this order
+        self.split = (split_plan[0], sym_plan_args(split_plan[1])) if split_plan is not None else None
         self.sum_spec = sum_spec            # diagnostic summation variant (all-pairs, num_active = N only)
         self.sym = sym_plan_args(sym_plan) if sym_plan is not None else None   # ... or the symmetric kernel's order (ORDER_MATCHED_SYM)
         self.n = pos.shape[0]
@@ -201,6 +207,17 @@ class OracleSim:
 
     def simulate(self, num_active=None, steps=1):
         num_active = self.n if num_active is None else num_active
+        if self.split is not None and self.o.active_bodies(num_active, self.n) == self.split[0].active:
+            assert self.mode == MODE_ALL_PAIRS
+            split, (shape, win, tab) = self.split
+            for _ in range(steps):
+                w, r = self.buffer_index, 1 - self.buffer_index
+                rc = self.o.lib.mapn_oracle_step_all_pairs_sym_split(self.pos[r], self.vel[r], self.pos[w], self.vel[w], self.n, split.active,
+                                                                     C.byref(self.params), self.threads, C.byref(shape), win, tab,
+                                                                     split.frozen_waves, split.frozen_sb)
+                assert rc == 0, rc
+                self.buffer_index = 1 - self.buffer_index
+            return
         if self.sym is not None:
             assert self.mode == MODE_ALL_PAIRS and self.o.active_bodies(num_active, self.n) == self.n
             shape, win, tab = self.sym

@@ -988,3 +988,123 @@ int mapn_oracle_step_all_pairs_sym(const float *old_pos, const float *old_vel, f
     free(arow); free(brow); free(brow1); free(acc);
     return rc;
 }
+
+/* =================================================================================================
+ * ORDER_MATCHED_SPLIT: the device's PARTIALLY ACTIVE step in its split form (csrc/mapn_sym_host.cpp, enqueue_sym_split;
+ * Compute.cpp:1041: bodies [0, active) advance, the frozen ones [active, N) still exert force).  Restated, in the device's order:
+ *   * per active body first what the FROZEN bodies do to it: the one-sided kernel's partial rows over the j-range [active, N) --
+ *     its ceil((N - active) / 64) tiles cut into S = waves * sb chunks (chunk_tiles), a chunk one fma chain from zero over ascending
+ *     j, a row = its `waves` chunk sums added in ascending order to zero -- the rows added in ascending order to zero
+ *     (sym_reduce_integrate_kernel, p.extra);
+ *   * then the symmetric plan of a job of `active` bodies (the bodies past it are the far-away stand-ins), window by window, exactly
+ *     as ORDER_MATCHED_SYM, the frozen sum standing where the running sum of "earlier windows" stands;
+ *   * total * mass, fused integrator; bodies [active, N) of the new buffers are left as they are.
+ * ================================================================================================= */
+typedef struct {
+    const float *old_pos;
+    uint32_t n_total, n_active, waves, sb;
+    float soft2;
+    float *acc;                 /* [3][np] */
+    size_t np;
+    uint32_t tid, nthreads;
+} frozen_job;
+
+__attribute__((target_clones("avx512f", "fma", "default")))
+static void frozen_block(const frozen_job *F, uint32_t b0, uint32_t nbod)
+{
+    float xi[IB], yi[IB], zi[IB], tx[IB], ty[IB], tz[IB], wx[IB], wy[IB], wz[IB], cx[IB], cy[IB], cz[IB];
+    const float soft2 = F->soft2;
+    for (uint32_t k = 0; k < IB; k++) {
+        uint32_t i = b0 + (k < nbod ? k : 0);
+        xi[k] = F->old_pos[4 * (size_t)i + 0]; yi[k] = F->old_pos[4 * (size_t)i + 1]; zi[k] = F->old_pos[4 * (size_t)i + 2];
+        tx[k] = ty[k] = tz[k] = 0.0f;
+    }
+    const uint32_t waves = F->waves, sb = F->sb, S = waves * sb;
+    const uint32_t j_first = F->n_active, j_count = F->n_total - F->n_active;
+    const uint32_t tiles = (j_count + 63u) / 64u, base = tiles / S, rem = tiles % S;
+    for (uint32_t row = 0; row < sb; row++) {
+        for (int k = 0; k < IB; k++) wx[k] = wy[k] = wz[k] = 0.0f;
+        for (uint32_t w = 0; w < waves; w++) {
+            const uint32_t c = row * waves + w;
+            const uint32_t t0 = c * base + (c < rem ? c : rem), t1 = t0 + base + (c < rem ? 1u : 0u);
+            uint32_t j0 = t0 * 64u, j1 = t1 * 64u;
+            if (j1 > j_count) j1 = j_count;
+            for (int k = 0; k < IB; k++) cx[k] = cy[k] = cz[k] = 0.0f;
+            const float *pj = F->old_pos + 4 * ((size_t)j_first + j0);
+            for (uint32_t j = j0; j < j1; j++, pj += 4) {
+                const float xj = pj[0], yj = pj[1], zj = pj[2];
+#pragma GCC ivdep
+                for (int k = 0; k < IB; k++) {
+                    float dx = xj - xi[k], dy = yj - yi[k], dz = zj - zi[k];
+                    float d = __builtin_fmaf(dx, dx, soft2);
+                    d = __builtin_fmaf(dy, dy, d);
+                    d = __builtin_fmaf(dz, dz, d);
+                    float inv = 1.0f / sqrtf(d);
+                    float inv3 = inv * inv * inv;
+                    cx[k] = __builtin_fmaf(dx, inv3, cx[k]);
+                    cy[k] = __builtin_fmaf(dy, inv3, cy[k]);
+                    cz[k] = __builtin_fmaf(dz, inv3, cz[k]);
+                }
+            }
+            for (int k = 0; k < IB; k++) { wx[k] = wx[k] + cx[k]; wy[k] = wy[k] + cy[k]; wz[k] = wz[k] + cz[k]; }
+        }
+        for (int k = 0; k < IB; k++) { tx[k] = tx[k] + wx[k]; ty[k] = ty[k] + wy[k]; tz[k] = tz[k] + wz[k]; }
+    }
+    for (uint32_t k = 0; k < nbod; k++) {
+        F->acc[b0 + k] = tx[k]; F->acc[F->np + b0 + k] = ty[k]; F->acc[2 * F->np + b0 + k] = tz[k];
+    }
+}
+
+static void *frozen_worker(void *arg)
+{
+    const frozen_job *F = (const frozen_job *)arg;
+    const uint32_t nblocks = (F->n_active + IB - 1) / IB;
+    for (uint32_t b = F->tid; b < nblocks; b += F->nthreads) {
+        const uint32_t b0 = b * IB, left = F->n_active - b0;
+        frozen_block(F, b0, left < IB ? left : IB);
+    }
+    return NULL;
+}
+
+/* shape / windows / tables: the plan of the ACTIVE bodies (mapn_get_split_plan); frozen_waves, frozen_sb: the one-sided launch's shape */
+int mapn_oracle_step_all_pairs_sym_split(const float *old_pos, const float *old_vel, float *new_pos, float *new_vel, uint32_t n_total,
+                                         uint32_t n_active, const mapn_oracle_params *p, int threads, const mapn_oracle_sym_shape *shape,
+                                         const uint32_t *windows, const uint32_t *tables, uint32_t frozen_waves, uint32_t frozen_sb)
+{
+    if (!shape || !windows || !tables || n_active == 0 || n_active >= n_total || shape->nb != (n_active + SYM_IB - 1u) / SYM_IB ||
+        shape->waves == 0 || shape->parts == 0 || (shape->sets != 2u && shape->sets != 16u) || frozen_waves == 0 || frozen_sb == 0) return -2;
+    if (threads <= 0) threads = mapn_oracle_hardware_threads();
+    const size_t np = (size_t)shape->nb * SYM_IB;
+    float *arow = (float *)malloc(sizeof(float) * 3u * SYM_IB * shape->nb * shape->parts);
+    float *brow = (float *)malloc(sizeof(float) * 192u * (np / 64u) * shape->brows);
+    float *brow1 = (float *)malloc(sizeof(float) * 192u * shape->nb * shape->parts);
+    float *acc = (float *)calloc(3u * np, sizeof(float));
+    int rc = (arow && brow && brow1 && acc) ? 0 : -1;
+    if (rc == 0) {
+        /* (1) the frozen bodies' rows, summed: the start value of every active body's sum */
+        const uint32_t nblocks = (n_active + IB - 1) / IB;
+        const int ft = (uint32_t)threads > nblocks ? (int)nblocks : threads;
+        frozen_job *jobs = (frozen_job *)calloc((size_t)ft, sizeof(frozen_job));
+        pthread_t *th = (pthread_t *)calloc((size_t)ft, sizeof(pthread_t));
+        if (!jobs || !th) rc = -1;
+        for (int t = 0; t < ft && rc == 0; t++) {
+            jobs[t] = (frozen_job){old_pos, n_total, n_active, frozen_waves, frozen_sb, p->soft2, acc, np, (uint32_t)t, (uint32_t)ft};
+            if (t > 0 && pthread_create(&th[t], NULL, frozen_worker, &jobs[t]) != 0) { frozen_worker(&jobs[t]); th[t] = 0; }
+        }
+        if (rc == 0) {
+            frozen_worker(&jobs[0]);
+            for (int t = 1; t < ft; t++) if (th[t]) pthread_join(th[t], NULL);
+        }
+        free(jobs); free(th);
+    }
+    /* (2) the active bodies among themselves: the symmetric plan of a job of n_active bodies, the frozen sum as the running sum */
+    for (uint32_t k = 0; k < shape->windows && rc == 0; k++) {
+        sym_job J = {old_pos, old_vel, new_pos, new_vel, n_active, p, shape, windows + 4u * k, tables + (size_t)k * shape->table_stride,
+                     arow, brow, brow1, acc, 0, k + 1u == shape->windows, 0, 0};
+        const uint32_t items = shape->nb * shape->parts;
+        rc = sym_run(sym_force_worker, &J, (uint32_t)threads > items ? (int)items : threads);
+        if (rc == 0) rc = sym_run(sym_reduce_worker, &J, threads);
+    }
+    free(arow); free(brow); free(brow1); free(acc);
+    return rc;
+}

@@ -1,0 +1,51 @@
+"""The order-matched restatement of the PARTIALLY ACTIVE step's split form (oracle/mapn_oracle.c, ORDER_MATCHED_SPLIT) against
+the oracle proper (reference order, Compute.cpp:1041 semantics) -- on the CPU, with plans computed without a device
+(mapn_sym_plan_describe): the frozen bodies' rows + the symmetric plan of the active bodies must add up to the same physics, leave
+the frozen tail alone, and respond to the one-sided launch's shape only by rounding."""
+import types
+
+import numpy as np
+import pytest
+
+import mapn
+from oracle import OracleSim, Params
+
+
+def split_of(n, active, waves, sb):
+    return types.SimpleNamespace(active=active, frozen=n - active, frozen_waves=waves, frozen_sb=sb)
+
+
+@pytest.mark.parametrize("n,num_active,parts,waves,gpw", [(4096, 2100, 4, 4, 0), (6000, 3072, 2, 8, 0), (8192, 4097, 4, 4, 1), (3000, 2048, 2, 4, 0)])
+def test_split_restatement_matches_the_reference_order_oracle(oracle, n, num_active, parts, waves, gpw):
+    active = oracle.active_bodies(num_active, n)
+    assert active < n
+    nb = (active + 1023) // 1024
+    plan = mapn.compute.describe_sym_plan(nb, groups_per_window=gpw, parts=parts, waves=waves)
+    if gpw:
+        assert len(plan.windows) > 1
+    pos, vel = oracle.initial_state(n, seed=3)
+    prm = Params(mass=70000.0 / n)
+    ref = OracleSim(oracle, pos, vel, params=prm)
+    out = {}
+    for fw, fsb in ((8, 2), (4, 1)):
+        sim = OracleSim(oracle, pos, vel, params=prm, split_plan=(split_of(n, active, fw, fsb), plan))
+        sim.simulate(num_active=num_active, steps=2)
+        out[(fw, fsb)] = [p.copy() for p in sim.pos]
+    ref.simulate(num_active=num_active, steps=2)
+    for key, bufs in out.items():
+        for b in (0, 1):
+            d = np.linalg.norm(bufs[b][:, :3].astype(np.float64) - ref.pos[b][:, :3], axis=1) / 400.0
+            assert d.max() < 1e-6, (key, b, d.max())
+            np.testing.assert_array_equal(bufs[b][active:], ref.pos[b][active:])      # the frozen tail: never written
+            assert np.abs(bufs[b][:active, 3] - ref.pos[b][:active, 3]).max() <= 1e-4 * ref.pos[b][:active, 3].max()
+    a, b = out[(8, 2)][1], out[(4, 1)][1]
+    assert np.linalg.norm(a[:, :3].astype(np.float64) - b[:, :3], axis=1).max() / 400.0 < 1e-6      # another cut of the frozen range: rounding only
+
+
+def test_split_restatement_refuses_shapes_that_do_not_fit(oracle):
+    n, active = 4096, 2048
+    pos, vel = oracle.initial_state(n, seed=1)
+    plan = mapn.compute.describe_sym_plan(3, parts=4, waves=4)          # a plan for 3 blocks: not the 2 blocks of 2048 active bodies
+    sim = OracleSim(oracle, pos, vel, params=Params(mass=1.0), split_plan=(split_of(n, active, 8, 1), plan))
+    with pytest.raises(AssertionError):
+        sim.simulate(num_active=active)

@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--xcd", choices=["auto", "off", "on"], default="auto",
                     help="XCD-aware parts of the symmetric kernel (1 GPU): calibrate the dies' speeds during the untimed prewarm and size "
                          "every part by the die it runs on; auto keeps them only if an untimed A/B against the default plan wins")
+    ap.add_argument("--xcd-weights", default="", help="w0,...,w7: run the symmetric kernel under THESE relative die speeds (1024 = the fastest; mapn_set_sym_xcd_weights) -- no "
+                                                      "calibration, no A/B: replays the plan of an earlier run's line (config.xcd_aware_parts.weights) bit for bit")
+    ap.add_argument("--no-central-well-leg", action="store_true", help="skip the untimed ~0.3 s behind the run that measures the HBM-bound CENTRAL_WELL step at 4 Mi and 16 Mi bodies (single GPU)")
     ap.add_argument("--overlap", action="store_true", help="sharded mode: own-segment launch overlapped with the all-gather")
     ap.add_argument("--trial-seconds", type=float, default=90.0,
                     help="wall-time budget of the exchange trial (N > 1, --gather auto): once it is spent the candidates not yet tried are skipped")
@@ -271,6 +274,11 @@ def main():
     kern = {"auto": mapn.KERNEL_AUTO, "lds": mapn.KERNEL_LDS, "sgpr": mapn.KERNEL_SCALAR, "sym": mapn.KERNEL_SYMMETRIC}[a.kernel]
     # XCD-aware parts (1 GPU, symmetric kernel): the LIBRARY calibrates the dies when the context is created (MAPN_FLAG_XCD_CALIBRATE:
     # the plan any C-ABI caller gets with that one config bit); below, an untimed A/B decides whether the weights stay
+    given_w = [int(x) for x in a.xcd_weights.split(",")] if a.xcd_weights else None
+    if given_w is not None and (len(given_w) != 8 or world > 1):
+        sys.exit("bench: --xcd-weights takes eight comma-separated weights and applies to the single-GPU run")
+    if given_w is not None:
+        a.xcd = "off"                                          # (no calibration and no A/B: the plan is the one asked for)
     xcd_by_library = dist is None and a.mode == "all_pairs" and a.xcd != "off" and kern in (mapn.KERNEL_AUTO, mapn.KERNEL_SYMMETRIC) and not a.plan and not a.graph
     # (N > 1: the same flag makes every rank's library measure ITS GPU with a temporary unsharded context when the sharded symmetric step
     #  is prepared -- no collective in it -- and plan the rank's launch with those weights; the A/B below decides here too)
@@ -526,6 +534,11 @@ def main():
     # XCD-aware parts (1 GPU, symmetric kernel): the eight dies do not run at one speed and a launch gives each the same work.
     # Untimed: calibrate, then an A/B of the weighted plan against the default one; the weights stay only if they win.
     xcd = {"mode": a.xcd, "weights": None, "used": False, "source": None}
+    if given_w is not None:
+        c.set_sym_xcd_weights(given_w)
+        plw = c.sym_plan()
+        xcd.update({"mode": "given", "weights": list(plw.xcd_weight) if plw.xcd_mode else given_w, "used": plw.xcd_mode != 0, "source": "--xcd-weights (no calibration, no A/B)",
+                    "form": {0: None, 1: "spread", 2: "class-aware"}.get(plw.xcd_mode)})
     if dist is not None and world > 1 and "symmetric" in gather_algo and a.xcd != "off" and not a.plan:
         # SHARDED symmetric step: the library has planned every rank's launch with the die weights of ITS GPU (MAPN_FLAG_XCD_CALIBRATE:
         # a temporary unsharded context's calibration when the step was prepared -- no collective in it, and every die holds heavy and
@@ -594,6 +607,8 @@ def main():
                 c.set_sym_xcd_weights(None)
             except mapn.MapnError:
                 pass
+    verdict = torch.zeros(1, dtype=torch.int32, device=red_dev) if dist is not None else None     # the closing collective's ONE tensor, made before any timed region
+
     def run_steps(k, recoverable):
         """k steps, then the barrier + device sync.  With a peer-to-peer form on N > 1 ranks a device-side check or wait that fails on ANY rank
         (they are all bounded: every rank gets out of its own) comes back as text on EVERY rank -- the closing collective carries the verdict --
@@ -611,14 +626,15 @@ def main():
             torch.cuda.synchronize()
         run_steps.idle_at = time.perf_counter()               # THIS rank's device is idle: its k steps are done (the closing collective is still to come)
         if dist is not None:
-            if recoverable:
-                bad = torch.tensor([1 if fail else 0], device=red_dev)
-                dist.all_reduce(bad, op=dist.ReduceOp.MAX)      # (this collective IS the barrier)
-                if bad.item() and not fail:
-                    fail = "a device-side check or wait failed on another rank"
-            else:
-                dist.barrier()
+            # ONE collective closes the region for every form: it is the barrier AND carries the verdict (no tensor is created, no second
+            # collective issued inside the timed region: VERDICT r4 #7); .item() waits for it, the device sync after it finds nothing left
+            verdict.fill_(1 if fail else 0)
+            dist.all_reduce(verdict, op=dist.ReduceOp.MAX)
+            if verdict.item() and not fail:
+                fail = "a device-side check or wait failed on another rank"
             torch.cuda.synchronize()
+            if fail and not recoverable:
+                raise mapn.MapnError(-4, fail)
         return fail
 
     fallback_after_failure = None
@@ -730,18 +746,44 @@ def main():
                 power = power_leg(step_batch, hw, ms_per_step=elapsed / a.steps * 1e3)
         except (mapn.MapnError, OSError) as e:
             print(f"[bench] power leg unavailable: {e}", file=sys.stderr, flush=True)
+    sym_plan_desc = None
+    if st.kernel_name.decode() == "force_sym_kernel":
+        try:
+            pl = c.sym_plan()
+            sym_plan_desc = {"waves_per_workgroup": pl.waves, "parts_per_block": pl.parts, "taper": [pl.taper1, pl.taper2],
+                             "wave_bias_older_to_younger": list(pl.wave_bias), "windows": len(pl.windows), "table_sets": pl.sets,
+                             "xcd_mode": {0: "none", 1: "spread", 2: "class-aware (heavy blocks on the faster dies)"}.get(pl.xcd_mode), "class_dies": pl.class_die if pl.xcd_mode == 2 else None}
+        except mapn.MapnError:
+            pass
+    # The plan of this run, replayable: from the seeded initial state exactly 10 steps under the plan that was timed, then the
+    # checksums of both position buffers.  Two runs with the same --xcd-weights (or both with the default plan) print the same pair; runs
+    # whose calibrations differ do not -- the weights are part of the summation order.  Untimed, single GPU.
+    replay = None
+    if world == 1 and dist is None and a.mode == "all_pairs":
+        try:
+            pos0, vel0 = mapn.generate_initial_state(n, seed=a.seed)
+            c.upload_state(pos0, vel0)
+            for _ in range(10):
+                c.Simulate(n, c.GetFenceValue())
+            replay = {"steps": 10, "checksums": [int(x) for x in c.replica_checksum()],
+                      "note": "sum of the 32-bit words of each position buffer after 10 steps from the seeded state under the timed plan: equal for equal plans (pass config.xcd_aware_parts.weights as --xcd-weights to replay a calibrated run)"}
+        except mapn.MapnError as e:
+            print(f"[bench] replay checksum unavailable: {e}", file=sys.stderr, flush=True)
+    # The HBM-bound mode, in the driver's line ("CENTRAL_WELL mode is HBM-bound at 56 B/body -- report GB/s for it"):
+    # CSMain as shipped at the reference's maximum (defines.h:45: 4 194 304 bodies -- 235 MB per step, inside the 256 MiB Infinity Cache) and at
+    # 16 777 216 bodies (940 MB per step: past every cache, the kernel's non-temporal form).  Untimed, behind everything that is; ~0.1 s of steps each.
+    central_well = None
+    if world == 1 and dist is None and a.mode == "all_pairs" and not a.no_central_well_leg and rank == 0:
+        central_well = []
+        c.close()                                              # (the leg's contexts take up to 0.9 GB: give the main context's scratch back first)
+        for nb_cw in (4 * 1024 * 1024, 16 * 1024 * 1024):
+            try:
+                central_well.append(central_well_leg(mapn, local_rank, nb_cw))
+            except (mapn.MapnError, MemoryError) as e:
+                central_well.append({"bodies": nb_cw, "error": str(e)[:200]})
     if rank == 0:
         pairs_per_step = float(n) * float(n) if a.mode == "all_pairs" else float(n)
         value = pairs_per_step * a.steps / elapsed
-        sym_plan_desc = None
-        if st.kernel_name.decode() == "force_sym_kernel":
-            try:
-                pl = c.sym_plan()
-                sym_plan_desc = {"waves_per_workgroup": pl.waves, "parts_per_block": pl.parts, "taper": [pl.taper1, pl.taper2],
-                                 "wave_bias_older_to_younger": list(pl.wave_bias), "windows": len(pl.windows), "table_sets": pl.sets,
-                                 "xcd_mode": {0: "none", 1: "spread", 2: "class-aware (heavy blocks on the faster dies)"}.get(pl.xcd_mode), "class_dies": pl.class_die if pl.xcd_mode == 2 else None}
-            except mapn.MapnError:
-                pass
         out = {
             "metric": "body-pair interactions/s" if a.mode == "all_pairs" else "bodies/s",
             "value": value,
@@ -767,7 +809,8 @@ def main():
                        "repeats": repeats,
                        "step_ms_note": "device time (HIP events on the compute stream) of the steps of the timed region that carried events; ms_per_step is the wall clock over all of them",
                        "p2p_failure": p2p_failure, "fallback_after_failure": fallback_after_failure, "sharded_symmetric_deviation_after_run": sym_dev_after,
-                       "xcd_aware_parts": xcd, "symmetric_plan": sym_plan_desc},
+                       "xcd_aware_parts": xcd, "symmetric_plan": sym_plan_desc, "replay": replay, "central_well": central_well,
+                       "closing_collective_us": ((elapsed - elapsed_idle) * 1e6) if dist is not None else None},
         }
         if a.mode == "all_pairs":
             peak = info.peak_fp32_flops / 1e12
@@ -834,10 +877,42 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_stdout_fd, 1)
         print(json.dumps(out), flush=True)
-    c.close()
+    c.close()                                                  # (idempotent: the central-well leg has already closed it on a single GPU)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def central_well_leg(mapn, device, bodies, seconds=0.1):
+    """The HBM-bound step (MAPN_FORCE_CENTRAL_WELL: nBodyGravityCS.hlsl:86-109 exactly as shipped, 16 + 12 bytes read and 16 + 12 written per
+    body) at `bodies` bodies: wall clock over ~`seconds` of back-to-back steps after a warm-up, no timers; GB/s = 56 x bodies / step time,
+    priced against the 8 TB/s specification and the 6.29 TB/s a float4 copy reaches on this part (MI355X guide)."""
+    import numpy as np
+    rng = np.random.default_rng(1)
+    pos = np.zeros((bodies, 4), np.float32)
+    pos[:, :3] = rng.uniform(-700.0, 700.0, size=(bodies, 3)).astype(np.float32)      # (the two-shell state's value range; the kernel's time does not depend on the data)
+    vel = rng.uniform(-15.0, 15.0, size=(bodies, 3)).astype(np.float32)
+    with mapn.Compute(bodies, device=device, force_mode=mapn.FORCE_CENTRAL_WELL, flags=mapn.FLAG_NO_INIT) as w:
+        w.upload_state(pos, vel)
+        del pos, vel
+        w.set_timers(0)
+        est = HBM_BYTES_PER_BODY * bodies / 6.0e12
+        k = max(20, min(4000, int(seconds / est)))
+        for _ in range(max(10, k // 4)):
+            w.Simulate(bodies, w.GetFenceValue())
+        w.WaitForGpu()
+        best = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(k):
+                w.Simulate(bodies, w.GetFenceValue())
+            w.WaitForGpu()
+            best = min(best, (time.perf_counter() - t0) / k)
+    gbps = HBM_BYTES_PER_BODY * bodies / best / 1e9
+    return {"bodies": bodies, "steps_per_region": k, "ms_per_step": round(best * 1e3, 5), "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4),
+            "frac_of_6.29": round(gbps / 6290.0, 4), "bytes_per_step": HBM_BYTES_PER_BODY * bodies,
+            "form": "non-temporal loads and stores" if HBM_BYTES_PER_BODY * bodies > (320 << 20) else "plain (the step's state fits the 256 MiB Infinity Cache: a cache rate)",
+            "timing": "wall clock over the region (best of 3), untimed by the contract"}
 
 
 def launch_ranks(n_ranks):

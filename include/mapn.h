@@ -100,8 +100,9 @@ typedef enum mapn_init_variant {
                                           (one-sided kernel, block count not a multiple of 8, a partitioned
                                           device) creation succeeds with the default plan and mapn_last_error() says why.  On a SHARDED
                                           context the flag acts when the sharded symmetric step is prepared (mapn_set_gather_algorithm
-                                          4 / 5 / 6): a temporary UNSHARDED context of the same size measures this rank's GPU (no
-                                          collective in it) and the rank's launch is planned with those weights;
+                                          4 / 5 / 6): a temporary UNSHARDED context -- of the same size up to 262 144 bodies, of 65 536 bodies beyond
+                                          (the same dies; about 0.4 s either way) -- measures this rank's GPU (no collective in it) and the rank's
+                                          launch is planned with those weights; where that fails or the weights are not kept mapn_last_error() says why;
                                           mapn_get_sym_plan(...)->xcd_mode != 0 tells whether the weights are in use. */
 
 /*
@@ -365,6 +366,10 @@ int mapn_set_external_gather(mapn_ctx *ctx, int enabled);
  * every step, against checksums their pusher stores behind them (a mismatch makes the next mapn_simulate / mapn_wait_idle /
  * mapn_download_* fail with MAPN_ERR_COMM naming the pusher) -- the analogue of the reference's fence protocol between the
  * two adapters (Compute.cpp:1012, Render.cpp:796-826), which has no data check at all.
+ * COLLECTIVE in effect: every rank must have drained its own work (mapn_wait_idle) and all ranks must have met at a barrier of the
+ * launcher, at the same step, before any of them calls this -- buffer_index names the buffer the NEXT step writes, and a peer that has
+ * already enqueued that step stores its new slice into it while it is being summed here (a torn sum, a false "replicas differ").
+ * bench.py barriers first.
  */
 int mapn_replica_checksum(mapn_ctx *ctx, uint64_t out[2]);
 /* the slice [first, first+count) of bodies this context owns */

@@ -259,6 +259,8 @@ int mapn_p2p_status(mapn_ctx *c)
 int mapn_replica_checksum(mapn_ctx *c, uint64_t out[2])
 {
     if (!c || !out) return fail(MAPN_ERR_INVALID_ARGUMENT, "replica_checksum: null argument");
+    // (both buffers, the one the NEXT step writes included: a peer that has already enqueued that step may be pushing into it while it
+    //  is summed -- the header makes the barrier the caller's duty: every rank drained, all at the same step)
     std::vector<uint32_t> host((size_t)c->n * 4);
     for (uint32_t b = 0; b < 2; b++) {
         if (int rc = mapn_download_buffer(c, b, reinterpret_cast<float *>(host.data()), nullptr)) return rc;

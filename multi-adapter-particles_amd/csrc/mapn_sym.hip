@@ -254,17 +254,20 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
     // The first piece may start inside a meeting (k0 = t0 % 64 steps of it ran in the previous wave): the lane then
     // starts with body (lane + k0) % 64; every later piece starts a meeting.  The NEXT piece's bodies are fetched
     // while the current one is computed (a meeting is ~9 us of a wave's life, a global load ~1-2 us).
+    uint32_t arrived = 1u;                                 // wave-uniform: the peers' position counters were there (nothing to wait for: 1)
     auto first_piece = [&]() {
         if (p.wait_counters) {
             // (the I-block is this rank's own slice; everything else waits for the peers' pushes -- the counters have
             //  normally been there since before this launch started)
             const bool need = lane < p.wait_world && lane != p.wait_rank;
-            (void)wait_counters(p.wait_counters, p.wait_self ? p.wait_rank : lane, need, p.wait_need, p.wait_timeout_ticks, p.wait_status, 1u + lane, p.wait_dead);
+            arrived = wait_counters(p.wait_counters, p.wait_self ? p.wait_rank : lane, need, p.wait_need, p.wait_timeout_ticks, p.wait_status, 1u + lane, p.wait_dead);
         }
         if (t0 < t1) { meeting(t0 >> 6, jb, d, g); pn = body_j(jb * 64u + ((lane + t0) & 63u)); }
         // what the peers pushed is CHECKED here, once per launch, spread over the launch's waves (a few loads per wave, in flight
         // together with the first J-block: the wave waits for that one anyway)
-        if (p.verify_sums)
+        // (only when the counters arrived: after a timeout or the dead word the slices are simply not there, and the check would
+        //  overwrite "peer q is late" with "peer q pushed corrupted data": ADVICE r4)
+        if (p.verify_sums && arrived)
             verify_pushed(pos, p.verify_sums, p.verify_epoch, p.verify_count, p.wait_world, p.wait_rank, p.wait_self,
                           (la * p.parts + s) * WAVES + w, gridDim.x * gridDim.y * WAVES, lane, p.wait_status, p.wait_dead);
     };
@@ -583,6 +586,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     const uint32_t bid = blockIdx.x, nblk = gridDim.x;
     constexpr uint32_t B = 256u / G;                       // bodies per workgroup and pass
     __shared__ uint32_t ok;
+    __shared__ uint32_t bad;                               // a body of this workgroup never got all of its rows (self-validating rows): nothing of it is published
     __shared__ float part[G][3][B];
 
     // diagnostic launches only (MAPN_STAMP_DUMP): wall-clock stamps of the workgroup's phases; null otherwise
@@ -590,6 +594,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         if (p.timeline && threadIdx.x == 0) p.timeline[(size_t)bid * 8u + k] = __builtin_amdgcn_s_memrealtime();
     };
     stamp(0);
+    if (threadIdx.x == 0) bad = 0u;                        // (read only behind the barriers below)
     // split table of the block that ran a meeting: set = class (+ 2 * (LOCAL block mod 8) with XCD-weighted parts)
     const uint32_t *splits = p.tab + p.sets * (p.nwaves + 1u);
     auto split_of = [&](uint32_t a, uint32_t la) { return splits + (size_t)((sym_runs_half(a, p.half_d) ? 0u : 1u) + (p.sets > 2u ? 2u * (la & 7u) : 0u)) * p.max_meetings; };
@@ -765,7 +770,15 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         }
         if (late) {
             __hip_atomic_store(p.status, late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (p.phase == 0u) __hip_atomic_store(p.flags_mine + SYM_DEAD_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (p.phase == 0u) {
+                // A rank whose rows never validated must not go on as if they had: this body is NOT integrated, nothing of
+                // it is stored or pushed, and the workgroup withholds its share of the position counters -- the peers' bounded waits for
+                // this rank's slice then give up too and every rank of the job reports, instead of all of them holding bit-identical
+                // replicas of a wrong state.  (Once dead, every later launch of this rank ends up here at once: no garbage at full speed.)
+                __hip_atomic_store(p.flags_mine + SYM_DEAD_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                continue;
+            }
         }
         ax *= p.mass; ay *= p.mass; az *= p.mass;
         const uint32_t i = p.rank * p.count + il;
@@ -812,6 +825,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     if (p.release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     __syncthreads();
     stamp(5);                                              // position stores acknowledged
+    if (bad) return;                                       // (uniform: read behind the barrier) no share for the counters -- the peers must not take this slice for complete
     if (threadIdx.x < 64u) {
         // every workgroup adds ITS share of SYM_COUNT_PER_LAUNCH to this rank's position counter at every peer (fire and forget: the
         // workgroup leaves at once instead of waiting for a ticket to come back; the shares of a launch sum to
@@ -878,9 +892,7 @@ hipError_t launch_p2p_wait(const uint32_t *counters, uint32_t need, uint32_t wor
 hipError_t launch_force_sym(const SymArgs &a, uint32_t waves, hipStream_t st)
 {
     const dim3 grid(a.shard_nbl ? a.shard_nbl : a.nb, a.parts);
-    // (experiments only: MAPN_SYM_PAD_LDS=bytes of unused dynamic LDS, e.g. 60000 leaves room for ONE workgroup per CU)
-    static const unsigned pad = [] { const char *e = getenv("MAPN_SYM_PAD_LDS"); return e ? (unsigned)strtoul(e, nullptr, 10) : 0u; }();
-    if (waves == 4) hipLaunchKernelGGL((force_sym_kernel<4>), grid, dim3(256), pad, st, a);
+    if (waves == 4) hipLaunchKernelGGL((force_sym_kernel<4>), grid, dim3(256), 0, st, a);
     else if (waves == 8) hipLaunchKernelGGL((force_sym_kernel<8>), grid, dim3(512), 0, st, a);
     else return hipErrorInvalidConfiguration;
     return hipGetLastError();

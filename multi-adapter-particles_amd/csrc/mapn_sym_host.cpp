@@ -47,7 +47,7 @@ bool sym_applies(const mapn_ctx *c, bool sharded)
 {
     if (c->cfg.kernel != MAPN_KERNEL_SYMMETRIC && c->cfg.kernel != MAPN_KERNEL_AUTO) return false;
     if (c->cfg.force_mode != MAPN_FORCE_ALL_PAIRS) return false;
-    const char *off = getenv("MAPN_NO_SYM");
+    const char *off = test_hook("MAPN_NO_SYM");                       // (a hook: MAPN_TEST_HOOKS=1 as well)
     if (off && off[0] == '1' && c->cfg.kernel == MAPN_KERNEL_AUTO) return false;
     if (sharded) return c->cfg.world_size >= 2 && c->count % mapn::SYM_BLOCK == 0 && c->count * (uint32_t)c->cfg.world_size == c->n;
     return c->cfg.world_size == 1 && c->n >= mapn::SYM_BLOCK;   // (a smaller job does not fill one block: one-sided)
@@ -161,7 +161,7 @@ int prepare_sym(mapn_ctx *c, bool sharded)
     std::string err;
     bool built = false;
     // XCD weights: class-aware where it applies (heavy blocks on the fast dies), else spread; MAPN_SYM_XCD_MODE=spread: the A/B of the earlier form
-    static const uint32_t xcd_mode = [] { const char *e = getenv("MAPN_SYM_XCD_MODE"); return (e && e[0] == 's') ? 1u : 0u; }();
+    static const uint32_t xcd_mode = [] { const char *e = test_hook("MAPN_SYM_XCD_MODE"); return (e && e[0] == 's') ? 1u : 0u; }();
     for (const Shape &sh : tries)
         if ((built = mapn::build_sym_plan(nb, gpw, sh.parts, sh.t1, sh.t2, sh.waves, sh.hi, sh.lo, c->sym_xcd_weighted ? c->sym_xcd_w : nullptr, nbl,
                                           sharded ? (uint32_t)c->cfg.rank * nbl : 0u, xcd_mode, c->sym_plan, err))) break;
@@ -234,7 +234,10 @@ StepForm sym_step_form(const mapn_ctx *c, uint32_t active)
     const double Ap = (double)(((uint64_t)active + mapn::SYM_BLOCK - 1u) / mapn::SYM_BLOCK * mapn::SYM_BLOCK);
     const double one = ratio * A * N, full = N * N, split = Ap * Ap + ratio * A * (N - A) + 1.2e8;
     const double other = full_ok ? full : one;
-    if (active >= 8u * mapn::SYM_BLOCK && c->act_failed != active && split < other) return FORM_SYM_SPLIT;   // (fewer than 8 blocks do not fill the device under the symmetric kernel)
+    // (3 % in hand: the symmetric kernel over an awkward block count -- one that fills no whole rounds of the compute units -- runs up to
+    //  7 % behind the model, e.g. 61 440 of 65 536 bodies active: split 0.644 ms against 0.621 for the full form; profiles/r05_partial_active_sweep.txt;
+    //  fewer than 8 blocks do not fill the device under the symmetric kernel at all)
+    if (active >= 8u * mapn::SYM_BLOCK && c->act_failed != active && split < 0.97 * other) return FORM_SYM_SPLIT;
     return full_ok ? FORM_SYM_FULL : FORM_ONE_SIDED;
 }
 
@@ -452,7 +455,7 @@ bool sym_shard_eligible(const mapn_ctx *c, uint32_t active)
 // are the positions of gather algorithm 5 checked against their pushers' checksums (default; MAPN_SYM_PUSH_CHECK=0: the A/B without)
 bool sym_push_check()
 {
-    static const bool on = [] { const char *e = getenv("MAPN_SYM_PUSH_CHECK"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char *e = test_hook("MAPN_SYM_PUSH_CHECK"); return !(e && e[0] == '0'); }();   // (a hook: a stray variable cannot remove the only data check of algorithm 5)
     return on;
 }
 
@@ -521,12 +524,12 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     // arrival flags per (sender, 256-body chunk) behind the receive region -- with PUSHED positions (same box, rank 0 of 65 536 / 8:
     // 93.2 against 93.5 us per step); where the launch also PULLS the peers' positions the workgroups' spread-out ends delay
     // the position counters and the ticket form stays (95.1 against 96.6).  MAPN_SYM_SHARD_CHUNK_FLAGS=0 / 2: never / always (A/B)
-    static const int chunk_mode = [] { const char *e = test_hook("MAPN_SYM_SHARD_CHUNK_FLAGS"); return e ? atoi(e) : 1; }();
-    const bool chunked = chunk_mode == 2 || (chunk_mode == 1 && push);
+    static const int chunk_mode = [] { const char *e = test_hook("MAPN_SYM_SHARD_CHUNK_FLAGS"); return e ? atoi(e) : -1; }();   // (-1: not set -- read ONCE: the form cannot flip between two steps)
+    const bool chunked = chunk_mode == 2 || ((chunk_mode == 1 || chunk_mode == -1) && push);
     h.chunk_flags = chunked ? (uint32_t)mapn::sym_region_chunk_flags_word(world, c->count) : 0u;
     // round 4: no arrival flags at all -- the rows validate themselves (SymShardArgs::poll_rows); MAPN_SYM_SHARD_CHUNK_FLAGS = 0 / 1 / 2 (a
     // hook): the flag forms of round 3, for the A/B
-    h.poll_rows = test_hook("MAPN_SYM_SHARD_CHUNK_FLAGS") ? 0u : 1u;
+    h.poll_rows = chunk_mode >= 0 ? 0u : 1u;
     h.pos_sums = push && sym_push_check() ? (uint32_t)mapn::sym_region_pos_sums_word(world, c->count) : 0u;
     h.status = c->async_status;
     h.rank = rank; h.world = world; h.count = c->count;
@@ -608,15 +611,23 @@ int calibrate_for_shard(mapn_ctx *c)
     if (!sym_applies(c, true) || (c->count / mapn::SYM_BLOCK) % 8u != 0u) return MAPN_OK;
     mapn_config t = c->cfg;
     t.rank = 0; t.world_size = 1; t.flags = MAPN_FLAG_XCD_CALIBRATE;
+    // BOUNDED: beyond 262 144 bodies the temporary context is one of 65 536 -- the same dies under the same kernel, 3.5 MiB of
+    // state and about 0.4 s, instead of a second full state, up to 1 GiB of scratch and whole-N steps of 0.15 s (1 Mi) .. 2.5 s (4 Mi) each
+    if (c->n > 262144u) t.num_particles = 65536u;
     mapn_ctx *tmp = nullptr;
     const std::string keep = g_last_error;
-    if (mapn_create(&t, &tmp) == MAPN_OK && tmp->sym_ready && tmp->sym_plan.xcd_mode != 0u) {
+    std::string note;
+    const int rc = mapn_create(&t, &tmp);
+    if (rc == MAPN_OK && tmp->sym_ready && tmp->sym_plan.xcd_mode != 0u) {
         for (int k = 0; k < 8; k++) c->sym_xcd_w[k] = tmp->sym_plan.xcd_weight[k];
         c->sym_xcd_weighted = true;
+    } else {
+        note = "MAPN_FLAG_XCD_CALIBRATE (sharded): no die weights -- " + (rc != MAPN_OK ? "the temporary calibration context could not be created: " + g_last_error
+                                                                                         : (g_last_error.empty() ? std::string("the calibrated plan was not kept") : g_last_error)) + "; the default plan runs";
     }
     if (tmp) (void)mapn_destroy(tmp);
     (void)hipSetDevice(c->device);
-    g_last_error = keep;
+    g_last_error = note.empty() ? keep : note;             // (never fatal, but no longer silent)
     return MAPN_OK;
 }
 

@@ -75,6 +75,34 @@ def main():
         c.close()
         dist.destroy_process_group()
         return
+    if mode == "symrow_corrupt":
+        # a rank whose reaction rows never validate must not integrate and publish as if they had.  Rank 1 flips one
+        # bit of ONE row of exchange 3 after its tag was formed (test hook; the row is one it sends to itself): its receiving thread waits
+        # out the bound, rank 1 reports -- and because it then neither stores that body nor adds the workgroup's share to its position
+        # counter, rank 0's wait for rank 1's slice gives up as well: BOTH ranks report, nobody holds a wrong replica in silence.
+        if rank == 1:
+            os.environ["MAPN_TEST_HOOKS"] = "1"; os.environ["MAPN_TEST_CORRUPT_ROW"] = "3"
+        c.p2p_setup_torch()
+        c.set_gather_algorithm(int(sys.argv[8]))
+        c.set_timeouts(p2p_ms=400)
+        dist.barrier()
+        failed = None
+        try:
+            for _ in range(3):
+                c.Simulate(n, c.GetFenceValue())
+            c.WaitForGpu()
+        except mapn.MapnError as e:
+            failed = e
+        assert failed is not None and failed.status == -4, f"rank {rank}: the failed exchange went unreported"
+        if rank == 1:
+            assert "never arrived whole" in str(failed) and 0x100 <= c.p2p_status() < 0x200, (str(failed), c.p2p_status())
+        else:
+            assert "rank 1" in str(failed) and c.p2p_status() == 2, (str(failed), c.p2p_status())
+        open(os.path.join(out_dir, f"row_failure_reported_by_rank{rank}"), "w").write(str(failed))
+        dist.barrier()
+        c.close()
+        dist.destroy_process_group()
+        return
     mixed = mode.endswith("_mixed")                     # every third step freezes part of the bodies: the step then runs one-sided
     if mixed:
         mode = mode[:-len("_mixed")]

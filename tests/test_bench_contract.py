@@ -72,11 +72,11 @@ def test_committed_pmc_summaries_belong_to_the_current_kernel_sources():
     spec = importlib.util.spec_from_file_location("bench_for_sha", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
     sha = bench.kernel_source_sha16()
-    for tag, kernel in (("r04_sym", "force_sym_kernel"), ("r04_onesided", "force_sgpr_kernel")):
+    for tag, kernel in (("r05_sym", "force_sym_kernel"), ("r05_onesided", "force_sgpr_kernel")):
         d = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json")))
         assert d["_kernel_source_sha16"] == sha, f"profiles/{tag}_pmc_summary.json is stale: re-run tools/evidence.sh pmc"
     traffic, src = bench.pmc_traffic("force_sym_kernel", 65536, 1)
-    assert traffic and 3e7 < traffic < 2e8 and src.endswith("r04_sym_pmc_summary.json")     # rows: N^2 / 128 + 16 N x parts bytes, + the positions
+    assert traffic and 3e7 < traffic < 2e8 and src.endswith("r05_sym_pmc_summary.json")     # rows: N^2 / 128 + 16 N x parts bytes, + the positions
 
 
 @pytest.mark.gpu
@@ -116,6 +116,39 @@ def test_bench_json_contract():
     rep = d["config"]["repeats"]            # five regions of K steps, listed with their median, for every K; SURVEY 8(d)'s count needs K >= 100
     assert len(rep["ms_per_step"]) == 5 and rep["meets_survey_8d"] is False and abs(rep["ms_per_step"][0] - d["ms_per_step"]) < 1e-4
     assert d["value"] > 3.0e12            # the 40 %-of-peak target is 3.15e12 at kernel level
+    # the HBM-bound mode in the same line: CSMain as shipped at 4 Mi bodies (defines.h:45) and at 16 Mi, GB/s = 56 N / t
+    cw = d["config"]["central_well"]
+    assert [e["bodies"] for e in cw] == [4 * 1024 * 1024, 16 * 1024 * 1024], cw
+    for e in cw:
+        assert "error" not in e, e
+        assert abs(e["GBps"] - 56.0 * e["bodies"] / (e["ms_per_step"] * 1e-3) / 1e9) < 0.01 * e["GBps"]
+        assert 3000.0 < e["GBps"] < 9000.0 and abs(e["frac_of_8TBps"] - e["GBps"] / 8000.0) < 1e-3 and abs(e["frac_of_6.29"] - e["GBps"] / 6290.0) < 1e-3, e
+    assert "non-temporal" in cw[1]["form"] and "Infinity Cache" in cw[0]["form"]
+    rp = d["config"]["replay"]              # 10 steps from the seeded state under the timed plan: the pair of checksums a re-run with the same weights reproduces
+    assert rp["steps"] == 10 and len(rp["checksums"]) == 2 and all(isinstance(x, int) and x > 0 for x in rp["checksums"])
+    assert d["config"]["closing_collective_us"] is None     # (N = 1: no collective closes the region)
+
+
+@pytest.mark.gpu
+def test_bench_replays_a_plan_from_given_xcd_weights():
+    """the headline plan's die weights differ from box to box and run to run, i.e. so does its summation order.  With
+    `--xcd-weights w0,...,w7` (-> mapn_set_sym_xcd_weights, no calibration, no A/B) a run is replayable: two runs with the same weights
+    print identical `config.replay.checksums`, another weighting prints others."""
+    def run(w):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-power-leg",
+                            "--no-central-well-leg", "--prewarm-ms", "50"] + (["--xcd-weights", w] if w else ["--xcd", "off"]), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    w = "1024,900,1000,950,1024,880,990,1010"
+    a, b, other, plain = run(w), run(w), run("1000,1024,950,1024,900,1010,880,990"), run("")
+    for d in (a, b, other):
+        x = d["config"]["xcd_aware_parts"]
+        assert x["mode"] == "given" and x["used"] is True and x["form"] == "class-aware" and d["config"]["symmetric_plan"]["xcd_mode"].startswith("class-aware")
+    assert a["config"]["xcd_aware_parts"]["weights"] == [int(v) for v in w.split(",")]
+    assert a["config"]["replay"]["checksums"] == b["config"]["replay"]["checksums"]
+    assert a["config"]["replay"]["checksums"] != other["config"]["replay"]["checksums"]
+    assert plain["config"]["xcd_aware_parts"]["used"] is False and plain["config"]["replay"]["checksums"] != a["config"]["replay"]["checksums"]
+    assert "central_well" in plain["config"] and plain["config"]["central_well"] is None      # (--no-central-well-leg)
 
 
 @pytest.mark.gpu
@@ -199,6 +232,8 @@ def test_bench_two_ranks_one_gpu_with_the_direct_exchange():
     assert d["config"]["parallelism"] == "bodies sharded x2" and "cpu_baseline" not in d
     # the contract's figure includes the closing collective; the time until every rank's own device was idle (MAX over ranks) is listed beside it
     assert 0.0 < d["ms_per_step_before_closing_barrier"] <= d["ms_per_step"]
+    cc = d["config"]["closing_collective_us"]          # what the ONE closing collective (barrier + verdict) adds to the K steps, MAX over ranks
+    assert cc is not None and abs(cc - (d["ms_per_step"] - d["ms_per_step_before_closing_barrier"]) * 30 * 1e3) < 1.0 and 0.0 <= cc < 20000.0
 
 
 @pytest.mark.gpu

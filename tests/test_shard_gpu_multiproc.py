@@ -116,6 +116,22 @@ def test_corrupted_pushed_position_is_reported_by_the_receiving_rank(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "corruption_reported"))
 
 
+@pytest.mark.parametrize("algo", [5, 4])
+def test_a_rank_whose_rows_never_validate_does_not_publish_and_every_rank_reports(tmp_path, algo):
+    """in the self-validating-rows form a receiver whose rows never validated used to integrate the incomplete sum, store
+    and push the result with valid checksums and add its share to the position counters -- only the failing rank saw MAPN_ERR_COMM,
+    its peers held bit-identical but wrong replicas.  Now that body is not integrated, nothing of it is published and the workgroup
+    withholds its counter share: the peers' bounded waits for the slice give up too.  Two processes, pushed (5) and pulled (4) positions."""
+    port = 29600 + (os.getpid() % 2000) + 23 + algo
+    worker = os.path.join(ROOT, "tests", "shard_gpu_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), "8192", "3", str(tmp_path), "symrow_corrupt", str(algo)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    for r in (0, 1):
+        assert os.path.exists(os.path.join(str(tmp_path), f"row_failure_reported_by_rank{r}"))
+
+
 @pytest.mark.parametrize("mode", ["sym", "sympush"])
 @pytest.mark.parametrize("world,n", [(2, 8192), (4, 8192), (8, 8192), (3, 9216), (2, 6144), (8, 16384)])
 def test_symmetric_step_sharded_over_processes(tmp_path, oracle, world, n, mode):

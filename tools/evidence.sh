@@ -16,6 +16,9 @@
 #   parity1000                   tests/parity_report.py at 65 536 bodies, 1000 steps, all legs -> JSON
 #   ubench                       BASELINE configs[4]: the MFMA-against-packed-VALU A/B (tools/ubench --ab) under rocprofv3 --kernel-trace --stats + the gpu test's report
 #   soak MODE                    several real processes on one GPU, long runs: MODE = flow | sym | sympush (against p2p)
+#   closing                      what the ONE closing collective (barrier + verdict) adds to a timed region of K = 20 / 200 steps: two ranks sharing this GPU
+#                                (gloo) and one rank over the RCCL backend -> closing_cost.txt
+#   partial                      partially active steps: one-sided / full symmetric / split form over a sweep of num_active (tools/partial_sweep.py)
 #   power                        rocm-smi package power / shader clock / temperature while each force kernel runs flat out for 14 s (tools/power_probe.sh)
 set -u
 R=$PWD; W=${1:-suite}; shift || true
@@ -27,6 +30,17 @@ suite)
   sel=${1:-fast}; [ $sel = fast ] && M="gpu and not slow" || M="gpu"
   python -m pytest tests -m "$M" -q > $O/pytest_$sel.txt 2>&1; tail -4 $O/pytest_$sel.txt
   python bench.py > $O/bench_default.json 2> $O/bench_default.err; line default < $O/bench_default.json ;;
+closing)
+  field() { python -c "import sys,json; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print('$1', 'K', d['steps'], 'ms/step %.5f' % d['ms_per_step'], 'before the closing collective %.5f' % d['ms_per_step_before_closing_barrier'], 'closing collective %.1f us per region' % d['config']['closing_collective_us'], '= %.2f %% of the region' % (100 * d['config']['closing_collective_us'] / (d['ms_per_step'] * d['steps'] * 1e3)), d['config']['exchange'])"; }
+  echo "# (ms_per_step - ms_per_step_before_closing_barrier) x K: the time between the LAST rank's device going idle and the closing all-reduce + sync returning, MAX over ranks" | tee $O/closing_cost.txt
+  for K in 20 200 20 200; do
+    python bench.py --gpus 2 --steps $K --warmup 5 --gather sympush --dist-backend gloo --same-device --prewarm-ms 100 --bodies 65536 --p2p-timeout-ms 5000 2> $O/closing_gloo_$K.err | field "2 ranks on one GPU, gloo, 65536 bodies, sharded symmetric step:" | tee -a $O/closing_cost.txt
+  done
+  for K in 20 200 20 200; do
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port $((29800 + K % 90)) bench.py --gpus 1 --steps $K --warmup 5 --force-comm --no-cpu-baseline --prewarm-ms 100 2> $O/closing_rccl_$K.err | field "1 rank, RCCL backend (device tensors), 65536 bodies, all-gather behind every step:" | tee -a $O/closing_cost.txt
+  done ;;
+partial)
+  python tools/partial_sweep.py "$@" 2>&1 | tee $O/partial_sweep.txt ;;
 power)
   bash tools/power_probe.sh > $O/power_probe.txt 2>&1; cat $O/power_probe.txt ;;
 bench)
@@ -36,7 +50,7 @@ stats)
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$k -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --kernel $k > $O/bench_profiled_$k.json 2> $O/bench_profiled_$k.err
   cd $R; f=$(ls -t $(find $O/stats_$k -name "*kernel_stats.csv") | head -1); cp $f $O/kernel_stats_$k.csv; head -5 $f; line "profiled $k" < $O/bench_profiled_$k.json ;;
 pmc)
-  k=${1:-sym}; tag=${2:-r04_$k}; cd /tmp
+  k=${1:-sym}; tag=${2:-r05_$k}; cd /tmp
   P() { d=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$k/$d -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --kernel $k > /dev/null 2> $O/pmc_$k.$d.err; }
   P fetch FETCH_SIZE; P write WRITE_SIZE
   P sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAVES

@@ -607,34 +607,95 @@ def main():
                 c.set_sym_xcd_weights(None)
             except mapn.MapnError:
                 pass
-    verdict = torch.zeros(1, dtype=torch.int32, device=red_dev) if dist is not None else None     # the closing collective's ONE tensor, made before any timed region
+    # The closing collective of a timed region (N > 1): made BEFORE any timed region, never inside one.
+    #   * RCCL backend: the barrier is an all-reduce of one pre-made device word enqueued, stream-ordered, BEHIND this rank's K steps on the
+    #     library's compute stream (torch.cuda.ExternalStream) while the device is still working on them -- its host-side launch cost and
+    #     the peers' arrival overlap the steps, and what is left after the last rank's last step is the collective's kernel and one host
+    #     sync.  The verdict (did a device-side check fail on any rank?) travels in a second collective AFTER the region is closed.
+    #   * gloo (tests: ranks sharing one device, host tensors): one host-side all-reduce is barrier and verdict.
+    verdict = torch.zeros(1, dtype=torch.int32, device=red_dev) if dist is not None else None
+    barrier_word = torch.zeros(1, dtype=torch.int32, device="cuda") if (dist is not None and a.dist_backend == "nccl") else None
+    ev_first = torch.cuda.Event(enable_timing=True) if barrier_word is not None else None
+    ev_last = torch.cuda.Event(enable_timing=True) if barrier_word is not None else None
+    stream_cache = {}
+
+    def compute_stream_of(ctx):
+        """The library's compute stream as a torch stream (one wrapper per context: a rebuilt context has another stream)."""
+        ptr = ctx.compute_stream
+        if ptr not in stream_cache:
+            stream_cache.clear()
+            stream_cache[ptr] = torch.cuda.ExternalStream(ptr, device=torch.device("cuda", local_rank))
+        return stream_cache[ptr]
 
     def run_steps(k, recoverable):
-        """k steps, then the barrier + device sync.  With a peer-to-peer form on N > 1 ranks a device-side check or wait that fails on ANY rank
-        (they are all bounded: every rank gets out of its own) comes back as text on EVERY rank -- the closing collective carries the verdict --
-        instead of leaving the others in a barrier for ever."""
+        """k steps, then the barrier + device sync.  run_steps.closed_at: the moment the region closed (barrier passed, device idle);
+        run_steps.idle_s: how long THIS rank's k steps took without the closing collective (RCCL backend: HIP events on the compute stream
+        around them; gloo: wall clock until its device was idle).  With a peer-to-peer form on N > 1 ranks a device-side check or wait that
+        fails on ANY rank (they are all bounded: every rank gets out of its own) comes back as text on EVERY rank -- the verdict collective
+        carries it -- instead of leaving the others in a barrier for ever."""
         fail = None
+        t_begin = time.perf_counter()
+        ordered = None
+        if barrier_word is not None and gather_fn is None:
+            try:
+                ordered = compute_stream_of(c)
+            except Exception as e:                             # (no stream wrapper: the host-side form below)
+                print(f"[bench rank {rank}] stream-ordered closing barrier unavailable ({e}); closing on the host", file=sys.stderr, flush=True)
+        issued = False
         try:
+            if ordered is not None:
+                ev_first.record(ordered)
             for _ in range(k):
                 step()
-            c.WaitForGpu()
+            if ordered is not None:
+                ev_last.record(ordered)
+                with torch.cuda.stream(ordered):
+                    dist.all_reduce(barrier_word, op=dist.ReduceOp.MAX)      # the barrier: behind this rank's k steps, on the device
+                issued = True
+            else:
+                c.WaitForGpu()
         except mapn.MapnError as e:
             if not recoverable:
                 raise
             fail = str(e)
+        if ordered is not None and not issued:                 # (a step failed to enqueue: the peers' barrier still needs this rank)
+            dist.all_reduce(barrier_word, op=dist.ReduceOp.MAX)
         if torch is not None:
             torch.cuda.synchronize()
-        run_steps.idle_at = time.perf_counter()               # THIS rank's device is idle: its k steps are done (the closing collective is still to come)
-        if dist is not None:
-            # ONE collective closes the region for every form: it is the barrier AND carries the verdict (no tensor is created, no second
-            # collective issued inside the timed region: VERDICT r4 #7); .item() waits for it, the device sync after it finds nothing left
+        run_steps.idle_s = time.perf_counter() - t_begin       # THIS rank's device is idle: its k steps are done
+        if ordered is not None:
+            # stream-ordered form: the device sync above returned behind the barrier collective -- every rank's k steps are done, the region
+            # is closed.  The library's own drain (its bookkeeping of timer events, the check of the status words the device-side waits and
+            # data checks leave) follows OUTSIDE the region; what it finds goes into the verdict.
+            run_steps.closed_at = time.perf_counter()
+            try:
+                c.WaitForGpu()
+            except mapn.MapnError as e:
+                if not recoverable:
+                    raise
+                fail = fail or str(e)
+        if dist is not None and ordered is None:
             verdict.fill_(1 if fail else 0)
-            dist.all_reduce(verdict, op=dist.ReduceOp.MAX)
-            if verdict.item() and not fail:
-                fail = "a device-side check or wait failed on another rank"
+            dist.all_reduce(verdict, op=dist.ReduceOp.MAX)      # (host-side form: this collective IS the barrier, and carries the verdict)
+            bad = bool(verdict.item())
             torch.cuda.synchronize()
-            if fail and not recoverable:
-                raise mapn.MapnError(-4, fail)
+            run_steps.closed_at = time.perf_counter()
+        else:
+            if ordered is None:
+                run_steps.closed_at = time.perf_counter()      # (one GPU, no process group)
+            bad = bool(fail)
+            if dist is not None:
+                try:
+                    run_steps.idle_s = ev_first.elapsed_time(ev_last) * 1e-3 if issued else run_steps.idle_s
+                except RuntimeError:
+                    pass
+                verdict.fill_(1 if fail else 0)                # the verdict: outside the timed region
+                dist.all_reduce(verdict, op=dist.ReduceOp.MAX)
+                bad = bool(verdict.item())
+        if bad and not fail:
+            fail = "a device-side check or wait failed on another rank"
+        if fail and not recoverable:
+            raise mapn.MapnError(-4, fail)
         return fail
 
     fallback_after_failure = None
@@ -648,8 +709,8 @@ def main():
             c.kernel_stats(reset=True)
             t0 = time.perf_counter()
             fail = run_steps(a.steps, recoverable)
-            elapsed = time.perf_counter() - t0
-            elapsed_idle = run_steps.idle_at - t0              # (N > 1: without the closing collective -- reported beside the contract's figure, never instead of it)
+            elapsed = run_steps.closed_at - t0                 # barrier + device sync on both sides of exactly K steps
+            elapsed_idle = min(run_steps.idle_s, elapsed)      # (N > 1: without the closing collective -- reported beside the contract's figure, never instead of it)
         if not fail:
             break
         # A peer-to-peer form that had passed its trial failed in the run itself (a pushed position that did not match its checksum, a
@@ -723,7 +784,7 @@ def main():
             t0 = time.perf_counter()
             if run_steps(a.steps, recoverable):
                 break
-            dt_rep = time.perf_counter() - t0
+            dt_rep = run_steps.closed_at - t0
             if dist is not None:
                 t = torch.tensor([dt_rep], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)

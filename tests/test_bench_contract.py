@@ -140,7 +140,9 @@ def test_bench_replays_a_plan_from_given_xcd_weights():
         assert r.returncode == 0, r.stderr
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     w = "1024,900,1000,950,1024,880,990,1010"
-    a, b, other, plain = run(w), run(w), run("1000,1024,950,1024,900,1010,880,990"), run("")
+    # (another MULTISET of speeds: a permutation of the same eight values gives the same class-aware plan -- and the same bits --
+    #  because the plan sizes a class's parts by its dies' speeds in descending order, whichever dispatch slots hold them)
+    a, b, other, plain = run(w), run(w), run("1024,1000,960,1000,990,1000,940,1000"), run("")
     for d in (a, b, other):
         x = d["config"]["xcd_aware_parts"]
         assert x["mode"] == "given" and x["used"] is True and x["form"] == "class-aware" and d["config"]["symmetric_plan"]["xcd_mode"].startswith("class-aware")

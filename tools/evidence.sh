@@ -48,14 +48,16 @@ bench)
 stats)
   k=${1:-sym}; cd /tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$k -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --kernel $k > $O/bench_profiled_$k.json 2> $O/bench_profiled_$k.err
-  cd $R; f=$(ls -t $(find $O/stats_$k -name "*kernel_stats.csv") | head -1); cp $f $O/kernel_stats_$k.csv; head -5 $f; line "profiled $k" < $O/bench_profiled_$k.json ;;
+  cd $R; f=$(ls -t $(find $O/stats_$k -name "*kernel_stats.csv") | head -1); cp $f $O/kernel_stats_$k.csv; head -5 $f; line "profiled $k" < $O/bench_profiled_$k.json
+  rm -rf $O/stats_$k ;;     # (the raw trace: gpurun merges at most 64 MiB back)
 pmc)
   k=${1:-sym}; tag=${2:-r05_$k}; cd /tmp
   P() { d=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$k/$d -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --kernel $k > /dev/null 2> $O/pmc_$k.$d.err; }
   P fetch FETCH_SIZE; P write WRITE_SIZE
   P sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAVES
   P grbm GRBM_GUI_ACTIVE GRBM_COUNT
-  cd $R; python tools/pmc_summary.py $O/pmc_$k $tag > $O/pmc_summary_$k.txt 2>&1; tail -30 $O/pmc_summary_$k.txt ;;
+  cd $R; python tools/pmc_summary.py $O/pmc_$k $tag > $O/pmc_summary_$k.txt 2>&1; tail -30 $O/pmc_summary_$k.txt
+  cp profiles/${tag}_pmc_summary.txt profiles/${tag}_pmc_summary.json $O/; rm -rf $O/pmc_$k ;;     # (summaries travel back in gpurun_out; the raw counter files stay on the box)
 issue)
   t=${1:-.}; cd /tmp
   P() { d=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$d -- python3 $R/$t/bench.py --steps 12 --warmup 3 --no-cpu-baseline > /dev/null 2> $O/$d.err; }

@@ -5,6 +5,9 @@
  * (reference/Particles/Compute.h:33-78 + AdapterShared.h:51-60), whose only caller is
  * `class Particles` (Particles.cpp) from one host thread.  Each entry point below names the
  * reference member it replaces.  Plain pointers and sizes only; no C++ or torch types.
+ * What is NOT the reference's surface -- launch plans, XCD calibration, kernel statistics, stamped diagnostics: the entry points the
+ * bench harness and the parity tests use to look inside -- lives in mapn_tuning.h and is versioned separately: a caller that
+ * replaces `class Compute` (compat/Compute.hpp) needs this header alone.
  *
  * Conventions
  *   - every function returning `int` returns MAPN_OK (0) or a negative mapn_status; the
@@ -33,7 +36,8 @@ extern "C" {
 #pragma GCC visibility push(default)   /* libmapn.so is built with -fvisibility=hidden: what this header declares is ALL it exports */
 #endif
 
-#define MAPN_ABI_VERSION 3   /* 3 (round 4): windows_capacity in the two plan queries, mapn_replica_checksum, MAPN_FLAG_XCD_CALIBRATE */
+#define MAPN_ABI_VERSION 4   /* 4 (round 5): this header is the Compute surface + the sharded mode only -- plans, calibration, kernel statistics and the
+                                other tuning / introspection entry points moved to mapn_tuning.h, versioned on their own (MAPN_TUNING_ABI_VERSION) */
 
 typedef struct mapn_ctx mapn_ctx;
 
@@ -64,7 +68,8 @@ typedef enum mapn_kernel {
                                    keep the reaction rows within MAPN_SYM_MAX_MB (default 1024), and is allocated by
                                    mapn_create -- which fails if the memory is not to be had.  Under
                                    MAPN_KERNEL_AUTO the same failure only selects the one-sided kernel
-                                   (mapn_get_sym_plan tells why). */
+                                   (mapn_get_sym_plan, mapn_tuning.h, tells why).  A step with num_active < N runs whichever of three
+                                   forms is cheapest for that count: see mapn_simulate. */
     /* No MFMA variant (BASELINE configs[4] A/B; re-measured by `pytest -m gpu` on every run since round 4:
        tests/test_gpu_mfma_ab.py): on gfx950 the f32 MFMA shapes do NOT run beside the packed fp32 VALU stream
        of the same SIMD -- their times add (16 v_pk_fma_f32 + one v_mfma_f32_16x16x4_f32: 106 cycles against
@@ -165,6 +170,11 @@ int mapn_destroy(mapn_ctx *ctx);
  * yet, the compute stream parks until it does -- bounded by mapn_set_timeouts, default 10 s, after
  * which the next call returns MAPN_ERR_STATE).  Pass 0 when there is no consumer.  With
  * MAPN_FLAG_STRICT_CONSUMER an unsignalled value is a loud MAPN_ERR_STATE instead of a queued wait.
+ * A PARTIALLY ACTIVE all-pairs step (num_active < N) runs the cheapest of three forms for that (N, num_active) -- always the same one,
+ * so results stay bit-reproducible: the full symmetric step whose reduce launch stops early; the one-sided kernel over active x N; or
+ * the SPLIT form (active x active under the symmetric kernel with a plan of the active blocks alone + active x frozen one-sided: measured
+ * 1.14 - 1.47 x the one-sided step from half the bodies active upwards).  The FIRST step with a new count builds the split form's plan
+ * and scratch (a host-side plan, a table upload, allocations behind a drained stream); the steps after it do not allocate.
  * Afterwards the fence value is +1 and the buffer index flipped (MoveToNextFrame,
  * Compute.cpp:993-1004).  A device-side wait that timed out in an EARLIER step (peer-to-peer
  * exchange, consumer fence) makes this call fail with MAPN_ERR_COMM / MAPN_ERR_STATE.
@@ -375,7 +385,7 @@ int mapn_replica_checksum(mapn_ctx *ctx, uint64_t out[2]);
 /* the slice [first, first+count) of bodies this context owns */
 int mapn_shard_range(const mapn_ctx *ctx, uint32_t *first, uint32_t *count);
 
-/* ---- introspection for the bench harness ---- */
+/* ---- the device (replaces the adapter enumeration of Particles.cpp:96-123) ---- */
 typedef struct mapn_device_info {
     char     name[128];
     char     arch[64];
@@ -389,157 +399,6 @@ typedef struct mapn_device_info {
 int mapn_get_device_info(int device, mapn_device_info *out);
 int mapn_device_count(void);
 
-/* Force-kernel statistics accumulated by mapn_simulate: every step records HIP events on the
- * compute stream around the all-pairs force launch(es); avg_seconds is their mean device time
- * since the last reset.  This is what bench.py's roofline line is computed from. */
-typedef struct mapn_kernel_stats {
-    char     kernel_name[64];
-    uint64_t launches;
-    double   avg_seconds;
-    uint32_t grid_x, grid_y, block_x;   /* of the force launch mapn_simulate enqueued last */
-    uint32_t bodies_per_lane, j_splits; /* j_splits = grid_y * (block_x / 64) chunks of 64-body tiles */
-    uint32_t fused;              /* 1: the integrator runs inside the force launch (one launch per step) */
-    uint32_t grid_z;             /* j-segments per launch (1 unless the sharded overlap structure) */
-    uint32_t epilogue;           /* 0 partial rows + reduce_integrate launch, 1 fused in the workgroup,
-                                    2 last-arriver ticket (rows summed by the last workgroup of the i-tile),
-                                    3 the symmetric kernel's rows + sym_reduce_integrate launch */
-    uint32_t force_launches_per_step;
-    uint32_t split_active;       /* != 0: the step enqueued last was a PARTIALLY ACTIVE one in its split form -- these many bodies met each other under
-                                    the symmetric kernel (a plan of the active blocks alone), the frozen ones acted on them through one one-sided
-                                    launch in front (kernel_name "force_sym_kernel", grid of the symmetric launch) */
-} mapn_kernel_stats;
-int mapn_get_kernel_stats(mapn_ctx *ctx, int reset, mapn_kernel_stats *out);
-/* The individual samples behind those means: for every step since the last reset that carried timer events (every T-th,
- * mapn_set_timers) its index among the steps since the reset, the step's device time and its force launch's device time
- * (0 when the step had none), in step order -- how the step time is SPREAD over a run.  *count = samples held (at most 4096);
- * at most `capacity` are copied. */
-int mapn_get_step_samples(mapn_ctx *ctx, uint32_t *step_index, float *step_ms, float *force_ms, uint32_t capacity, uint32_t *count);
-
-/* Tuning hooks (tests exercise every kernel variant through these; AUTO restores the default).
- * bodies_per_lane in {2,4,8}, waves in {1,2,4,8,16}, sb >= 1 (j-split across workgroups).
- * fused: 0 = two launches (partial rows + reduce_integrate_kernel), 1 = one launch (integrator in
- * the workgroup when sb == 1, else by the last-arriver ticket), 2 = ticket form even when sb == 1.
- * Summation order (what an order-matched checker must reproduce): the 64-body tiles of the j-range
- * are cut into S = sb * waves chunks (the first tiles % S chunks take one tile more); a chunk is
- * summed over ascending j into a zero accumulator with fused multiply-adds; the `waves` chunk sums
- * of a workgroup are added in ascending order, then the sb row sums in ascending order; the mass
- * multiplies the total. */
-int mapn_set_force_plan(mapn_ctx *ctx, int kernel, uint32_t bodies_per_lane, uint32_t waves,
-                        uint32_t sb, int fused);
-/*
- * The SYMMETRIC kernel's launch plan (csrc/mapn_sym_plan.h).  A step is made in `windows` force launches (partner
- * distance groups [g0, g1) each; one launch while the reaction rows fit MAPN_SYM_MAX_MB, default 1024), each
- * followed by a reduce launch that carries the running sum; inside a launch `parts` workgroups of `waves` waves
- * share the meetings of every 1024-body block, cut to the STEP so that every wave carries the same cost.
- * windows[4 k ..] = {g0, g1, meetings of a class-0 block, of a class-1 block}; tables = per window
- * bounds[sets][parts * waves + 1] (first linear step of every wave) then split[sets][max_meetings] (the part whose
- * head row holds the last steps of a meeting cut between two workgroups, 0xffffffff otherwise); class 0 = the blocks
- * that also run the half-ring group (even block count; of the pair (p, p + nb / 2) block p when p is even, block p + nb / 2 when p is odd); set = class, or class + 2 * (block mod 8) when the
- * parts are XCD-weighted (sets = 16; the block counted within its launch).  What an order-matched checker must reproduce
- * (the CPU checker restates exactly this): per wave one fused-multiply-add chain per body over its steps in
- * order; the workgroup's waves added in ascending order into ONE row per (block, part); the reaction of a meeting as
- * two chains (even / odd bodies of the lane) folded once per piece, pieces of a cut meeting added first steps + last
- * steps; per body: rows of its block in ascending part order, then per group in ascending order the meeting's row and
- * its head row, windows in ascending order; the mass multiplies the total.
- * (The tables array holds info->windows * info->table_stride words, then the info->wgmap_entries words of the class-aware workgroup map.
- *  launch_a0: first block of the launch in the whole job -- a rank's first block, 0 unsharded; xcd_mode 0: class-aware where it applies,
- *  else spread; 1: spread only.)
- * mapn_sym_plan_describe computes the plan of a shape WITHOUT a device (CPU tests, the oracle);
- * mapn_get_sym_plan returns the plan a context runs (a0 / nbl: first block and block count of this rank when sharded);
- * mapn_set_sym_plan is the tuning hook (waves 4 or 8; taper1 = taper2 = 0: equal parts; groups_per_window 0: as many
- * as fit; waves = parts = 0: back to the default shape) -- it re-allocates the scratch, never call it per step.
- * WAVE BIAS (wave_bias_hi : wave_bias_lo; 0 : 0 or equal = none).  A SIMD holds two of this kernel's waves and serves the older
- * one first; in an 8-wave workgroup (one per compute unit) waves 0 .. 3 are the older wave of their SIMDs, and the plan gives
- * them hi / lo times the steps of waves 4 .. 7 so that both end together (measured optimum about 10 : 3).  The defaults: 8-wave
- * workgroups with 10 : 3 where a launch's workgroups fill whole rounds of the compute units, 3 : 1 for a sharded launch; the
- * equal-wave 4-wave shape otherwise and whenever several ranks share one device.  Still one linear run of steps per wave, so
- * everything above holds unchanged.
- */
-typedef struct mapn_sym_plan_info {
-    uint32_t nb, groups, windows;
-    uint32_t parts, taper1, taper2, waves;
-    uint32_t wave_bias[2];       /* share of a workgroup's steps: first half of its waves : second half (1 : 1 = equal) */
-    uint32_t brows, max_meetings, table_stride;
-    uint32_t sets;               /* table sets per window: 2 (one per class) or 16 (class + 2 * (block mod 8): XCD-weighted parts) */
-    uint32_t xcd_weight[8];      /* the relative die speeds the parts were weighted with (xcd_mode != 0), else 0 */
-    uint32_t xcd_mode;           /* 0: no XCD weights; 1: "spread" (16 table sets: the parts of every block spread over the dies); 2: "class-aware"
-                                    (round 4): the blocks that run the half-ring group -- 3.1 % more steps at 65 536 bodies -- put their parts on
-                                    the four FASTEST dies, the others on the four slowest, every part sized by its die (2 table sets + wgmap) */
-    uint32_t wgmap_offset, wgmap_entries;   /* class-aware: tables[wgmap_offset + y * blocks + x] = (block of the launch << 16) | part that
-                                               workgroup (x, y) of the grid runs; wgmap_entries = blocks * parts (0: none) */
-    uint32_t la_flip;            /* no weights, a sharded launch of one block per die: 1 = workgroup (x, y) runs block x ^ 1, which puts the blocks with the
-                                    half-ring group on the odd dispatch slots -- the faster dies by 2 - 3 % on every box measured */
-    uint32_t class_die[8];       /* class-aware: dispatch slots (workgroup number mod 8) of class 0's four dies, then class 1's, fastest first */
-    uint32_t a0, nbl;
-    uint32_t active_compute_units;  /* sharded: compute units that really take this process's workgroups (probed; a CU mask leaves fewer) */
-    uint32_t exchange_workgroups;   /* sharded: most workgroups the exchange launch may have (they must all be resident at once) */
-    uint64_t scratch_bytes;      /* device memory the symmetric step holds (rows, running sum, tables) */
-    char     error[256];         /* why a shape was refused / why the kernel does not run */
-} mapn_sym_plan_info;
-int mapn_sym_plan_describe(uint32_t nb, uint32_t groups_per_window, uint32_t parts, uint32_t taper1, uint32_t taper2,
-                           uint32_t waves, uint32_t wave_bias_hi, uint32_t wave_bias_lo, const uint32_t *xcd_weights,
-                           uint32_t launch_blocks, uint32_t launch_a0, uint32_t xcd_mode, mapn_sym_plan_info *info,
-                           uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity);
-/* Two-call pattern: first with windows = tables = NULL to learn info->windows and info->windows * info->table_stride, then with
- * buffers; BOTH capacities are counted in uint32 (4 per window) and checked -- a caller that sized its arrays from an earlier plan
- * (before mapn_set_sym_plan / another MAPN_SYM_MAX_MB changed the window count) gets MAPN_ERR_INVALID_ARGUMENT, not an overflow. */
-int mapn_get_sym_plan(mapn_ctx *ctx, mapn_sym_plan_info *info, uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity);
-int mapn_set_sym_plan(mapn_ctx *ctx, uint32_t waves, uint32_t parts, uint32_t taper1, uint32_t taper2, uint32_t groups_per_window,
-                      uint32_t wave_bias_hi, uint32_t wave_bias_lo);
-/*
- * The plan of a PARTIALLY ACTIVE step in its split form (mapn_kernel_stats.split_active != 0): the `active` = roundup64(num_active)
- * bodies meet each other under the symmetric kernel with the plan returned in info / windows / tables (a job of `active` bodies: nb =
- * ceil(active / 1024) blocks, the default shape for that size, the context's XCD weights where they apply), and the `frozen` bodies
- * [active, N) act on them through ONE launch of the one-sided kernel in front whose partial rows the first window's reduce launch
- * adds before its own.  What an order-matched checker must reproduce: per active body first the frozen rows -- the j-range
- * [active, N) cut and summed exactly as mapn_set_force_plan describes for (frozen_waves, frozen_sb), rows added in ascending order to
- * zero -- then the symmetric plan's order over the bodies [0, active) as for mapn_get_sym_plan; the mass multiplies the total.
- * MAPN_ERR_STATE until such a step has run.  Same two-call pattern and capacity checks as mapn_get_sym_plan.
- */
-typedef struct mapn_split_info {
-    uint32_t active, frozen;
-    uint32_t frozen_kernel;          /* mapn_kernel of the launch over the frozen bodies (MAPN_KERNEL_SCALAR / MAPN_KERNEL_LDS) */
-    uint32_t frozen_bodies_per_lane, frozen_waves, frozen_sb;
-    uint32_t reserved[2];
-} mapn_split_info;
-int mapn_get_split_plan(mapn_ctx *ctx, mapn_split_info *split, mapn_sym_plan_info *info, uint32_t *windows, uint64_t windows_capacity,
-                        uint32_t *tables, uint64_t tables_capacity);
-/*
- * XCD-aware parts.  The eight XCDs of an MI355X do not run at one speed under this kernel (measured 0.538 - 0.570 us per
- * step, the same dies slow on every launch of a box) while a launch gives every die the same work, so it ends with the
- * slowest one.  mapn_calibrate_sym_xcds runs `steps` stamped steps (REAL steps, like mapn_measure_clock) and returns the
- * dies' relative speeds (1024 = the fastest), indexed by DISPATCH SLOT -- workgroup number mod 8, not the XCC_ID register; mapn_set_sym_xcd_weights makes the plan spread the parts of every block over
- * the dies (workgroup (x, y) of the grid runs part y of block (x + y) mod blocks) with a share of the block's steps
- * proportional to the speed of the die a part runs on (NULL or equal weights: back to the default plan).  Takes effect where
- * a launch covers a multiple of 8 blocks.  The weights are part of the plan: results are bit-reproducible for given weights,
- * and differ between weightings like between any two summation orders.  bench.py calibrates and says so in its line.
- */
-int mapn_calibrate_sym_xcds(mapn_ctx *ctx, int steps, uint32_t out_weights[8]);
-int mapn_set_sym_xcd_weights(mapn_ctx *ctx, const uint32_t *weights8);
-
-/* Sharded mode: switch the own/remote overlap structure (MAPN_FLAG_SHARD_OVERLAP) at run time, so a
- * launcher can time both structures on the node it runs on; all ranks must agree. */
-int mapn_set_shard_overlap(mapn_ctx *ctx, int enabled);
-
-/* The shader clock the chip HOLDS under this kernel (it lowers its clock under load): runs `steps`
- * ordinary steps whose force launch additionally stamps s_memtime / s_memrealtime around every
- * wave's pair loop into a scratch buffer nothing else reads (no stamp executes in a normal launch),
- * and reports the median over waves of d(s_memtime) / d(s_memrealtime) x 100 MHz.
- * SIDE EFFECTS: these are real steps -- positions, velocities, fence value and buffer index advance exactly as by
- * `steps` calls of mapn_simulate(ctx, N, 0) (no consumer wait); in a sharded job every rank must call it.  Scalar-cache
- * and symmetric force kernels, all-pairs mode only: anything else is refused BEFORE a step is taken. */
-typedef struct mapn_clock_info {
-    double   shader_clock_ghz;       /* median over the stamped waves of the last diagnostic launch */
-    double   shader_clock_ghz_p10, shader_clock_ghz_p90;
-    double   median_wave_cycles;     /* shader cycles one wave spent in its pair loop */
-    uint32_t waves_stamped, steps;
-} mapn_clock_info;
-int mapn_measure_clock(mapn_ctx *ctx, int steps, mapn_clock_info *out);
-
-/* Step timers: 0 = off, T >= 1 = record the event pair on every T-th step (default 1: every
- * step, like the reference's D3D12GpuTimer).  Each hipEventRecord costs a few microseconds of
- * queue time, which matters once a sharded step is ~0.1 ms. */
-int mapn_set_timers(mapn_ctx *ctx, int interval);
 /* The compute stream (hipStream_t) steps are enqueued on, for callers that record events. */
 void *mapn_compute_stream(mapn_ctx *ctx);
 

@@ -88,11 +88,12 @@ class SplitInfo(C.Structure):
                 ("frozen_waves", C.c_uint32), ("frozen_sb", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
-# every symbol include/mapn.h declares: (name, restype, argtypes)
+# every symbol include/mapn.h and include/mapn_tuning.h declare: (name, restype, argtypes)
 _fp = C.POINTER(C.c_float)
 _ctx = C.c_void_p
 SIGNATURES = {
     "mapn_abi_version": (C.c_int, []),
+    "mapn_tuning_abi_version": (C.c_int, []),
     "mapn_last_error": (C.c_char_p, []),
     "mapn_config_default": (C.c_int, [C.POINTER(Config)]),
     "mapn_create": (C.c_int, [C.POINTER(Config), C.POINTER(_ctx)]),

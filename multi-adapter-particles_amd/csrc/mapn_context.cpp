@@ -560,6 +560,8 @@ extern "C" {
 
 int mapn_abi_version(void) { return MAPN_ABI_VERSION; }
 
+int mapn_tuning_abi_version(void) { return MAPN_TUNING_ABI_VERSION; }
+
 const char *mapn_last_error(void) { return g_last_error.c_str(); }
 
 int mapn_config_default(mapn_config *cfg)

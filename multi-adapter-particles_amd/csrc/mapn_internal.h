@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "mapn.h"
+#include "mapn_tuning.h"
 #include "mapn_comm.h"
 #include "mapn_kernels.h"
 #include "mapn_sym_plan.h"

@@ -4,7 +4,7 @@
 #include <algorithm>
 #include <cstdio>
 
-#include "mapn.h"
+#include "mapn_tuning.h"
 
 namespace mapn {
 

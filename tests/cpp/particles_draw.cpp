@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "Compute.hpp"
+#include "mapn_tuning.h"   // (this TEST looks at the launch plan; the shim itself needs mapn.h alone)
 
 using mapn::Compute;
 

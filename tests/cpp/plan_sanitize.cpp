@@ -8,7 +8,7 @@
 #include <cstring>
 #include <vector>
 
-#include "mapn.h"
+#include "mapn_tuning.h"
 
 int main()
 {

@@ -14,10 +14,16 @@ from mapn import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    hdr = open(os.path.join(ROOT, "include", "mapn.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(mapn_[a-z_0-9]+)\s*\(", hdr)))
+HEADERS = ("mapn.h", "mapn_tuning.h")     # the drop-in boundary (the Compute surface + the sharded mode) / tuning and introspection, versioned apart
+
+
+def _declared(headers=HEADERS):
+    names = set()
+    for h in headers:
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        names |= set(re.findall(r"\b(mapn_[a-z_0-9]+)\s*\(", hdr))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -37,8 +43,29 @@ def test_library_exports_nothing_but_the_declared_c_abi():
     assert funcs == _declared(), sorted(set(funcs) ^ set(_declared()))
 
 
+def test_the_two_headers_split_the_boundary_from_the_tuning_surface():
+    """include/mapn.h is what replaces a member of the reference's `class Compute` (+ the state hand-off and the sharded
+    mode); plans, calibration, statistics and diagnostics live in include/mapn_tuning.h with their own version.  No name is declared
+    twice; the shim a Particles.cpp-style caller links (compat/Compute.hpp) needs mapn.h alone."""
+    core, tuning = set(_declared(("mapn.h",))), set(_declared(("mapn_tuning.h",)))
+    assert not (core & tuning)
+    for n in ("mapn_create", "mapn_create_from", "mapn_destroy", "mapn_simulate", "mapn_fence_value", "mapn_wait_idle", "mapn_get_shared_handles",
+              "mapn_adopt_position_buffers", "mapn_reset_from_async", "mapn_last_step_seconds", "mapn_comm_init", "mapn_set_gather_algorithm"):
+        assert n in core, n
+    for n in ("mapn_get_sym_plan", "mapn_set_sym_plan", "mapn_sym_plan_describe", "mapn_get_split_plan", "mapn_calibrate_sym_xcds", "mapn_set_sym_xcd_weights",
+              "mapn_get_kernel_stats", "mapn_set_force_plan", "mapn_measure_clock", "mapn_set_timers", "mapn_tuning_abi_version"):
+        assert n in tuning, n
+    assert len(tuning) == 13 and len(core) == 52, (len(tuning), len(core))
+    shim = open(os.path.join(ROOT, "multi-adapter-particles_amd", "compat", "Compute.hpp")).read()
+    assert '#include "mapn.h"' in shim and "mapn_tuning.h" not in shim
+    used = set(re.findall(r"\b(mapn_[a-z_0-9]+)\s*\(", shim))
+    assert used and used <= core, used - core
+
+
 def test_abi_version_and_timer_name(lib):
-    assert lib.mapn_abi_version() == 3
+    assert lib.mapn_abi_version() == 4 and lib.mapn_tuning_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "mapn.h")).read() + open(os.path.join(ROOT, "include", "mapn_tuning.h")).read()
+    assert "#define MAPN_ABI_VERSION 4" in hdr and "#define MAPN_TUNING_ABI_VERSION 1" in hdr
     assert lib.mapn_timer_name() == b"simulate ms"          # Compute.cpp:446
 
 

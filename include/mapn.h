@@ -77,7 +77,7 @@ typedef enum mapn_kernel {
        upper bounds: -7 % ... -65 %; the product's scalar kernel at one rank's share of the 1 048 576-body
        job, loads and integrator included, beats all of them), and the two that remove the most VALU work
        lose 3 decimal digits (profiles/r04_ubench_ab.txt, profiles/r04_ubench_ab_rocprofv3_kernel_stats.csv,
-       profiles/r02_mfma_recast_error.txt, DESIGN.md section 3.1). */
+       profiles/r02_mfma_recast_error.txt, DESIGN.md section 7). */
 } mapn_kernel;
 
 /* The three #if variants of LoadParticles (Compute.cpp:581-583), all seeded per body. */

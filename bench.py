@@ -67,6 +67,7 @@ def parse():
                          "every part by the die it runs on; auto keeps them only if an untimed A/B against the default plan wins")
     ap.add_argument("--xcd-weights", default="", help="w0,...,w7: run the symmetric kernel under THESE relative die speeds (1024 = the fastest; mapn_set_sym_xcd_weights) -- no "
                                                       "calibration, no A/B: replays the plan of an earlier run's line (config.xcd_aware_parts.weights) bit for bit")
+    ap.add_argument("--no-partial-leg", action="store_true", help="skip the untimed ~0.3 s behind the run that measures partially active steps (num_active = N/2, 3N/4) against the one-sided step (single GPU)")
     ap.add_argument("--no-central-well-leg", action="store_true", help="skip the untimed ~0.3 s behind the run that measures the HBM-bound CENTRAL_WELL step at 4 Mi and 16 Mi bodies (single GPU)")
     ap.add_argument("--overlap", action="store_true", help="sharded mode: own-segment launch overlapped with the all-gather")
     ap.add_argument("--trial-seconds", type=float, default=90.0,
@@ -830,6 +831,19 @@ def main():
                       "note": "sum of the 32-bit words of each position buffer after 10 steps from the seeded state under the timed plan: equal for equal plans (pass config.xcd_aware_parts.weights as --xcd-weights to replay a calibrated run)"}
         except mapn.MapnError as e:
             print(f"[bench] replay checksum unavailable: {e}", file=sys.stderr, flush=True)
+    # PARTIALLY ACTIVE steps in the driver's line: num_active = N/2 and 3N/4 -- the form the library picks by itself (the split
+    # form at this size) against the one-sided step round 4 ran there, selected through the MAPN_PARTIAL_FORM hook for the comparison only.
+    # Untimed, ~0.3 s, single GPU, after everything that is timed or checked.
+    partial = None
+    if world == 1 and dist is None and a.mode == "all_pairs" and not a.no_partial_leg and n >= 16384 and st.kernel_name.decode() == "force_sym_kernel":
+        try:
+            partial = partial_active_leg(mapn, c, n)
+        except mapn.MapnError as e:
+            print(f"[bench] partial-active leg unavailable: {e}", file=sys.stderr, flush=True)
+        finally:
+            os.environ.pop("MAPN_PARTIAL_FORM", None)
+            if partial_active_leg.set_hooks:
+                os.environ.pop("MAPN_TEST_HOOKS", None)
     # The HBM-bound mode, in the driver's line ("CENTRAL_WELL mode is HBM-bound at 56 B/body -- report GB/s for it"):
     # CSMain as shipped at the reference's maximum (defines.h:45: 4 194 304 bodies -- 235 MB per step, inside the 256 MiB Infinity Cache) and at
     # 16 777 216 bodies (940 MB per step: past every cache, the kernel's non-temporal form).  Untimed, behind everything that is; ~0.1 s of steps each.
@@ -870,7 +884,7 @@ def main():
                        "repeats": repeats,
                        "step_ms_note": "device time (HIP events on the compute stream) of the steps of the timed region that carried events; ms_per_step is the wall clock over all of them",
                        "p2p_failure": p2p_failure, "fallback_after_failure": fallback_after_failure, "sharded_symmetric_deviation_after_run": sym_dev_after,
-                       "xcd_aware_parts": xcd, "symmetric_plan": sym_plan_desc, "replay": replay, "central_well": central_well,
+                       "xcd_aware_parts": xcd, "symmetric_plan": sym_plan_desc, "replay": replay, "central_well": central_well, "partial_active": partial,
                        "closing_collective_us": ((elapsed - elapsed_idle) * 1e6) if dist is not None else None},
         }
         if a.mode == "all_pairs":
@@ -942,6 +956,45 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def partial_active_leg(mapn, c, n, seconds=0.04):
+    """ms per step with num_active = N/2 and 3N/4 (Particles.cpp:391-394's slider; Compute.cpp:1041): the form the library picks, and the
+    one-sided step over active x N it ran there until round 4 (MAPN_PARTIAL_FORM=one, a test hook, for this comparison only)."""
+    partial_active_leg.set_hooks = os.environ.get("MAPN_TEST_HOOKS") != "1"
+    out = []
+
+    def ms(na, k):
+        for _ in range(max(4, k // 4)):
+            c.Simulate(na, c.GetFenceValue())
+        c.WaitForGpu()
+        best = float("inf")
+        for _ in range(2):
+            t0 = time.perf_counter()
+            for _ in range(k):
+                c.Simulate(na, c.GetFenceValue())
+            c.WaitForGpu()
+            best = min(best, (time.perf_counter() - t0) / k * 1e3)
+        return best
+    c.set_timers(0)
+    for num, den in ((1, 2), (3, 4)):
+        na = n * num // den // 64 * 64
+        k = max(4, min(200, int(seconds / (0.6e-3 * (n / 65536.0) ** 2 * num / den))))
+        os.environ.pop("MAPN_PARTIAL_FORM", None)
+        t_pick = ms(na, k)
+        st = c.kernel_stats()
+        form = "split" if st.split_active else ("full symmetric" if st.kernel_name.decode() == "force_sym_kernel" else "one-sided")
+        os.environ["MAPN_TEST_HOOKS"] = "1"; os.environ["MAPN_PARTIAL_FORM"] = "one"
+        t_one = ms(na, k)
+        os.environ.pop("MAPN_PARTIAL_FORM")
+        if partial_active_leg.set_hooks:
+            os.environ.pop("MAPN_TEST_HOOKS", None)
+        out.append({"num_active": na, "form_picked": form, "ms_per_step": round(t_pick, 5), "ms_per_step_one_sided": round(t_one, 5),
+                    "speedup_over_one_sided": round(t_one / t_pick, 4), "interactions_per_s": float(na) * n / (t_pick * 1e-3)})
+    return out
+
+
+partial_active_leg.set_hooks = False
 
 
 def central_well_leg(mapn, device, bodies, seconds=0.1):

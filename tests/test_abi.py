@@ -192,3 +192,11 @@ def test_force_kernel_keeps_its_scalar_loads(tmp_path):
         assert vec <= 2 * int(k2) + 2, f"{name}: {vec} vector dwordx3 loads -- the j-loads were de-scalarised"
     default = [b for n_, k2, w, e, b in bodies if (k2, w, e) == ("1", "8", "2")][0]
     assert len(re.findall(r"v_pk_fma_f32", default)) == 56 and "scratch_" not in default
+
+
+def test_graft_entry_build_succeeds_on_the_cpu():
+    """The driver's "does it build" check (`__graft_entry__.build()`: hipcc cross-compiles without a GPU) -- including the version
+    assertions it makes about the two headers (an ABI bump that forgot them would fail the round's build check, not a test)."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); print('built')"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "built" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]

@@ -124,6 +124,9 @@ def test_bench_json_contract():
         assert abs(e["GBps"] - 56.0 * e["bodies"] / (e["ms_per_step"] * 1e-3) / 1e9) < 0.01 * e["GBps"]
         assert 3000.0 < e["GBps"] < 9000.0 and abs(e["frac_of_8TBps"] - e["GBps"] / 8000.0) < 1e-3 and abs(e["frac_of_6.29"] - e["GBps"] / 6290.0) < 1e-3, e
     assert "non-temporal" in cw[1]["form"] and "Infinity Cache" in cw[0]["form"]
+    pa = d["config"]["partial_active"]      # partially active steps in the same line: the split form against the one-sided step round 4 ran
+    assert [e["num_active"] for e in pa] == [32768, 49152] and all(e["form_picked"] == "split" for e in pa), pa
+    assert pa[0]["speedup_over_one_sided"] > 1.06 and pa[1]["speedup_over_one_sided"] > 1.15, pa     # (measured 1.15 - 1.16 and 1.25 - 1.27; the bound at N/2 is 1.18)
     rp = d["config"]["replay"]              # 10 steps from the seeded state under the timed plan: the pair of checksums a re-run with the same weights reproduces
     assert rp["steps"] == 10 and len(rp["checksums"]) == 2 and all(isinstance(x, int) and x > 0 for x in rp["checksums"])
     assert d["config"]["closing_collective_us"] is None     # (N = 1: no collective closes the region)
@@ -136,7 +139,7 @@ def test_bench_replays_a_plan_from_given_xcd_weights():
     print identical `config.replay.checksums`, another weighting prints others."""
     def run(w):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-power-leg",
-                            "--no-central-well-leg", "--prewarm-ms", "50"] + (["--xcd-weights", w] if w else ["--xcd", "off"]), capture_output=True, text=True, timeout=600)
+                            "--no-central-well-leg", "--no-partial-leg", "--prewarm-ms", "50"] + (["--xcd-weights", w] if w else ["--xcd", "off"]), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     w = "1024,900,1000,950,1024,880,990,1010"

@@ -114,6 +114,26 @@ def test_the_slider_moves_through_all_three_forms_and_the_results_follow_the_ora
                     np.testing.assert_array_equal(pb[a:], before[0][a:]); np.testing.assert_array_equal(vb[a:], before[1][a:])
 
 
+def test_split_form_free_running_100_steps_half_active(oracle):
+    """100 free-running steps with half of the 65 536 bodies active (the others frozen where the seeded state put them): against the
+    oracle proper every body within 5e-6 relative (T2's statistic for 100 steps, tests/test_parity_1000.py: 2e-6 with all bodies active),
+    the frozen half untouched in both buffers after all of them."""
+    n, na = 65536, 32768
+    pos, vel = oracle.initial_state(n, seed=1)
+    sim = OracleSim(oracle, pos, vel, params=Params(mass=70000.0 / n)); sim.simulate(num_active=na, steps=100)
+    with mapn.Compute(n, mass=70000.0 / n, seed=1) as c:
+        draw(c, 100, na)
+        assert c.kernel_stats().split_active == na
+        bufs = [c.download_buffer(b) for b in (0, 1)]
+        p, v = c.download_state()
+    rp = sim.latest[0]
+    rel = np.linalg.norm(p[:na, :3].astype(np.float64) - rp[:na, :3], axis=1) / np.maximum(np.linalg.norm(rp[:na, :3].astype(np.float64), axis=1), 1e-30)
+    print(f"100 steps, 32 768 of 65 536 bodies active (split form) vs the reference-order oracle: max rel {rel.max():.2e}, median {np.median(rel):.2e}")
+    assert rel.max() < 5e-6 and np.median(rel) < 1e-7
+    for pb, vb in bufs:
+        np.testing.assert_array_equal(pb[na:], pos[na:]); np.testing.assert_array_equal(vb[na:], vel[na:])
+
+
 def test_split_form_is_bit_reproducible_and_graph_replay_equals_eager(oracle):
     n, na = 65536, 32768 + 64
     res = []

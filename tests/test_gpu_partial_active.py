@@ -142,9 +142,16 @@ def test_split_form_is_bit_reproducible_and_graph_replay_equals_eager(oracle):
             c.set_timers(0)                                   # (a step that carries timer events runs eagerly)
             draw(c, 2); draw(c, 5, na); draw(c, 1); draw(c, 3, na)
             assert c.kernel_stats().split_active == na
-            res.append([c.download_buffer(b) for b in (0, 1)])
+            # ... and a count that runs one-sided with a SMALLER row buffer first, then the split form (whose frozen rows make that buffer
+            # grow, i.e. move), then the small count again: the captured step of the other ping-pong parity must not replay onto the old buffer
+            with mapn.Compute(n, mass=70000.0 / n, flags=flags) as d:
+                d.set_timers(0)
+                draw(d, 3, 20000); assert d.kernel_stats().kernel_name.decode() == "force_sgpr_kernel"
+                draw(d, 1, na); draw(d, 2, 20000); draw(d, 2, na)
+                res_d = [d.download_buffer(b) for b in (0, 1)]
+            res.append([c.download_buffer(b) for b in (0, 1)] + res_d)
     for other in res[1:]:
-        for b in (0, 1):
+        for b in range(4):
             np.testing.assert_array_equal(res[0][b][0], other[b][0])
             np.testing.assert_array_equal(res[0][b][1], other[b][1])
 

@@ -191,6 +191,10 @@ int ensure_partial(mapn_ctx *c, size_t slots, size_t stride)
 {
     const size_t need = slots * stride * sizeof(float4);
     if (need <= c->partial_bytes) return MAPN_OK;
+    // (the buffer moves: steps still in flight read the old one, and a captured step of the OTHER ping-pong parity holds its address --
+    //  num_active changing between two replays could otherwise replay a graph onto freed memory)
+    HIP_TRY(hipStreamSynchronize(c->compute));
+    drop_graphs(c);
     if (c->partial) HIP_TRY(hipFree(c->partial));
     c->partial = nullptr;
     c->partial_bytes = 0;

@@ -586,7 +586,6 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     const uint32_t bid = blockIdx.x, nblk = gridDim.x;
     constexpr uint32_t B = 256u / G;                       // bodies per workgroup and pass
     __shared__ uint32_t ok;
-    __shared__ uint32_t bad;                               // a body of this workgroup never got all of its rows (self-validating rows): nothing of it is published
     __shared__ float part[G][3][B];
 
     // diagnostic launches only (MAPN_STAMP_DUMP): wall-clock stamps of the workgroup's phases; null otherwise
@@ -594,7 +593,6 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         if (p.timeline && threadIdx.x == 0) p.timeline[(size_t)bid * 8u + k] = __builtin_amdgcn_s_memrealtime();
     };
     stamp(0);
-    if (threadIdx.x == 0) bad = 0u;                        // (read only behind the barriers below)
     // split table of the block that ran a meeting: set = class (+ 2 * (LOCAL block mod 8) with XCD-weighted parts)
     const uint32_t *splits = p.tab + p.sets * (p.nwaves + 1u);
     auto split_of = [&](uint32_t a, uint32_t la) { return splits + (size_t)((sym_runs_half(a, p.half_d) ? 0u : 1u) + (p.sets > 2u ? 2u * (la & 7u) : 0u)) * p.max_meetings; };
@@ -771,13 +769,19 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         if (late) {
             __hip_atomic_store(p.status, late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (p.phase == 0u) {
-                // A rank whose rows never validated must not go on as if they had: this body is NOT integrated, nothing of
-                // it is stored or pushed, and the workgroup withholds its share of the position counters -- the peers' bounded waits for
-                // this rank's slice then give up too and every rank of the job reports, instead of all of them holding bit-identical
-                // replicas of a wrong state.  (Once dead, every later launch of this rank ends up here at once: no garbage at full speed.)
+                // A rank whose rows never validated must not go on as if they had: until round 4 it integrated the incomplete sum,
+                // published the result with valid checksums and counted itself complete -- only IT reported, the peers held bit-identical
+                // wrong replicas.  Now the failing thread POISONS this rank's position counter at every peer (a value 1.5 x 2^30 short of what
+                // this publication must reach: no number of shares makes that up, and every later launch of the dead rank poisons again), so
+                // the peers' bounded waits for this rank's slice give up too and every rank of the job reports.  Nothing of this costs the
+                // healthy path a cycle (a workgroup flag that withholds the share did: +0.36 us on the exchange launch, same box).
                 __hip_atomic_store(p.flags_mine + SYM_DEAD_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(&bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                continue;
+                if (p.pos_step) {
+                    const uint32_t poison = p.pos_step * SYM_COUNT_PER_LAUNCH - 0x60000000u;
+                    for (uint32_t q = 0; q < p.world; q++)
+                        if (p.pull_self ? q == p.rank : q != p.rank)
+                            __hip_atomic_store(p.flags_peer[q] + SYM_POS_BASE + p.rank, poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         }
         ax *= p.mass; ay *= p.mass; az *= p.mass;
@@ -825,7 +829,6 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     if (p.release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     __syncthreads();
     stamp(5);                                              // position stores acknowledged
-    if (bad) return;                                       // (uniform: read behind the barrier) no share for the counters -- the peers must not take this slice for complete
     if (threadIdx.x < 64u) {
         // every workgroup adds ITS share of SYM_COUNT_PER_LAUNCH to this rank's position counter at every peer (fire and forget: the
         // workgroup leaves at once instead of waiting for a ticket to come back; the shares of a launch sum to

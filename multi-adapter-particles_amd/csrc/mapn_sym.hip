@@ -773,8 +773,8 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
                 // published the result with valid checksums and counted itself complete -- only IT reported, the peers held bit-identical
                 // wrong replicas.  Now the failing thread POISONS this rank's position counter at every peer (a value 1.5 x 2^30 short of what
                 // this publication must reach: no number of shares makes that up, and every later launch of the dead rank poisons again), so
-                // the peers' bounded waits for this rank's slice give up too and every rank of the job reports.  Nothing of this costs the
-                // healthy path a cycle (a workgroup flag that withholds the share did: +0.36 us on the exchange launch, same box).
+                // the peers' bounded waits for this rank's slice give up too and every rank of the job reports.  All of it sits in this cold
+                // branch (same box: exchange launch 11.98 -> 12.14 us; a workgroup flag that withholds the share instead: 11.80 -> 12.16).
                 __hip_atomic_store(p.flags_mine + SYM_DEAD_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (p.pos_step) {
                     const uint32_t poison = p.pos_step * SYM_COUNT_PER_LAUNCH - 0x60000000u;

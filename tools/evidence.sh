@@ -47,12 +47,12 @@ bench)
   python bench.py "$@" > $O/bench.json 2> $O/bench.err; line "bench $*" < $O/bench.json ;;
 stats)
   k=${1:-sym}; cd /tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$k -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --kernel $k > $O/bench_profiled_$k.json 2> $O/bench_profiled_$k.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$k -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-partial-leg --kernel $k > $O/bench_profiled_$k.json 2> $O/bench_profiled_$k.err
   cd $R; f=$(ls -t $(find $O/stats_$k -name "*kernel_stats.csv") | head -1); cp $f $O/kernel_stats_$k.csv; head -5 $f; line "profiled $k" < $O/bench_profiled_$k.json
   rm -rf $O/stats_$k ;;     # (the raw trace: gpurun merges at most 64 MiB back)
 pmc)
   k=${1:-sym}; tag=${2:-r05_$k}; cd /tmp
-  P() { d=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$k/$d -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --kernel $k > /dev/null 2> $O/pmc_$k.$d.err; }
+  P() { d=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$k/$d -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-partial-leg --kernel $k > /dev/null 2> $O/pmc_$k.$d.err; }   # (--no-partial-leg: that leg launches the SAME force kernel over fewer blocks and would be averaged into its per-launch figures)
   P fetch FETCH_SIZE; P write WRITE_SIZE
   P sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAVES
   P grbm GRBM_GUI_ACTIVE GRBM_COUNT

@@ -990,7 +990,9 @@ def partial_active_leg(mapn, c, n, seconds=0.04):
         if partial_active_leg.set_hooks:
             os.environ.pop("MAPN_TEST_HOOKS", None)
         out.append({"num_active": na, "form_picked": form, "ms_per_step": round(t_pick, 5), "ms_per_step_one_sided": round(t_one, 5),
-                    "speedup_over_one_sided": round(t_one / t_pick, 4), "interactions_per_s": float(na) * n / (t_pick * 1e-3)})
+                    "speedup_over_one_sided": round(t_one / t_pick, 4), "interactions_per_s": float(na) * n / (t_pick * 1e-3),
+                    "note": "ordered pairs the step must account for: num_active x N (the frozen bodies still exert force); bound of the split form over the "
+                            "one-sided step at the two kernels' rates (7.1e12 / 4.9e12): 1 / (x / 1.45 + 1 - x), x = num_active / N"})
     return out
 
 

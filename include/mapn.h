@@ -99,8 +99,9 @@ typedef enum mapn_init_variant {
                                           the plan bench.py's headline number is measured with, for any C-ABI caller
                                           (compat/Compute.hpp: one config bit).  Up to 262 144 bodies the weighted plan is then VERIFIED
                                           (another 0.2 s): plain steps under it and under the default plan, interleaved, best of two
-                                          bursts each -- it stays only if it wins by 0.2 %, otherwise the default plan runs and
-                                          mapn_last_error() says so (the calibration reads lone stamped launches and can catch a
+                                          bursts each -- it stays only if it wins by 0.2 %; a reading that loses gets ONE second reading (another
+                                          0.4 s, only then), and if that loses too the default plan runs and mapn_last_error() says so,
+                                          with the weights that lost (the calibration reads lone stamped launches and can catch a
                                           transient).  A hint: where XCD weights do not apply
                                           (one-sided kernel, block count not a multiple of 8, a partitioned
                                           device) creation succeeds with the default plan and mapn_last_error() says why.  On a SHARDED

@@ -667,18 +667,23 @@ int calibrate_at_creation(mapn_ctx *c)
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     (void)hipGetLastError();
+    // Calibrate, apply -- and VERIFY: the calibration reads lone stamped launches, and now and then what it reads is a transient (a die
+    // measured 6 - 13 % slow for a few launches: weights like that cost 2 - 4 % per step).  The weighted plan stays only if it wins an A/B
+    // of plain steps against the default plan -- best of two bursts each, interleaved, 0.2 % margin: the decision bench.py has always made
+    // for itself, now the library's.  A reading that loses gets ONE second reading (round 5: of four creations on one box one lost its
+    // A/B by 0.5 % where the other three won by 1.1 - 1.2 %; a second calibration is 0.4 s, only in that case).  (The A/B up to 262 144
+    // bodies: beyond, four bursts would cost seconds and a launch is long enough to average the transients out.  MAPN_XCD_VERIFY=0 with
+    // MAPN_TEST_HOOKS=1: no A/B, for the tests that need the weighted plan.)
     uint32_t w[8];
-    if (!rc) rc = mapn_calibrate_sym_xcds(c, c->n <= 131072u ? 8 : c->n <= 262144u ? 4 : 1, w);
-    if (!rc) rc = mapn_set_sym_xcd_weights(c, w);
-    std::string note = rc ? "MAPN_FLAG_XCD_CALIBRATE: " + g_last_error + "; the default plan runs" : std::string();
-    if (rc) (void)mapn_set_sym_xcd_weights(c, nullptr);
-    // ... and VERIFIED: the calibration reads lone stamped launches, and now and then what it reads is a transient (a die measured
-    // 6 - 13 % slow for a few launches: weights like that cost 2 - 4 % per step).  The weighted plan stays only if it wins an A/B of
-    // plain steps against the default plan -- best of two bursts each, interleaved, 0.2 % margin: the decision bench.py has always
-    // made for itself, now the library's.  (Up to 262 144 bodies: beyond, four bursts would cost seconds and a launch is long enough
-    // to average the transients out.  MAPN_XCD_VERIFY=0 with MAPN_TEST_HOOKS=1: no A/B, for the tests that need the weighted plan.)
+    std::string note;
     const char *vf = test_hook("MAPN_XCD_VERIFY");
-    if (!rc && c->n <= 262144u && !(vf && vf[0] == '0')) {
+    const bool verify = c->n <= 262144u && !(vf && vf[0] == '0');
+    if (rc) { note = "MAPN_FLAG_XCD_CALIBRATE: " + g_last_error + "; the default plan runs"; }     // (the clock ramp's steps failed: nothing is calibrated)
+    for (int attempt = 0; attempt < 2 && !rc; attempt++) {
+        rc = mapn_calibrate_sym_xcds(c, c->n <= 131072u ? 8 : c->n <= 262144u ? 4 : 1, w);
+        if (!rc) rc = mapn_set_sym_xcd_weights(c, w);
+        if (rc) { note = "MAPN_FLAG_XCD_CALIBRATE: " + g_last_error + "; the default plan runs"; (void)mapn_set_sym_xcd_weights(c, nullptr); rc = MAPN_OK; break; }
+        if (!verify) break;
         const double est = 0.6e-3 * ((double)c->n / 65536.0) * ((double)c->n / 65536.0);
         const int kk = std::max(2, std::min(64, (int)(0.04 / est)));
         hipEvent_t a0 = nullptr, a1 = nullptr;
@@ -700,17 +705,15 @@ int calibrate_at_creation(mapn_ctx *c)
         if (a0) (void)hipEventDestroy(a0);
         if (a1) (void)hipEventDestroy(a1);
         (void)hipGetLastError();
-        if (!rc) {
-            const bool keep = best_w < 1e29f && best_w < best_d * 0.998f;
-            rc = mapn_set_sym_xcd_weights(c, keep ? w : nullptr);
-            if (!rc && !keep) {
-                char msg[256];
-                snprintf(msg, sizeof msg, "MAPN_FLAG_XCD_CALIBRATE: the calibrated plan did not win its A/B against the default plan (%.4f against %.4f ms per step); the default plan runs",
-                         (double)best_w, (double)best_d);
-                note = msg;
-            }
-        }
-        if (rc) { note = "MAPN_FLAG_XCD_CALIBRATE: " + g_last_error + "; the default plan runs"; (void)mapn_set_sym_xcd_weights(c, nullptr); }
+        if (rc) { note = "MAPN_FLAG_XCD_CALIBRATE: " + g_last_error + "; the default plan runs"; (void)mapn_set_sym_xcd_weights(c, nullptr); rc = MAPN_OK; break; }
+        const bool keep = best_w < 1e29f && best_w < best_d * 0.998f;
+        rc = mapn_set_sym_xcd_weights(c, keep ? w : nullptr);
+        if (rc) { note = "MAPN_FLAG_XCD_CALIBRATE: " + g_last_error + "; the default plan runs"; (void)mapn_set_sym_xcd_weights(c, nullptr); rc = MAPN_OK; break; }
+        if (keep) { note.clear(); break; }
+        char msg[320];
+        snprintf(msg, sizeof msg, "MAPN_FLAG_XCD_CALIBRATE: the calibrated plan (weights %u %u %u %u %u %u %u %u, reading %d of 2) did not win its A/B against the default plan "
+                 "(%.4f against %.4f ms per step); the default plan runs", w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], attempt + 1, (double)best_w, (double)best_d);
+        note = msg;
     }
     // put everything back
     rc = mapn_wait_idle(c);

@@ -17,7 +17,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define MAPN_TUNING_ABI_VERSION 1   /* 1 (round 5): split off mapn.h (ABI 3); new: mapn_get_split_plan, mapn_kernel_stats.split_active */
+#define MAPN_TUNING_ABI_VERSION 1   /* 1 (round 5): split off mapn.h (ABI 3); new: mapn_get_split_plan, mapn_kernel_stats.split_active, mapn_shard_describe */
 int mapn_tuning_abi_version(void);
 
 /* Force-kernel statistics accumulated by mapn_simulate: every step records HIP events on the
@@ -147,6 +147,24 @@ int mapn_get_split_plan(mapn_ctx *ctx, mapn_split_info *split, mapn_sym_plan_inf
  */
 int mapn_calibrate_sym_xcds(mapn_ctx *ctx, int steps, uint32_t out_weights[8]);
 int mapn_set_sym_xcd_weights(mapn_ctx *ctx, const uint32_t *weights8);
+
+/*
+ * The sharded mode's host arithmetic as data, WITHOUT a device (the CPU multi-process test composes a sharded run from it; the
+ * library's own mapn_create and step go through the same helpers): the slice rank `rank` of `world_size` owns, the bodies of it a step
+ * with num_active advances (Compute.cpp:1041's rounding: bodies [0, roundup64(num_active)) of the whole job), whether the sharded
+ * symmetric step (gather algorithms 4 / 5 / 6) applies to that shape, this rank's blocks, and which ranks it produces reactions for /
+ * receives reactions from (bit q of send_mask / recv_mask; mapn_sym_plan_describe(..., launch_blocks = nbl, launch_a0 = a0, ...) gives
+ * the rank's launch plan).
+ */
+typedef struct mapn_shard_info {
+    uint32_t first, count;
+    uint32_t active_first, active_count;
+    uint32_t sym_applies;
+    uint32_t nb, nbl, a0;
+    uint32_t send_mask, recv_mask;
+    uint32_t reserved[2];
+} mapn_shard_info;
+int mapn_shard_describe(uint32_t num_particles, int32_t rank, int32_t world_size, int32_t num_active, mapn_shard_info *out);
 
 /* Sharded mode: switch the own/remote overlap structure (MAPN_FLAG_SHARD_OVERLAP) at run time, so a
  * launcher can time both structures on the node it runs on; all ranks must agree. */

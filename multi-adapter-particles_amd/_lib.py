@@ -83,6 +83,10 @@ class SymPlanInfo(C.Structure):
     ]
 
 
+class ShardInfo(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("first", "count", "active_first", "active_count", "sym_applies", "nb", "nbl", "a0", "send_mask", "recv_mask")] + [("reserved", C.c_uint32 * 2)]
+
+
 class SplitInfo(C.Structure):
     _fields_ = [("active", C.c_uint32), ("frozen", C.c_uint32), ("frozen_kernel", C.c_uint32), ("frozen_bodies_per_lane", C.c_uint32),
                 ("frozen_waves", C.c_uint32), ("frozen_sb", C.c_uint32), ("reserved", C.c_uint32 * 2)]
@@ -148,6 +152,7 @@ SIGNATURES = {
     "mapn_get_step_samples": (C.c_int, [_ctx, C.POINTER(C.c_uint32), _fp, _fp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mapn_set_force_plan": (C.c_int, [_ctx, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     "mapn_set_shard_overlap": (C.c_int, [_ctx, C.c_int]),
+    "mapn_shard_describe": (C.c_int, [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(ShardInfo)]),
     "mapn_calibrate_sym_xcds": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_uint32 * 8)]),
     "mapn_set_sym_xcd_weights": (C.c_int, [_ctx, C.POINTER(C.c_uint32 * 8)]),
     "mapn_sym_plan_describe": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32 * 8), C.c_uint32, C.c_uint32, C.c_uint32,

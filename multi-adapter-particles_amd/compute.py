@@ -397,6 +397,13 @@ class SymPlan:
         return self.tables[o:o + self.max_meetings]
 
 
+def describe_shard(num_particles: int, rank: int, world_size: int, num_active: int | None = None) -> "_lib.ShardInfo":
+    """The sharded mode's host arithmetic for one rank, computed by the library without a device (mapn_shard_describe)."""
+    info = _lib.ShardInfo()
+    check(load_library().mapn_shard_describe(int(num_particles), int(rank), int(world_size), int(num_particles if num_active is None else num_active), C.byref(info)))
+    return info
+
+
 def describe_sym_plan(nb: int, groups_per_window: int = 0, parts: int = 32, taper1: int | None = None, taper2: int = 0, waves: int = 4,
                       xcd_weights=None, launch_blocks: int = 0, wave_bias=(1, 1), launch_a0: int = 0, xcd_mode: int = 0) -> SymPlan:
     """The plan of a shape, computed on the host without a device (csrc/mapn_sym_plan.cpp)."""

@@ -278,8 +278,7 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
 {
     const uint32_t w = c->buffer_index, r = 1 - c->buffer_index;
     // this shard's active bodies: [first, min(first+count, active))
-    const uint32_t lo = c->first, hi = std::min(c->first + c->count, active);
-    const uint32_t i_count = hi > lo ? hi - lo : 0;
+    const uint32_t lo = c->first, i_count = shard_active_count(c->first, c->count, active);
     mapn::StepArgs a = base_args(c, w, r);
     a.i_first = lo;
     a.i_count = i_count;
@@ -510,8 +509,7 @@ int create_common(const mapn_config *cfg, mapn_ctx **out)
     c->n = cfg->num_particles;
     c->device = cfg->device;
     c->cus = prop.multiProcessorCount;
-    c->count = c->n / (uint32_t)cfg->world_size;
-    c->first = c->count * (uint32_t)cfg->rank;
+    shard_slice(c->n, (uint32_t)cfg->rank, (uint32_t)cfg->world_size, c->first, c->count);
     c->timers_enabled = true;
     *out = c;
 

@@ -40,6 +40,13 @@ int fail(int code, const char *fmt, ...);
 const char *test_hook(const char *name);
 
 constexpr uint32_t kBlock = 64;            // defines.h:37 BLOCK_SIZE: granularity of num_active
+
+// The sharded mode's slicing arithmetic, in ONE place: mapn_create, the step and the device-less mapn_shard_describe (which the CPU
+// multi-process test drives) all go through these two.
+//   rank p of P owns the contiguous slice [p N / P, (p + 1) N / P) of positions and velocities (P divides N);
+//   of it, a step with `active` = roundup64(num_active) bodies advances [first, min(first + count, active)).
+inline void shard_slice(uint32_t n, uint32_t rank, uint32_t world, uint32_t &first, uint32_t &count) { count = n / world; first = count * rank; }
+inline uint32_t shard_active_count(uint32_t first, uint32_t count, uint32_t active) { const uint32_t hi = std::min(first + count, active); return hi > first ? hi - first : 0u; }
 constexpr int kTimerRing = 64;             // in-flight step timers
 constexpr int kAverageOver = 20;           // D3D12GpuTimer.h averageOver (Compute.cpp:445)
 constexpr uint64_t kHeapAlign = 64 * 1024; // Compute.cpp:185-194: 64 KiB placement alignment

@@ -271,6 +271,28 @@ int mapn_replica_checksum(mapn_ctx *c, uint64_t out[2])
     return MAPN_OK;
 }
 
+// The sharded mode's host arithmetic WITHOUT a device: the same helpers mapn_create and the step use (shard_slice,
+// shard_active_count, active_bodies, sym_shard_masks) -- what the CPU multi-process test composes a sharded run from.
+int mapn_shard_describe(uint32_t num_particles, int32_t rank, int32_t world_size, int32_t num_active, mapn_shard_info *out)
+{
+    if (!out) return fail(MAPN_ERR_INVALID_ARGUMENT, "shard_describe: null argument");
+    memset(out, 0, sizeof *out);
+    if (num_particles == 0 || world_size < 1 || rank < 0 || rank >= world_size)
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "rank %d / world_size %d", rank, world_size);
+    if (num_particles % (uint32_t)world_size)
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "world_size %d must divide num_particles %u", world_size, num_particles);
+    shard_slice(num_particles, (uint32_t)rank, (uint32_t)world_size, out->first, out->count);
+    const uint32_t active = active_bodies(num_active, num_particles);
+    out->active_first = out->first;
+    out->active_count = shard_active_count(out->first, out->count, active);
+    out->sym_applies = (world_size >= 2 && world_size <= mapn::P2P_MAX_RANKS && out->count % mapn::SYM_BLOCK == 0u) ? 1u : 0u;
+    if (out->sym_applies) {
+        out->nb = num_particles / mapn::SYM_BLOCK; out->nbl = out->count / mapn::SYM_BLOCK; out->a0 = (uint32_t)rank * out->nbl;
+        sym_shard_masks(out->nb, (uint32_t)world_size, (uint32_t)rank, out->send_mask, out->recv_mask);
+    }
+    return MAPN_OK;
+}
+
 int mapn_set_external_gather(mapn_ctx *c, int enabled)
 {
     if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");

@@ -1,7 +1,11 @@
 """Multi-rank logic on CPU: world_size-2 gloo processes shard the bodies, each advances its own
 slice (with the oracle -- tests may use it as the compute), all-gathers the new float4 position
-slices, and the composed trajectory must equal the single-rank one bit for bit.  This pins the
-host-side decomposition the GPU path uses (ShardPlan == csrc/mapn_context.cpp's slicing)."""
+slices, and the composed trajectory must equal the single-rank one bit for bit.
+
+Which bodies a rank owns and which of them a step advances comes from the PRODUCT -- `mapn_shard_describe`, the device-less
+entry point over the very helpers `mapn_create` and the step use (csrc/mapn_internal.h: shard_slice, shard_active_count;
+active_bodies; sym_shard_masks) -- so the run is evidence about the library's host arithmetic (until round 5
+it exercised tests/shard_model.py, a Python model, alone).  The model stays as a second opinion: the two must agree on every shape."""
 import os
 import sys
 
@@ -39,6 +43,37 @@ def test_active_slice_clamps_per_rank():
     assert plan[1].gather_bytes_sent() == 256 * 16 and plan[1].gather_bytes_received() == 768 * 16
 
 
+def test_product_shard_arithmetic_agrees_with_the_model_and_with_itself_across_ranks():
+    """mapn_shard_describe (product, no device) against tests/shard_model.py on many shapes: slices, active slices, and -- where the
+    sharded symmetric step applies -- masks that are each other's mirror (q in send(r)  <=>  r in recv(q)), every rank sending to
+    itself, and block ranges that tile the job."""
+    from mapn.compute import describe_shard
+    import shard_model as shard
+    for n, world in [(65536, 8), (1048576, 8), (8192, 2), (9216, 3), (16384, 8), (6144, 2), (4096, 2), (96, 3), (7, 1), (262144, 4)]:
+        infos = [describe_shard(n, r, world, na) for r in range(world) for na in (n,)]
+        for na in (n, n // 2 + 100, 64, 1, 0, -5, 10 * n):
+            for r in range(world):
+                i = describe_shard(n, r, world, na)
+                assert (i.first, i.count) == shard_range(n, r, world)
+                assert (i.active_first, i.active_count) == ShardPlan(n, r, world).active_slice(na), (n, world, r, na)
+        applies = world >= 2 and (n // world) % 1024 == 0
+        assert all(bool(i.sym_applies) == applies for i in infos)
+        if applies:
+            assert [i.a0 for i in infos] == [r * (n // world // 1024) for r in range(world)] and all(i.nb == n // 1024 and i.nbl == n // world // 1024 for i in infos)
+            for r, i in enumerate(infos):
+                assert (i.send_mask >> r) & 1 and (i.recv_mask >> r) & 1          # a rank's own blocks meet each other
+                for q, j in enumerate(infos):
+                    assert ((i.send_mask >> q) & 1) == ((j.recv_mask >> r) & 1), (n, world, r, q)
+            # the masks are what the meeting schedule says (the model's restatement of it)
+            for r, i in enumerate(infos):
+                send, recv = shard.sym_shard_masks(n // 1024, world, r)
+                assert (send, recv) == (i.send_mask, i.recv_mask)
+    with pytest.raises(mapn.MapnError):
+        describe_shard(100, 0, 3)
+    with pytest.raises(mapn.MapnError):
+        describe_shard(100, 2, 2)
+
+
 def _worker(rank, world, port, n, steps, num_active, out_dir):
     sys.path.insert(0, ROOT)
     import torch
@@ -50,14 +85,17 @@ def _worker(rank, world, port, n, steps, num_active, out_dir):
     o = Oracle()
     prm = Params(mass=70000.0 / n)
     pos0, vel0 = o.initial_state(n, seed=1)
-    plan = ShardPlan(n, rank, world)
+    from mapn.compute import describe_shard
+    plan = describe_shard(n, rank, world)                  # the PRODUCT's slicing (no device needed)
+    assert (plan.first, plan.count) == (ShardPlan(n, rank, world).first, ShardPlan(n, rank, world).count)
     # full position replica + full-size velocity array of which only the own slice is maintained
     pos = [pos0.copy(), pos0.copy()]
     vel = [vel0.copy(), vel0.copy()]
     idx = 0
     for _ in range(steps):
         w, r = idx, 1 - idx
-        first, count = plan.active_slice(num_active)
+        step_info = describe_shard(n, rank, world, num_active)     # ... and which of the rank's bodies THIS step advances
+        first, count = step_info.active_first, step_info.active_count
         if count:
             p, v = o.step_slice(pos[r], vel[r], first, count, params=prm, threads=2)
             pos[w][first:first + count] = p

@@ -374,6 +374,7 @@ int prepare_sym_active(mapn_ctx *c, uint32_t active)
     const mapn::SymPlanHost &pl = s.plan;
     // the one-sided launch over the frozen bodies: the default plan of an active x (N - active) launch, partial rows instead of the integrator
     s.frozen = choose_plan(c, active, c->n - active, 1, false);
+    env_plan("MAPN_FROZEN_PLAN", s.frozen);                // (hook: "k,waves,sb" -- the sweep behind the default)
     s.frozen.epi = mapn::EPI_ROWS;
     auto grow = [](void **p, size_t &have, size_t need) -> hipError_t {
         if (need <= have) return hipSuccess;

@@ -89,6 +89,35 @@ def test_split_form_against_its_order_matched_oracle(oracle, monkeypatch, n, num
     np.testing.assert_array_equal(p[a:], rp[a:])
 
 
+@pytest.mark.parametrize("n,num_active", [(65536, 32768), (65536, 40960), (131072, 73728)])
+def test_split_form_under_xcd_weights_against_its_order_matched_oracle(oracle, n, num_active):
+    """A context with XCD weights (a calibrated one: MAPN_FLAG_XCD_CALIBRATE; here a fixed lopsided set) plans the ACTIVE blocks' launch
+    with them too where they apply (a multiple of 8 active blocks): class-aware (32 and 40 active blocks) or spread over the dies (72
+    blocks x 7 parts) -- another summation order, restated by the oracle from the split plan the context reports."""
+    mass = 70000.0 / n
+    pos, vel = oracle.initial_state(n, seed=9)
+    weights = [1024, 900, 1000, 950, 1024, 880, 990, 1010]
+    with mapn.Compute(n, mass=mass, seed=9, flags=mapn.FLAG_NO_INIT) as c:
+        c.upload_state(pos, vel)
+        c.set_sym_xcd_weights(weights)
+        draw(c, 2, num_active)
+        assert c.kernel_stats().split_active == num_active
+        split, plan = c.split_plan()
+        assert plan.xcd_mode in (1, 2) and plan.xcd_weight == weights and plan.nb == num_active // 1024, (plan.xcd_mode, plan.nb)
+        p, v = c.download_state()
+        c.upload_state(pos, vel); draw(c, 2, num_active)
+        np.testing.assert_array_equal(c.download_state()[0], p)            # bit-reproducible for given weights
+    sim = OracleSim(oracle, pos, vel, params=Params(mass=mass), split_plan=(split, plan))
+    sim.simulate(num_active=num_active, steps=2)
+    rp = sim.latest[0]
+    a = split.active
+    rel = np.linalg.norm(p[:a, :3].astype(np.float64) - rp[:a, :3], axis=1) / np.maximum(np.linalg.norm(rp[:a, :3].astype(np.float64), axis=1), 1e-30)
+    same = float((p[:a, :3] == rp[:a, :3]).all(axis=1).mean())
+    print(f"N={n} active={a}: weighted split plan {plan.waves}x{plan.parts}, xcd_mode {plan.xcd_mode}, sets {plan.sets}: max rel {rel.max():.2e}, bit-identical {same:.4f}")
+    assert rel.max() <= 3e-7 and same >= 0.9
+    np.testing.assert_array_equal(p[a:], rp[a:])
+
+
 def test_the_slider_moves_through_all_three_forms_and_the_results_follow_the_oracle(oracle):
     """num_active changing from frame to frame (the slider of Particles.cpp:391-394): all bodies (the full symmetric step), half (split),
     the same again (no new plan), nearly all (full: the frozen few are not worth a split), a few (one-sided), another split count, all

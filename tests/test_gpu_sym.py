@@ -209,9 +209,11 @@ def test_symmetric_free_run_matches_golden_and_the_one_sided_kernel(oracle, gold
 
 
 def test_symmetric_context_falls_back_where_the_kernel_does_not_apply(oracle):
-    """Fewer than about 0.75 N active bodies, or N smaller than one 1024-body block: the step runs the scalar-cache kernel
-    (same results contract, incl. the frozen tail in BOTH ping-pong buffers); otherwise the symmetric kernel, whose reduce launch
-    simply stops at roundup64(num_active)."""
+    """A small job (4096 bodies: too few active blocks for the split form of tests/test_gpu_partial_active.py, which needs eight) with
+    fewer than about 0.75 N active bodies, or N smaller than one 1024-body block: the step runs the scalar-cache kernel (same results
+    contract, incl. the frozen tail in BOTH ping-pong buffers); otherwise the symmetric kernel over all bodies, whose reduce launch
+    simply stops at roundup64(num_active).  (From 8192 active bodies on the library weighs a third form against these two -- active x
+    active symmetric + active x frozen one-sided: sym_step_form, csrc/mapn_sym_host.cpp.)"""
     n = 4096
     pos, vel = oracle.initial_state(n, seed=4)
     prm = Params(mass=70000.0 / n)
@@ -221,7 +223,7 @@ def test_symmetric_context_falls_back_where_the_kernel_does_not_apply(oracle):
         # 1000 of 4096: the one-sided kernel's active x N pairs are cheaper than N x N / 1.4
         for na, name in ((n, "force_sym_kernel"), (3500, "force_sym_kernel"), (1000, "force_sgpr_kernel"), (3100, "force_sym_kernel"), (n, "force_sym_kernel")):
             sim.simulate(num_active=na); draw(c, 1, num_active=na)
-            assert c.kernel_stats().kernel_name.decode() == name
+            assert c.kernel_stats().kernel_name.decode() == name and c.kernel_stats().split_active == 0
             for b in (0, 1):
                 pb, vb = c.download_buffer(b)
                 assert errs(pb[:, :3], sim.pos[b][:, :3], SPREAD)[0] < 3e-6

@@ -185,6 +185,35 @@ def test_split_form_is_bit_reproducible_and_graph_replay_equals_eager(oracle):
             np.testing.assert_array_equal(res[0][b][1], other[b][1])
 
 
+def test_a_random_slider_sequence_replays_bit_identically_eager_and_captured(oracle):
+    """Eighty steps whose num_active jumps at random between all three forms and many counts (every new count of the split form makes a
+    new plan, grows or reuses its scratch, may move the one-sided kernels' row buffer): two eager runs and a hipGraph run must agree bit
+    for bit in both buffers, and the final state must sit where the oracle's free run of the same sequence sits."""
+    n = 65536
+    rng = np.random.default_rng(12345)
+    seq = [int(x) for x in rng.choice([n, n, 61000, 57344, 49152, 40001, 32768, 32832, 24576, 20000, 9000, 3000, 64, 0], size=80)]
+    res = []
+    for flags in (0, 0, mapn.FLAG_USE_GRAPH):
+        with mapn.Compute(n, mass=70000.0 / n, flags=flags) as c:
+            c.set_timers(0)
+            forms = set()
+            for na in seq:
+                c.Simulate(na, c.GetFenceValue())
+                st = c.kernel_stats()
+                forms.add("split" if st.split_active else st.kernel_name.decode())
+            res.append([c.download_buffer(b) for b in (0, 1)])
+            assert {"split", "force_sym_kernel", "force_sgpr_kernel"} <= forms, forms
+    for other in res[1:]:
+        for b in (0, 1):
+            np.testing.assert_array_equal(res[0][b][0], other[b][0]); np.testing.assert_array_equal(res[0][b][1], other[b][1])
+    pos, vel = oracle.initial_state(n, seed=1)
+    sim = OracleSim(oracle, pos, vel, params=Params(mass=70000.0 / n))
+    for na in seq:
+        sim.simulate(num_active=na)
+    for b in (0, 1):
+        assert errs(res[0][b][0][:, :3], sim.pos[b][:, :3], SPREAD)[0] < 3e-6
+
+
 def test_split_form_falls_back_when_its_scratch_cannot_be_had(oracle, monkeypatch):
     """The split form's plan and scratch are made by the first step with a new num_active; if they cannot be had the step runs
     another form (and says why) instead of failing -- and is not tried again for that count."""

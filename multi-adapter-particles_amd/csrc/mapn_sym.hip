@@ -474,18 +474,18 @@ __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs
             ax += v.x; ay += v.y; az += v.z;
         }
     }
-    const SymRow *ar = p.arow + (size_t)a * p.parts * SYM_IB + (i - a * SYM_IB);
-    uint32_t s = 0;
-    for (; s + 8u <= p.parts; s += 8u) {                   // 8 loads in flight (one wave per SIMD: nothing else hides the latency), summed in ascending order
-        SymRow v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = ar[(size_t)(s + u) * SYM_IB];
-#pragma unroll
-        for (int u = 0; u < 8; u++) { ax += v[u].x; ay += v[u].y; az += v[u].z; }
-    }
-    for (; s < p.parts; s++) {
-        const SymRow v = ar[(size_t)s * SYM_IB];
-        ax += v.x; ay += v.y; az += v.z;
+    // The launch is ONE wave per SIMD walking a chain of dependent memory round trips (table lookup -> row loads -> sums), so what it
+    // costs is the NUMBER of trips (round 4: two per batch of eight groups + the a-rows + the state: 12 at 65 536 bodies, 10 us at 3.1
+    // TB/s).  Round 5: everything that depends on nothing goes out first (the body's state, the first batch's lookups, the a-rows),
+    // batches are 16 groups, and the NEXT batch's lookups are in flight with this batch's rows -- 4 trips.  The SUMS are taken in
+    // exactly the order they always were (the order-matched oracle does not change).
+    const bool last = p.acc_out == nullptr;
+    float4 pos = make_float4(0.f, 0.f, 0.f, 0.f);
+    float vx = 0.f, vy = 0.f, vz = 0.f;
+    if (last) {
+        pos = p.pos_old[i];
+        const float *v = p.vel_old + 3 * (size_t)i;
+        vx = v[0]; vy = v[1]; vz = v[2];
     }
     // the symmetric groups of this window; group g's row exists when some block meets this one under g: always for
     // g <= D, for the half-ring group D + 1 only if this block's half-ring PARTNER runs the pair's meetings (sym_runs_half)
@@ -496,44 +496,68 @@ __global__ __launch_bounds__(256) void sym_reduce_integrate_kernel(const SymArgs
     const uint32_t *splits = p.tab + p.sets * (p.nwaves + 1u);
     auto split_of = [&](uint32_t blk) { return splits + (size_t)((sym_runs_half(blk, p.half_d) ? 0u : 1u) + (p.sets > 2u ? 2u * (blk & 7u) : 0u)) * p.max_meetings; };
     const uint32_t t = jb % SYM_JPI;
-    for (uint32_t g = gs0; g < gend; g += 8u) {            // 8 meetings in flight, summed in ascending order
-        SymRow v[8], h[8];
-        uint32_t sp[8], apv[8];
-        // first ALL the table lookups of the batch, then all its row loads (the waits count in order)
+    constexpr uint32_t GB = 16u;                           // groups per batch
+    uint32_t sp[GB], apv[GB];
+    auto lookup = [&](uint32_t g, uint32_t (&spo)[GB], uint32_t (&apo)[GB]) {
 #pragma unroll
-        for (uint32_t u = 0; u < 8u; u++) {
+        for (uint32_t u = 0; u < GB; u++) {
             const uint32_t gu = g + u;
             const bool live = gu < gend;
             const uint32_t d = gu <= D ? gu : p.half_d;
-            apv[u] = a >= d ? a - d : a + p.nb - d;                                // the I-block that ran this meeting
-            sp[u] = live ? split_of(apv[u])[(gu - p.g0) * SYM_JPI + t] : 0xffffffffu;
+            apo[u] = a >= d ? a - d : a + p.nb - d;                                // the I-block that ran this meeting
+            spo[u] = live ? split_of(apo[u])[(gu - p.g0) * SYM_JPI + t] : 0xffffffffu;
         }
+    };
+    if (gs0 < gend) lookup(gs0, sp, apv);
+    const SymRow *ar = p.arow + (size_t)a * p.parts * SYM_IB + (i - a * SYM_IB);
+    uint32_t s = 0;
+    for (; s + 8u <= p.parts; s += 8u) {                   // 8 loads in flight, summed in ascending order
+        SymRow v[8];
 #pragma unroll
-        for (uint32_t u = 0; u < 8u; u++) {
+        for (int u = 0; u < 8; u++) v[u] = ar[(size_t)(s + u) * SYM_IB];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { ax += v[u].x; ay += v[u].y; az += v[u].z; }
+    }
+    if (s < p.parts) {                                     // (the usual case: 4 parts -- all in flight together)
+        SymRow v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) v[u] = ar[(size_t)(s + u < p.parts ? s + u : s) * SYM_IB];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++)
+            if (s + u < p.parts) { ax += v[u].x; ay += v[u].y; az += v[u].z; }
+    }
+    for (uint32_t g = gs0; g < gend; g += GB) {            // 16 meetings in flight, summed in ascending order
+        SymRow v[GB], h[GB];
+#pragma unroll
+        for (uint32_t u = 0; u < GB; u++) {
             // (no branch around a load: a lane without a row / without a head row re-reads a row that IS there and drops it --
-            //  eight branches per batch serialised the loads: the launch took 18.7 instead of 13.9 us at 65 536 bodies)
+            //  a branch per load serialised them: the launch took 18.7 instead of 13.9 us at 65 536 bodies)
             const bool live = g + u < gend;
             const SymRow *vsrc = br + (size_t)((live ? g + u : gs0) - gs0) * 64u;
             const SymRow *hsrc = sp[u] != 0xffffffffu ? p.brow1 + ((size_t)apv[u] * p.parts + sp[u]) * 64u + (i & 63u) : vsrc;
             v[u] = *vsrc;
             h[u] = *hsrc;
         }
+        uint32_t spn[GB], apn[GB];
+        const bool more = g + GB < gend;
+        if (more) lookup(g + GB, spn, apn);                // the next batch's lookups travel with this batch's rows
 #pragma unroll
-        for (uint32_t u = 0; u < 8u; u++) {
+        for (uint32_t u = 0; u < GB; u++) {
             if (!(g + u < gend)) v[u] = SymRow{0.f, 0.f, 0.f};
             if (sp[u] == 0xffffffffu) h[u] = SymRow{0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (uint32_t u = 0; u < 8u; u++) {
+        for (uint32_t u = 0; u < GB; u++) {
             ax += v[u].x; ay += v[u].y; az += v[u].z;
             ax += h[u].x; ay += h[u].y; az += h[u].z;
         }
+        if (more) {
+#pragma unroll
+            for (uint32_t u = 0; u < GB; u++) { sp[u] = spn[u]; apv[u] = apn[u]; }
+        }
     }
-    if (p.acc_out) { p.acc_out[i] = make_float4(ax, ay, az, 0.f); return; }
+    if (!last) { p.acc_out[i] = make_float4(ax, ay, az, 0.f); return; }
     ax *= p.mass; ay *= p.mass; az *= p.mass;
-    const float4 pos = p.pos_old[i];
-    const float *v = p.vel_old + 3 * (size_t)i;
-    float vx = v[0], vy = v[1], vz = v[2];
     vx = __builtin_fmaf(ax, p.dt, vx) * p.damping;
     vy = __builtin_fmaf(ay, p.dt, vy) * p.damping;
     vz = __builtin_fmaf(az, p.dt, vz) * p.damping;

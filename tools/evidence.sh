@@ -19,6 +19,7 @@
 #   closing                      what the ONE closing collective (barrier + verdict) adds to a timed region of K = 20 / 200 steps: two ranks sharing this GPU
 #                                (gloo) and one rank over the RCCL backend -> closing_cost.txt
 #   partial                      partially active steps: one-sided / full symmetric / split form over a sweep of num_active (tools/partial_sweep.py)
+#   partialstats [N ACTIVE]      rocprofv3 --kernel-trace --stats of 2000 half-active steps in the split form: the three launches' durations
 #   power                        rocm-smi package power / shader clock / temperature while each force kernel runs flat out for 14 s (tools/power_probe.sh)
 set -u
 R=$PWD; W=${1:-suite}; shift || true
@@ -41,6 +42,24 @@ closing)
   done ;;
 partial)
   python tools/partial_sweep.py "$@" 2>&1 | tee $O/partial_sweep.txt ;;
+partialstats)
+  # per-kernel times of a half-active step in its split form (65 536 bodies, 32 768 active; 2000 steps): the one-sided launch over the frozen
+  # bodies, the symmetric launch over the active blocks, the reduce launch
+  cat > /tmp/partial_steps.py <<'PY'
+import os, sys
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+import mapn
+n, na = int(sys.argv[1]), int(sys.argv[2])
+with mapn.Compute(n, device=0, mass=70000.0 / n) as c:
+    c.set_timers(0)
+    for _ in range(int(sys.argv[3])):
+        c.Simulate(na, c.GetFenceValue())
+    c.WaitForGpu()
+    assert c.kernel_stats().split_active == na
+PY
+  n=${1:-65536}; na=${2:-32768}; cd /tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/pstats -- python3 /tmp/partial_steps.py $n $na 2000 > /dev/null 2> $O/pstats.err
+  cd $R; f=$(ls -t $(find $O/pstats -name "*kernel_stats.csv") | head -1); cp $f $O/partial_kernel_stats.csv; head -6 $f; rm -rf $O/pstats ;;
 power)
   bash tools/power_probe.sh > $O/power_probe.txt 2>&1; cat $O/power_probe.txt ;;
 bench)

@@ -17,7 +17,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define MAPN_TUNING_ABI_VERSION 1   /* 1 (round 5): split off mapn.h (ABI 3); new: mapn_get_split_plan, mapn_kernel_stats.split_active, mapn_shard_describe */
+#define MAPN_TUNING_ABI_VERSION 1   /* 1 (round 5): split off mapn.h (ABI 3); new: mapn_get_split_plan, mapn_step_form_describe, mapn_kernel_stats.split_active, mapn_shard_describe */
 int mapn_tuning_abi_version(void);
 
 /* Force-kernel statistics accumulated by mapn_simulate: every step records HIP events on the
@@ -127,6 +127,11 @@ int mapn_set_sym_plan(mapn_ctx *ctx, uint32_t waves, uint32_t parts, uint32_t ta
  * zero -- then the symmetric plan's order over the bodies [0, active) as for mapn_get_sym_plan; the mass multiplies the total.
  * MAPN_ERR_STATE until such a step has run.  Same two-call pattern and capacity checks as mapn_get_sym_plan.
  */
+/* Which of the three forms an unsharded all-pairs step of a context whose symmetric kernel runs (MAPN_KERNEL_AUTO / SYMMETRIC, N >= 1024)
+ * takes for this (N, num_active), WITHOUT a device: 0 = the one-sided kernel over active x N, 1 = the full symmetric step (the reduce
+ * launch stops at roundup64(num_active)), 2 = the split form.  A pure function -- the cost model the library itself consults
+ * (csrc/mapn_sym_host.cpp, sym_form_by_cost) -- so a given count always sums in the same order; negative = an error. */
+int mapn_step_form_describe(uint32_t num_particles, int32_t num_active);
 typedef struct mapn_split_info {
     uint32_t active, frozen;
     uint32_t frozen_kernel;          /* mapn_kernel of the launch over the frozen bodies (MAPN_KERNEL_SCALAR / MAPN_KERNEL_LDS) */

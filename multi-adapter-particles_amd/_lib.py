@@ -152,6 +152,7 @@ SIGNATURES = {
     "mapn_get_step_samples": (C.c_int, [_ctx, C.POINTER(C.c_uint32), _fp, _fp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mapn_set_force_plan": (C.c_int, [_ctx, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     "mapn_set_shard_overlap": (C.c_int, [_ctx, C.c_int]),
+    "mapn_step_form_describe": (C.c_int, [C.c_uint32, C.c_int32]),
     "mapn_shard_describe": (C.c_int, [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(ShardInfo)]),
     "mapn_calibrate_sym_xcds": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_uint32 * 8)]),
     "mapn_set_sym_xcd_weights": (C.c_int, [_ctx, C.POINTER(C.c_uint32 * 8)]),

@@ -224,6 +224,7 @@ int stamps_prepare(mapn_ctx *c, size_t nw, mapn::SymArgs &a);
 mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t window);
 int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer);
 enum StepForm { FORM_ONE_SIDED = 0, FORM_SYM_FULL = 1, FORM_SYM_SPLIT = 2 };
+StepForm sym_form_by_cost(uint32_t n, uint32_t active);      // the cost model alone: a pure function of (N, roundup64(num_active))
 StepForm sym_step_form(const mapn_ctx *c, uint32_t active);   // which of the three forms an unsharded all-pairs step of `active` bodies runs
 int prepare_sym_active(mapn_ctx *c, uint32_t active);         // plan + scratch of the split form (no-op when already made for this A)
 void release_sym_active(mapn_ctx *c);

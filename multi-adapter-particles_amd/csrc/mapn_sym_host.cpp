@@ -209,15 +209,35 @@ int prepare_sym(mapn_ctx *c, bool sharded)
     return MAPN_OK;
 }
 
+// The cost model behind sym_step_form, a pure function of (N, active) -- also behind the device-less mapn_step_form_describe, which the
+// CPU tests hold against the measured sweep (profiles/r05_partial_active_sweep.txt).  Costs in pair evaluations at the symmetric
+// kernel's rate (measured, flat over 65 536 .. 4 194 304 bodies: 7.1e12 ordered pairs / s against 4.9e12 for the one-sided kernel):
+// full N^2; one-sided 1.45 A N; split roundup1024(A)^2 + 1.45 A (N - A) + the extra launch and the frozen rows' pass through the
+// reduce launch (about 17 us).
+StepForm sym_form_by_cost(uint32_t n, uint32_t active)
+{
+    if (active >= n) return FORM_SYM_FULL;
+    // (the full form stays the faster one against the one-sided kernel down to about 0.7 N active bodies)
+    const bool full_ok = (uint64_t)active * 4u >= (uint64_t)n * 3u;
+    const double ratio = 7.1 / 4.9, N = (double)n, A = (double)active;
+    const double Ap = (double)(((uint64_t)active + mapn::SYM_BLOCK - 1u) / mapn::SYM_BLOCK * mapn::SYM_BLOCK);
+    const double one = ratio * A * N, full = N * N, split = Ap * Ap + ratio * A * (N - A) + 1.2e8;
+    const double other = full_ok ? full : one;
+    // (3 % in hand: the symmetric kernel over an awkward block count -- one that fills no whole rounds of the compute units -- runs up to
+    //  7 % behind the model, e.g. 61 440 of 65 536 bodies active: split 0.644 ms against 0.621 for the full form; profiles/r05_partial_active_sweep.txt;
+    //  fewer than 8 blocks do not fill the device under the symmetric kernel at all)
+    if (active >= 8u * mapn::SYM_BLOCK && split < 0.97 * other) return FORM_SYM_SPLIT;
+    return full_ok ? FORM_SYM_FULL : FORM_ONE_SIDED;
+}
+
 // Which form an unsharded all-pairs step with `active` = roundup64(num_active) bodies runs (a pure function of the context's shape and
 // `active`: a given (N, num_active) always runs the same form, i.e. the same summation order):
 //   FORM_SYM_FULL   the symmetric kernel over all N bodies; the reduce launch stops at `active` (the frozen bodies still exert force)
 //   FORM_SYM_SPLIT  active x active under the symmetric kernel with a plan of the ACTIVE blocks only, active x frozen one-sided
 //                   (enqueue_sym_split) -- every evaluation that feeds only frozen bodies is dropped
 //   FORM_ONE_SIDED  active x N through the scalar-cache kernel
-// Costs in pair evaluations at the symmetric kernel's rate (measured, flat over 65 536 .. 4 194 304 bodies: 7.1e12 ordered pairs / s
-// against 4.9e12 for the one-sided kernel: profiles/r04_sizes_sym_vs_onesided.txt): full N^2; one-sided 1.45 A N; split
-// roundup1024(A)^2 + 1.45 A (N - A) + the extra launch and the frozen rows' pass through the reduce launch (about 17 us).
+// The choice is sym_form_by_cost above; here: whether the symmetric kernel runs in this context at all, the A/B hook, and a count
+// whose split plan could not be made.
 StepForm sym_step_form(const mapn_ctx *c, uint32_t active)
 {
     if (!c->sym_ready || c->sym_sharded || c->plan_forced || active == 0) return FORM_ONE_SIDED;
@@ -230,15 +250,9 @@ StepForm sym_step_form(const mapn_ctx *c, uint32_t active)
         if (f[0] == 'f') return FORM_SYM_FULL;
         if (f[0] == 's' && active >= 2u * mapn::SYM_BLOCK) return FORM_SYM_SPLIT;
     }
-    const double ratio = 7.1 / 4.9, N = (double)c->n, A = (double)active;
-    const double Ap = (double)(((uint64_t)active + mapn::SYM_BLOCK - 1u) / mapn::SYM_BLOCK * mapn::SYM_BLOCK);
-    const double one = ratio * A * N, full = N * N, split = Ap * Ap + ratio * A * (N - A) + 1.2e8;
-    const double other = full_ok ? full : one;
-    // (3 % in hand: the symmetric kernel over an awkward block count -- one that fills no whole rounds of the compute units -- runs up to
-    //  7 % behind the model, e.g. 61 440 of 65 536 bodies active: split 0.644 ms against 0.621 for the full form; profiles/r05_partial_active_sweep.txt;
-    //  fewer than 8 blocks do not fill the device under the symmetric kernel at all)
-    if (active >= 8u * mapn::SYM_BLOCK && c->act_failed != active && split < 0.97 * other) return FORM_SYM_SPLIT;
-    return full_ok ? FORM_SYM_FULL : FORM_ONE_SIDED;
+    const StepForm form = sym_form_by_cost(c->n, active);
+    if (form == FORM_SYM_SPLIT && c->act_failed == active) return full_ok ? FORM_SYM_FULL : FORM_ONE_SIDED;   // (its plan or scratch could not be had for this count)
+    return form;
 }
 
 // this STEP runs the symmetric kernel over the whole job (all bodies active, or so many that the frozen ones are not worth a split)
@@ -893,6 +907,15 @@ int mapn_get_sym_plan(mapn_ctx *c, mapn_sym_plan_info *info, uint32_t *windows, 
     info->active_compute_units = c->sym_sharded ? (uint32_t)c->cus_active : 0u;
     info->exchange_workgroups = c->sym_sharded ? c->sym_exchange_cap : 0u;
     return export_plan(c->sym_plan, "get_sym_plan", info, windows, windows_capacity, tables, tables_capacity);
+}
+
+int mapn_step_form_describe(uint32_t num_particles, int32_t num_active)
+{
+    if (num_particles == 0) return fail(MAPN_ERR_INVALID_ARGUMENT, "step_form_describe: num_particles must be > 0");
+    const uint32_t active = active_bodies(num_active, num_particles);
+    if (active == 0) return (int)FORM_ONE_SIDED;                 // (nothing advances: the step only flips)
+    if (num_particles < mapn::SYM_BLOCK) return (int)FORM_ONE_SIDED;      // (less than one block: the symmetric kernel does not apply)
+    return (int)sym_form_by_cost(num_particles, active);
 }
 
 int mapn_get_split_plan(mapn_ctx *c, mapn_split_info *split, mapn_sym_plan_info *info, uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity)

@@ -49,3 +49,24 @@ def test_split_restatement_refuses_shapes_that_do_not_fit(oracle):
     sim = OracleSim(oracle, pos, vel, params=Params(mass=1.0), split_plan=(split_of(n, active, 8, 1), plan))
     with pytest.raises(AssertionError):
         sim.simulate(num_active=active)
+
+
+def test_the_cost_model_picks_what_the_sweep_measured(lib):
+    """mapn_step_form_describe (product, no device): the form an unsharded all-pairs step takes for (N, num_active), against the measured
+    sweep (profiles/r05_partial_active_sweep.txt: one box; where two forms were within 1 % either pick is right and is not listed here).
+    0 = one-sided, 1 = full symmetric, 2 = split."""
+    ONE, FULL, SPLIT = 0, 1, 2
+    table = {65536: {8192: ONE, 24576: SPLIT, 32768: SPLIT, 40960: SPLIT, 49152: SPLIT, 57344: SPLIT, 61440: FULL, 63552: FULL, 65536: FULL},
+             262144: {65536: SPLIT, 98304: SPLIT, 131072: SPLIT, 163840: SPLIT, 196608: SPLIT, 229376: SPLIT, 245760: SPLIT, 254272: FULL, 262144: FULL},
+             4194304: {2097152: SPLIT, 3145728: SPLIT, 4194304: FULL}}
+    for n, rows in table.items():
+        for na, want in rows.items():
+            assert lib.mapn_step_form_describe(n, na) == want, (n, na)
+    # rounding and edges: Compute.cpp:1041 (groups of 64), nothing active, more than N, a job smaller than one block, too few active blocks
+    assert lib.mapn_step_form_describe(65536, 32705) == lib.mapn_step_form_describe(65536, 32768) == SPLIT
+    assert lib.mapn_step_form_describe(65536, 0) == ONE and lib.mapn_step_form_describe(65536, -3) == ONE
+    assert lib.mapn_step_form_describe(65536, 10 ** 9) == FULL and lib.mapn_step_form_describe(1000, 1000) == ONE
+    assert lib.mapn_step_form_describe(4096, 3500) == FULL and lib.mapn_step_form_describe(4096, 1000) == ONE      # (tests/test_gpu_sym.py: the small job's forms)
+    assert lib.mapn_step_form_describe(0, 5) < 0
+    # a pure function: the same answer every time
+    assert len({lib.mapn_step_form_describe(100000, 50000) for _ in range(5)}) == 1

@@ -92,6 +92,10 @@ class Oracle:
         lib.mapn_oracle_step_all_pairs_sym_split.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int,
                                                              C.POINTER(SymShape), _u32p, _u32p, C.c_uint32, C.c_uint32]
         lib.mapn_oracle_step_all_pairs_sym_split.restype = C.c_int
+        _u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+        lib.mapn_oracle_step_all_pairs_sym_sharded.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.POINTER(Params), C.c_int, C.c_uint32,
+                                                               C.POINTER(SymShape), _u32p, _u32p, _u64p, C.c_uint32]
+        lib.mapn_oracle_step_all_pairs_sym_sharded.restype = C.c_int
         lib.mapn_oracle_step_all_pairs_f64.argtypes = [_f64p, _f64p, _f64p, _f64p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int]
         lib.mapn_oracle_step_all_pairs_f64.restype = C.c_int
         lib.mapn_oracle_accel_all_pairs.argtypes = [_f32p, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
@@ -186,6 +190,33 @@ class Oracle:
             else:
                 self.lib.mapn_oracle_step_all_pairs(pos, vel, npos, nvel, pos.shape[0], first, count, C.byref(params), threads)
         return npos[first:first + count].copy(), nvel[first:first + count].copy()
+
+
+def step_sym_sharded(oracle, pos, vel, params, rank_plans, threads=0):
+    """One all-active step of the SYMMETRIC kernel SHARDED over len(rank_plans) ranks in the device's summation order
+    (ORDER_MATCHED_SHARDED): rank_plans[r] = rank r's launch plan (duck-typed like sym_plan_args' argument: the plan
+    mapn_get_sym_plan returned on that rank).  Returns (new_pos, new_vel)."""
+    world = len(rank_plans)
+    n = pos.shape[0]
+    args = [sym_plan_args(pl) for pl in rank_plans]
+    shapes = (SymShape * world)(*[a[0] for a in args])
+    for a in args:
+        assert a[1].shape[0] == 1, "the sharded step is made in one window"
+    wins = np.ascontiguousarray(np.concatenate([a[1].reshape(-1) for a in args]), np.uint32)
+    offs = np.zeros(world, np.uint64)
+    tabs = []
+    at = 0
+    for r, a in enumerate(args):
+        offs[r] = at
+        tabs.append(a[2]); at += a[2].size
+    tab = np.ascontiguousarray(np.concatenate(tabs), np.uint32)
+    count = n // world
+    G = 8 if count <= 16384 else 4 if count <= 65536 else 1          # exchange_threads_per_body (csrc/mapn_sym.hip)
+    pos = np.ascontiguousarray(pos, np.float32); vel = np.ascontiguousarray(vel, np.float32)
+    npos, nvel = pos.copy(), vel.copy()
+    rc = oracle.lib.mapn_oracle_step_all_pairs_sym_sharded(pos, vel, npos, nvel, n, C.byref(params), threads, world, shapes, wins, tab, offs, G)
+    assert rc == 0, rc
+    return npos, nvel
 
 
 class OracleSim:

@@ -783,6 +783,7 @@ typedef struct {
     float *acc;                 /* [3][nb*1024] running sum between windows */
     int first_window, last_window;
     uint32_t tid, nthreads;
+    uint32_t a0, shard_nbl;     /* ORDER_MATCHED_SHARDED: this rank's first block and block count (0: the whole job in one launch) */
 } sym_job;
 
 static inline void sym_body(const sym_job *J, uint32_t i, float *x, float *y, float *z)
@@ -799,7 +800,8 @@ static void sym_workgroup(const sym_job *J, uint32_t a, uint32_t s, float *scrat
     const uint32_t nb = sh->nb, D = (nb - 1u) / 2u, half = (nb & 1u) ? 0u : nb / 2u, W = sh->waves;
     const uint32_t g0 = J->win[0];
     const uint32_t cls = sym_runs_half(a, half) ? 0u : 1u;
-    const uint32_t set = cls + (sh->sets > 2u ? 2u * (a & 7u) : 0u);
+    const uint32_t la = a - J->a0;                                       /* the block within its launch (a rank's blocks when sharded) */
+    const uint32_t set = cls + (sh->sets > 2u ? 2u * (la & 7u) : 0u);
     const uint32_t *bounds = J->tab + set * (sh->parts * W + 1u);
     const float soft2 = J->p->soft2;
     float *xi = scratch, *yi = xi + SYM_IB, *zi = yi + SYM_IB;          /* the I-block */
@@ -854,8 +856,9 @@ static void sym_workgroup(const sym_job *J, uint32_t a, uint32_t s, float *scrat
             t += steps;
             if (d == 0u) continue;
             /* where the piece's reactions go (force_sym_kernel) */
-            const size_t row = sh->brows ? ((size_t)jb * sh->brows + (g - (g0 ? g0 : 1u))) : 0;
-            float *r0 = J->brow + row * 192u, *h0 = J->brow1 + ((size_t)a * sh->parts + s) * 192u;
+            /* (sharded: one row per (J-block, local I-block) -- the exchange adds them up per destination rank) */
+            const size_t row = J->shard_nbl ? (size_t)jb * J->shard_nbl + la : sh->brows ? ((size_t)jb * sh->brows + (g - (g0 ? g0 : 1u))) : 0;
+            float *r0 = J->brow + row * 192u, *h0 = J->brow1 + ((size_t)la * sh->parts + s) * 192u;
             for (uint32_t l = 0; l < 64; l++) {
                 const float qx = rxe[l] + rxo[l], qy = rye[l] + ryo[l], qz = rze[l] + rzo[l];
                 if (steps == 64u) { r0[l] = qx; r0[64 + l] = qy; r0[128 + l] = qz; }
@@ -871,7 +874,7 @@ static void sym_workgroup(const sym_job *J, uint32_t a, uint32_t s, float *scrat
         }
     }
     /* the workgroup's row: waves in ascending order, starting from zero */
-    float *row = J->arow + ((size_t)a * sh->parts + s) * 3u * SYM_IB;
+    float *row = J->arow + ((size_t)la * sh->parts + s) * 3u * SYM_IB;
     for (uint32_t e = 0; e < SYM_IB; e++) {
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
         for (uint32_t w = 0; w < W; w++) {
@@ -887,7 +890,7 @@ static void sym_workgroup(const sym_job *J, uint32_t a, uint32_t s, float *scrat
         const uint32_t m = t0 >> 6, g = g0 + m / SYM_JPI, d = g <= D ? g : half;
         if (d == 0u) continue;
         const uint32_t jb = ((a + d) % nb) * SYM_JPI + m % SYM_JPI;
-        float *r0 = J->brow + ((size_t)jb * sh->brows + (g - (g0 ? g0 : 1u))) * 192u;
+        float *r0 = J->brow + (J->shard_nbl ? (size_t)jb * J->shard_nbl + la : (size_t)jb * sh->brows + (g - (g0 ? g0 : 1u))) * 192u;
         const float *e0 = edge + ((size_t)(0u * W + w - 1u) * 3u) * 64u, *e1 = edge + ((size_t)(1u * W + w) * 3u) * 64u;
         for (uint32_t l = 0; l < 192; l++) r0[l] = e0[l] + e1[l];
     }
@@ -899,8 +902,8 @@ static void *sym_force_worker(void *arg)
     const mapn_oracle_sym_shape *sh = J->sh;
     float *scratch = (float *)malloc(sizeof(float) * (3u * SYM_IB + (size_t)sh->waves * 3u * SYM_IB + 2u * sh->waves * 192u));
     if (!scratch) return NULL;
-    const uint32_t items = sh->nb * sh->parts;
-    for (uint32_t it = J->tid; it < items; it += J->nthreads) sym_workgroup(J, it / sh->parts, it % sh->parts, scratch);
+    const uint32_t items = (J->shard_nbl ? J->shard_nbl : sh->nb) * sh->parts;
+    for (uint32_t it = J->tid; it < items; it += J->nthreads) sym_workgroup(J, J->a0 + it / sh->parts, it % sh->parts, scratch);
     free(scratch);
     return NULL;
 }
@@ -980,7 +983,7 @@ int mapn_oracle_step_all_pairs_sym(const float *old_pos, const float *old_vel, f
     int rc = (arow && brow && brow1 && acc) ? 0 : -1;
     for (uint32_t k = 0; k < shape->windows && rc == 0; k++) {
         sym_job J = {old_pos, old_vel, new_pos, new_vel, n, p, shape, windows + 4u * k, tables + (size_t)k * shape->table_stride,
-                     arow, brow, brow1, acc, k == 0, k + 1u == shape->windows, 0, 0};
+                     arow, brow, brow1, acc, k == 0, k + 1u == shape->windows, 0, 0, 0, 0};
         const uint32_t items = shape->nb * shape->parts;
         rc = sym_run(sym_force_worker, &J, (uint32_t)threads > items ? (int)items : threads);
         if (rc == 0) rc = sym_run(sym_reduce_worker, &J, threads);
@@ -1100,11 +1103,129 @@ int mapn_oracle_step_all_pairs_sym_split(const float *old_pos, const float *old_
     /* (2) the active bodies among themselves: the symmetric plan of a job of n_active bodies, the frozen sum as the running sum */
     for (uint32_t k = 0; k < shape->windows && rc == 0; k++) {
         sym_job J = {old_pos, old_vel, new_pos, new_vel, n_active, p, shape, windows + 4u * k, tables + (size_t)k * shape->table_stride,
-                     arow, brow, brow1, acc, 0, k + 1u == shape->windows, 0, 0};
+                     arow, brow, brow1, acc, 0, k + 1u == shape->windows, 0, 0, 0, 0};
         const uint32_t items = shape->nb * shape->parts;
         rc = sym_run(sym_force_worker, &J, (uint32_t)threads > items ? (int)items : threads);
         if (rc == 0) rc = sym_run(sym_reduce_worker, &J, threads);
     }
     free(arow); free(brow); free(brow1); free(acc);
+    return rc;
+}
+
+/* =================================================================================================
+ * ORDER_MATCHED_SHARDED: the device's SYMMETRIC step SHARDED over ranks (gather algorithms 4 / 5 / 6; csrc/mapn_sym.hip,
+ * sym_shard_exchange_kernel), all ranks restated in one process.  Rank p owns the blocks [a0, a0 + nbl) and
+ *   * runs their meetings under ITS plan (force_sym_kernel with a0 / shard_nbl; one window): a-rows per (local block, part), reaction
+ *     rows per (J-block, local block), head rows per (local block, part) -- sym_workgroup above with J->a0, J->shard_nbl;
+ *   * SENDS, per destination rank q and body t of q: the rows of its blocks that met the body's block, local blocks ascending, a
+ *     meeting's row then its head row (zeros where there is none), added to zero;
+ *   * INTEGRATES its bodies: G partial sums of the a-rows -- parts [P g / G, P (g + 1) / G) ascending from zero -- added in ascending g
+ *     to zero, then the rows received, nearest sender first (this rank, rank - 1, rank - 2, ... mod world; a zero for a rank that sends
+ *     nothing, up to 16 places like the device), then total * mass and the fused integrator.
+ * What is left against the device is v_rsq_f32 alone; the transport (pushed / pulled positions, RCCL) changes no bit.
+ * ================================================================================================= */
+#define SHARD_MAX_RANKS 16u
+
+static inline uint32_t sym_group_of(uint32_t a, uint32_t b, uint32_t nb, uint32_t half)
+{
+    const uint32_t d = b >= a ? b - a : b + nb - a, D = (nb - 1u) / 2u;
+    return (d >= 1u && d <= D) ? d : (half && d == half && sym_runs_half(a, half)) ? D + 1u : 0u;
+}
+
+/* shapes[r], windows + 4 r, tables + table_offset[r]: rank r's plan (mapn_get_sym_plan on that rank); G: threads per body of the exchange
+ * launch (8 up to 16 384 bodies per rank, 4 up to 65 536, else 1: exchange_threads_per_body) */
+int mapn_oracle_step_all_pairs_sym_sharded(const float *old_pos, const float *old_vel, float *new_pos, float *new_vel, uint32_t n,
+                                           const mapn_oracle_params *p, int threads, uint32_t world, const mapn_oracle_sym_shape *shapes,
+                                           const uint32_t *windows, const uint32_t *tables, const uint64_t *table_offset, uint32_t G)
+{
+    if (!shapes || !windows || !tables || !table_offset || world < 2u || world > SHARD_MAX_RANKS || n % world || (n / world) % SYM_IB || G == 0u) return -2;
+    if (threads <= 0) threads = mapn_oracle_hardware_threads();
+    const uint32_t count = n / world, nb = n / SYM_IB, nbl = count / SYM_IB, half = (nb & 1u) ? 0u : nb / 2u;
+    for (uint32_t r = 0; r < world; r++)
+        if (shapes[r].nb != nb || shapes[r].windows != 1u || shapes[r].waves == 0 || shapes[r].parts == 0 || (shapes[r].sets != 2u && shapes[r].sets != 16u)) return -2;
+    /* recv[q][r][body of q]: what rank r sends rank q */
+    float *recv = (float *)calloc((size_t)world * world * count * 3u, sizeof(float));
+    uint32_t sends[SHARD_MAX_RANKS][SHARD_MAX_RANKS];          /* sends[r][q] != 0: rank r produces reactions for rank q */
+    memset(sends, 0, sizeof sends);
+    for (uint32_t a = 0; a < nb; a++)
+        for (uint32_t b = 0; b < nb; b++)
+            if (sym_group_of(a, b, nb, half)) sends[a / nbl][b / nbl] = 1u;
+    size_t arow_max = 0;
+    for (uint32_t r = 0; r < world; r++) if (shapes[r].parts > arow_max) arow_max = shapes[r].parts;
+    float **arows = (float **)calloc(world, sizeof(float *));
+    float *brow = (float *)malloc(sizeof(float) * 192u * (size_t)(n / 64u) * nbl);
+    float *brow1 = (float *)malloc(sizeof(float) * 192u * (size_t)nbl * arow_max);
+    int rc = (recv && arows && brow && brow1) ? 0 : -1;
+    for (uint32_t r = 0; r < world && rc == 0; r++) {
+        const mapn_oracle_sym_shape *sh = &shapes[r];
+        const uint32_t a0 = r * nbl;
+        arows[r] = (float *)malloc(sizeof(float) * 3u * SYM_IB * (size_t)nbl * sh->parts);
+        if (!arows[r]) { rc = -1; break; }
+        sym_job J = {old_pos, old_vel, new_pos, new_vel, n, p, sh, windows + 4u * r, tables + table_offset[r], arows[r], brow, brow1, NULL, 1, 1, 0, 0, a0, nbl};
+        const uint32_t items = nbl * sh->parts;
+        rc = sym_run(sym_force_worker, &J, (uint32_t)threads > items ? (int)items : threads);
+        if (rc) break;
+        /* SEND: per destination q and body t of q */
+        const uint32_t *splits = J.tab + sh->sets * (sh->parts * sh->waves + 1u);
+        for (uint32_t q = 0; q < world; q++) {
+            if (!sends[r][q]) continue;
+            for (uint32_t jl = 0; jl < count; jl++) {
+                const uint32_t t = q * count + jl, b = t / SYM_IB, jb = t >> 6, tt = jb % SYM_JPI, l = t & 63u;
+                float fx = 0.0f, fy = 0.0f, fz = 0.0f;
+                for (uint32_t la0 = 0; la0 < nbl; la0 += 8u)
+                    for (uint32_t u = 0; u < 8u; u++) {                    /* batches of eight like the device: a missing row is a zero that is still added */
+                        const uint32_t la = la0 + u;
+                        float vx = 0.0f, vy = 0.0f, vz = 0.0f, hx = 0.0f, hy = 0.0f, hz = 0.0f;
+                        const uint32_t gg = la < nbl ? sym_group_of(a0 + la, b, nb, half) : 0u;
+                        if (gg) {
+                            const float *r0 = brow + ((size_t)jb * nbl + la) * 192u;
+                            vx = r0[l]; vy = r0[64 + l]; vz = r0[128 + l];
+                            const uint32_t set = (sym_runs_half(a0 + la, half) ? 0u : 1u) + (sh->sets > 2u ? 2u * (la & 7u) : 0u);
+                            const uint32_t sp = (splits + (size_t)set * sh->max_meetings)[gg * SYM_JPI + tt];
+                            if (sp != SYM_NONE) {
+                                const float *h0 = brow1 + ((size_t)la * sh->parts + sp) * 192u;
+                                hx = h0[l]; hy = h0[64 + l]; hz = h0[128 + l];
+                            }
+                        }
+                        fx = fx + vx; fy = fy + vy; fz = fz + vz;
+                        fx = fx + hx; fy = fy + hy; fz = fz + hz;
+                    }
+                float *dst = recv + (((size_t)q * world + r) * count + jl) * 3u;
+                dst[0] = fx; dst[1] = fy; dst[2] = fz;
+            }
+        }
+    }
+    /* INTEGRATE: every rank its own bodies */
+    for (uint32_t r = 0; r < world && rc == 0; r++) {
+        const mapn_oracle_sym_shape *sh = &shapes[r];
+        for (uint32_t il = 0; il < count; il++) {
+            const uint32_t la = il / SYM_IB, e = il - la * SYM_IB, i = r * count + il;
+            float ax = 0.0f, ay = 0.0f, az = 0.0f;
+            for (uint32_t g = 0; g < G; g++) {
+                const uint32_t s0 = (uint32_t)(((uint64_t)sh->parts * g) / G), s1 = (uint32_t)(((uint64_t)sh->parts * (g + 1u)) / G);
+                float px = 0.0f, py = 0.0f, pz = 0.0f;
+                for (uint32_t s = s0; s < s1; s++) {
+                    const float *row = arows[r] + ((size_t)la * sh->parts + s) * 3u * SYM_IB + e;
+                    px = px + row[0]; py = py + row[SYM_IB]; pz = pz + row[2u * SYM_IB];
+                }
+                ax = ax + px; ay = ay + py; az = az + pz;
+            }
+            for (uint32_t k = 0; k < SHARD_MAX_RANKS; k++) {
+                float rx = 0.0f, ry = 0.0f, rz = 0.0f;
+                if (k < world) {
+                    const uint32_t q = r >= k ? r - k : r + world - k;
+                    if (sends[q][r]) {
+                        const float *src = recv + (((size_t)r * world + q) * count + il) * 3u;
+                        rx = src[0]; ry = src[1]; rz = src[2];
+                    }
+                }
+                ax = ax + rx; ay = ay + ry; az = az + rz;
+            }
+            integrate_fused(old_pos + 4 * (size_t)i, old_vel + 3 * (size_t)i, ax * p->mass, ay * p->mass, az * p->mass, p,
+                            new_pos + 4 * (size_t)i, new_vel + 3 * (size_t)i);
+        }
+    }
+    for (uint32_t r = 0; r < world; r++) free(arows ? arows[r] : NULL);
+    free(arows); free(recv); free(brow); free(brow1);
     return rc;
 }

@@ -138,6 +138,11 @@ def main():
             assert c.kernel_stats().kernel_name.decode() == want, c.kernel_stats().kernel_name
         pos, vel = c.download_state()
         other = c.download_buffer(c.buffer_index)[0]
+        if mode in ("sym", "sympush") and not mixed and num_active == n and count % 1024 == 0:
+            # this rank's launch plan, for the order-matched restatement of the sharded step (oracle: ORDER_MATCHED_SHARDED)
+            pl = c.sym_plan()
+            np.savez(os.path.join(out_dir, f"plan_rank{rank}.npz"), windows=pl.windows, tables=pl.tables,
+                     shape=np.array([pl.nb, pl.groups, pl.parts, pl.waves, pl.brows, pl.max_meetings, pl.table_stride, pl.sets, pl.a0, pl.nbl], np.uint32))
         # every replica must hold the same positions, bit for bit
         sums = [None] * world
         dist.all_gather_object(sums, (int(np.frombuffer(pos.tobytes(), np.uint32).sum(dtype=np.uint64)),

@@ -70,3 +70,24 @@ def test_the_cost_model_picks_what_the_sweep_measured(lib):
     assert lib.mapn_step_form_describe(0, 5) < 0
     # a pure function: the same answer every time
     assert len({lib.mapn_step_form_describe(100000, 50000) for _ in range(5)}) == 1
+
+
+@pytest.mark.parametrize("n,world,parts,waves", [(8192, 2, 8, 4), (8192, 4, 8, 4), (9216, 3, 8, 4), (16384, 8, 4, 8), (6144, 2, 4, 4)])
+def test_sharded_symmetric_restatement_matches_the_reference_order_oracle(oracle, n, world, parts, waves):
+    """ORDER_MATCHED_SHARDED (oracle/mapn_oracle.c): all ranks of the sharded symmetric step restated in one process from per-rank plans
+    computed without a device (mapn_sym_plan_describe with the rank's launch_blocks / launch_a0) -- force rows per rank, reactions summed per
+    destination, own partial sums + rows received nearest sender first -- against the oracle proper: the same physics to rounding, even and
+    odd block counts (the half-ring group alternates between the ranks), one block per rank up to eight."""
+    from oracle import step_sym_sharded
+    nb, nbl = n // 1024, n // 1024 // world
+    plans = [mapn.compute.describe_sym_plan(nb, parts=parts, waves=waves, launch_blocks=nbl, launch_a0=r * nbl) for r in range(world)]
+    pos, vel = oracle.initial_state(n, seed=2)
+    prm = Params(mass=70000.0 / n)
+    p, v = step_sym_sharded(oracle, pos, vel, prm, plans)
+    ref = OracleSim(oracle, pos, vel, params=prm); ref.simulate()
+    rp, rv = ref.latest
+    assert np.linalg.norm(p[:, :3].astype(np.float64) - rp[:, :3], axis=1).max() / 400.0 < 1e-6
+    assert np.linalg.norm(v.astype(np.float64) - rv, axis=1).max() / 15.0 < 2e-5
+    assert np.abs(p[:, 3] - rp[:, 3]).max() <= 1e-4 * rp[:, 3].max()
+    p2, v2 = step_sym_sharded(oracle, pos, vel, prm, plans, threads=3)
+    np.testing.assert_array_equal(p, p2); np.testing.assert_array_equal(v, v2)          # fixed-order sums: thread count changes nothing

@@ -154,6 +154,36 @@ def test_symmetric_step_sharded_over_processes(tmp_path, oracle, world, n, mode)
     assert dx < 8e-6 and dv < 1e-4, (dx, dv)
 
 
+@pytest.mark.parametrize("mode,world,n", [("sympush", 2, 8192), ("sym", 4, 8192), ("sympush", 8, 16384), ("sympush", 3, 9216), ("sympush", 2, 65536)])
+def test_sharded_symmetric_step_against_its_order_matched_oracle(tmp_path, oracle, mode, world, n):
+    """The sharded symmetric step's summation order restated on the CPU from the plans the RANKS report (every rank dumps
+    mapn_get_sym_plan): each rank's force rows, the reactions summed per destination over the sender's blocks, the receiver's G partial
+    sums + the rows received nearest sender first (oracle/mapn_oracle.c, ORDER_MATCHED_SHARDED).  What is left against the device is
+    v_rsq_f32 alone: most bodies bit-identical after two steps, none farther than an ulp or two of the position -- a row sent to the wrong
+    rank, summed in another order, dropped or doubled would show at 1e-5 and more.  `world` real processes on one GPU."""
+    import types
+    from oracle import Params, step_sym_sharded
+    steps = 2
+    got = _run_ranks(tmp_path, world, n, steps, mode, str(n))
+    plans = []
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"plan_rank{r}.npz"))
+        nb, groups, parts, waves, brows, max_meetings, table_stride, sets, a0, nbl = (int(x) for x in d["shape"])
+        assert a0 == r * (n // world // 1024) and nbl == n // world // 1024 and nb == n // 1024
+        plans.append(types.SimpleNamespace(nb=nb, groups=groups, parts=parts, waves=waves, brows=brows, max_meetings=max_meetings, table_stride=table_stride,
+                                           sets=sets, windows=d["windows"], tables=d["tables"]))
+    pos, vel = oracle.initial_state(n, seed=1)
+    prm = Params(mass=70000.0 / n)
+    for _ in range(steps):
+        pos, vel = step_sym_sharded(oracle, pos, vel, prm, plans)
+    p, v = got["pos"], got["vel"]
+    rel = np.linalg.norm(p[:, :3].astype(np.float64) - pos[:, :3], axis=1) / np.maximum(np.linalg.norm(pos[:, :3].astype(np.float64), axis=1), 1e-30)
+    same = float((p[:, :3] == pos[:, :3]).all(axis=1).mean())
+    print(f"{mode} world={world} n={n}: plan {plans[0].waves}x{plans[0].parts}: vs the order-matched sharded oracle after {steps} steps: max rel {rel.max():.2e}, bit-identical bodies {same:.4f}")
+    assert rel.max() <= 3e-7 and same >= 0.9
+    assert np.linalg.norm(v.astype(np.float64) - vel, axis=1).max() / 15.0 < 1e-6
+
+
 def test_pushed_positions_give_the_same_bits_as_pulled_ones(tmp_path):
     """Gather algorithm 5 against 4: the same arithmetic, another transport for the new positions -- bit-identical, also when
     steps that freeze part of the bodies (one-sided kernel + peer-to-peer pull, preceded by the wait for the peers' pushes) are

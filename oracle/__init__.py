@@ -94,7 +94,7 @@ class Oracle:
         lib.mapn_oracle_step_all_pairs_sym_split.restype = C.c_int
         _u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
         lib.mapn_oracle_step_all_pairs_sym_sharded.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.POINTER(Params), C.c_int, C.c_uint32,
-                                                               C.POINTER(SymShape), _u32p, _u32p, _u64p, C.c_uint32]
+                                                               C.POINTER(SymShape), _u32p, _u32p, _u64p, C.c_uint32, C.c_int32]
         lib.mapn_oracle_step_all_pairs_sym_sharded.restype = C.c_int
         lib.mapn_oracle_step_all_pairs_f64.argtypes = [_f64p, _f64p, _f64p, _f64p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int]
         lib.mapn_oracle_step_all_pairs_f64.restype = C.c_int
@@ -192,10 +192,11 @@ class Oracle:
         return npos[first:first + count].copy(), nvel[first:first + count].copy()
 
 
-def step_sym_sharded(oracle, pos, vel, params, rank_plans, threads=0):
+def step_sym_sharded(oracle, pos, vel, params, rank_plans, threads=0, only_rank=-1):
     """One all-active step of the SYMMETRIC kernel SHARDED over len(rank_plans) ranks in the device's summation order
     (ORDER_MATCHED_SHARDED): rank_plans[r] = rank r's launch plan (duck-typed like sym_plan_args' argument: the plan
-    mapn_get_sym_plan returned on that rank).  Returns (new_pos, new_vel)."""
+    mapn_get_sym_plan returned on that rank).  only_rank >= 0: that rank alone, receiving nothing from the others (the device's loopback
+    hook MAPN_P2P_LOOPBACK=2; the other entries of rank_plans are then not looked at beyond their shape).  Returns (new_pos, new_vel)."""
     world = len(rank_plans)
     n = pos.shape[0]
     args = [sym_plan_args(pl) for pl in rank_plans]
@@ -214,7 +215,7 @@ def step_sym_sharded(oracle, pos, vel, params, rank_plans, threads=0):
     G = 8 if count <= 16384 else 4 if count <= 65536 else 1          # exchange_threads_per_body (csrc/mapn_sym.hip)
     pos = np.ascontiguousarray(pos, np.float32); vel = np.ascontiguousarray(vel, np.float32)
     npos, nvel = pos.copy(), vel.copy()
-    rc = oracle.lib.mapn_oracle_step_all_pairs_sym_sharded(pos, vel, npos, nvel, n, C.byref(params), threads, world, shapes, wins, tab, offs, G)
+    rc = oracle.lib.mapn_oracle_step_all_pairs_sym_sharded(pos, vel, npos, nvel, n, C.byref(params), threads, world, shapes, wins, tab, offs, G, int(only_rank))
     assert rc == 0, rc
     return npos, nvel
 

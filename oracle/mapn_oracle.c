@@ -1136,8 +1136,10 @@ static inline uint32_t sym_group_of(uint32_t a, uint32_t b, uint32_t nb, uint32_
  * launch (8 up to 16 384 bodies per rank, 4 up to 65 536, else 1: exchange_threads_per_body) */
 int mapn_oracle_step_all_pairs_sym_sharded(const float *old_pos, const float *old_vel, float *new_pos, float *new_vel, uint32_t n,
                                            const mapn_oracle_params *p, int threads, uint32_t world, const mapn_oracle_sym_shape *shapes,
-                                           const uint32_t *windows, const uint32_t *tables, const uint64_t *table_offset, uint32_t G)
+                                           const uint32_t *windows, const uint32_t *tables, const uint64_t *table_offset, uint32_t G, int32_t only_rank)
 {
+    /* only_rank >= 0: that rank ALONE, receiving nothing from the others (the device's loopback hook MAPN_P2P_LOOPBACK=2: its bodies get the
+     * forces of its blocks' meetings plus the reactions of meetings between two of its own blocks); the other ranks' bodies are left as they are */
     if (!shapes || !windows || !tables || !table_offset || world < 2u || world > SHARD_MAX_RANKS || n % world || (n / world) % SYM_IB || G == 0u) return -2;
     if (threads <= 0) threads = mapn_oracle_hardware_threads();
     const uint32_t count = n / world, nb = n / SYM_IB, nbl = count / SYM_IB, half = (nb & 1u) ? 0u : nb / 2u;
@@ -1157,6 +1159,7 @@ int mapn_oracle_step_all_pairs_sym_sharded(const float *old_pos, const float *ol
     float *brow1 = (float *)malloc(sizeof(float) * 192u * (size_t)nbl * arow_max);
     int rc = (recv && arows && brow && brow1) ? 0 : -1;
     for (uint32_t r = 0; r < world && rc == 0; r++) {
+        if (only_rank >= 0 && r != (uint32_t)only_rank) continue;
         const mapn_oracle_sym_shape *sh = &shapes[r];
         const uint32_t a0 = r * nbl;
         arows[r] = (float *)malloc(sizeof(float) * 3u * SYM_IB * (size_t)nbl * sh->parts);
@@ -1197,6 +1200,7 @@ int mapn_oracle_step_all_pairs_sym_sharded(const float *old_pos, const float *ol
     }
     /* INTEGRATE: every rank its own bodies */
     for (uint32_t r = 0; r < world && rc == 0; r++) {
+        if (only_rank >= 0 && r != (uint32_t)only_rank) continue;
         const mapn_oracle_sym_shape *sh = &shapes[r];
         for (uint32_t il = 0; il < count; il++) {
             const uint32_t la = il / SYM_IB, e = il - la * SYM_IB, i = r * count + il;
@@ -1214,7 +1218,7 @@ int mapn_oracle_step_all_pairs_sym_sharded(const float *old_pos, const float *ol
                 float rx = 0.0f, ry = 0.0f, rz = 0.0f;
                 if (k < world) {
                     const uint32_t q = r >= k ? r - k : r + world - k;
-                    if (sends[q][r]) {
+                    if (sends[q][r] && (only_rank < 0 || q == r)) {
                         const float *src = recv + (((size_t)r * world + q) * count + il) * 3u;
                         rx = src[0]; ry = src[1]; rz = src[2];
                     }

@@ -400,6 +400,14 @@ def test_sharded_symmetric_step_with_biased_waves_one_rank_loopback(oracle, monk
             draw(c, 1)
             p, v = c.download_state()
             assert c.kernel_stats().kernel_name.decode() == "force_sym_kernel" and c.p2p_status() == 0
+            # ... and bit for bit what the ORDER-MATCHED restatement of the sharded step says for a rank that receives nothing from the
+            # others (oracle: ORDER_MATCHED_SHARDED, only_rank): the plan is the one the real 8-GPU job runs -- one rank per GPU
+            from oracle import step_sym_sharded
+            op, ov = step_sym_sharded(oracle, pos, vel, Params(mass=mass), [plan] * world, only_rank=0)
+            same = float((p[:nbl * 1024, :3] == op[:nbl * 1024, :3]).all(axis=1).mean())
+            rel = np.linalg.norm(p[:nbl * 1024, :3].astype(np.float64) - op[:nbl * 1024, :3], axis=1) / np.linalg.norm(op[:nbl * 1024, :3].astype(np.float64), axis=1)
+            print(f"algorithm {algo}, plan {plan.waves}x{plan.parts} bias {plan.wave_bias}: rank 0 alone vs the order-matched sharded oracle: max rel {rel.max():.2e}, bit-identical {same:.4f}")
+            assert rel.max() <= 1.3e-7 and same >= 0.99
             draw(c, 300)                                       # and a long run: counters, tags and tickets over many exchanges
             p300, v300 = c.download_state()
             assert c.p2p_status() == 0 and np.isfinite(p300).all()

@@ -154,8 +154,9 @@ def test_symmetric_step_sharded_over_processes(tmp_path, oracle, world, n, mode)
     assert dx < 8e-6 and dv < 1e-4, (dx, dv)
 
 
-@pytest.mark.parametrize("mode,world,n", [("sympush", 2, 8192), ("sym", 4, 8192), ("sympush", 8, 16384), ("sympush", 3, 9216), ("sympush", 2, 65536)])
-def test_sharded_symmetric_step_against_its_order_matched_oracle(tmp_path, oracle, mode, world, n):
+@pytest.mark.parametrize("mode,world,n,xcd_w", [("sympush", 2, 8192, None), ("sym", 4, 8192, None), ("sympush", 8, 16384, None), ("sympush", 3, 9216, None), ("sympush", 2, 65536, None),
+                                               ("sympush", 2, 16384, "1024,900,1000,950,1024,880,990,1010"), ("sym", 4, 65536, "1024,900,1000,950,1024,880,990,1010")])
+def test_sharded_symmetric_step_against_its_order_matched_oracle(tmp_path, oracle, mode, world, n, xcd_w):
     """The sharded symmetric step's summation order restated on the CPU from the plans the RANKS report (every rank dumps
     mapn_get_sym_plan): each rank's force rows, the reactions summed per destination over the sender's blocks, the receiver's G partial
     sums + the rows received nearest sender first (oracle/mapn_oracle.c, ORDER_MATCHED_SHARDED).  What is left against the device is
@@ -164,7 +165,7 @@ def test_sharded_symmetric_step_against_its_order_matched_oracle(tmp_path, oracl
     import types
     from oracle import Params, step_sym_sharded
     steps = 2
-    got = _run_ranks(tmp_path, world, n, steps, mode, str(n))
+    got = _run_ranks(tmp_path, world, n, steps, mode, str(n), env={"MAPN_WORKER_XCD_W": xcd_w} if xcd_w else None)     # (xcd_w: XCD-weighted parts in every rank's launch)
     plans = []
     for r in range(world):
         d = np.load(os.path.join(str(tmp_path), f"plan_rank{r}.npz"))
@@ -179,7 +180,9 @@ def test_sharded_symmetric_step_against_its_order_matched_oracle(tmp_path, oracl
     p, v = got["pos"], got["vel"]
     rel = np.linalg.norm(p[:, :3].astype(np.float64) - pos[:, :3], axis=1) / np.maximum(np.linalg.norm(pos[:, :3].astype(np.float64), axis=1), 1e-30)
     same = float((p[:, :3] == pos[:, :3]).all(axis=1).mean())
-    print(f"{mode} world={world} n={n}: plan {plans[0].waves}x{plans[0].parts}: vs the order-matched sharded oracle after {steps} steps: max rel {rel.max():.2e}, bit-identical bodies {same:.4f}")
+    if xcd_w:
+        assert plans[0].sets == 16 or d["tables"].size > plans[0].table_stride            # 16 table sets (spread) or a workgroup map behind the tables (class-aware)
+    print(f"{mode} world={world} n={n}: plan {plans[0].waves}x{plans[0].parts} sets {plans[0].sets}: vs the order-matched sharded oracle after {steps} steps: max rel {rel.max():.2e}, bit-identical bodies {same:.4f}")
     assert rel.max() <= 3e-7 and same >= 0.9
     assert np.linalg.norm(v.astype(np.float64) - vel, axis=1).max() / 15.0 < 1e-6
 

@@ -255,6 +255,34 @@ def test_split_form_at_4mi_bodies_half_active(oracle):
     np.testing.assert_array_equal(p[na:], pos[na:]); np.testing.assert_array_equal(v[na:], vel[na:])
 
 
+@pytest.mark.slow
+def test_split_form_1000_steps_half_active_against_the_oracle_and_its_double_accumulated_twin(oracle):
+    """The north_star's tolerance for the new path: 65 536 bodies, half of them active (the frozen half exerting force from where the seeded
+    state put it), 1000 free-running steps in the split form against the oracle proper -- the statements T1 / T3 of
+    tests/test_parity_1000.py: median <= 1e-5, RMS <= 5e-5, >= 99.9 % of the active bodies within 1e-4, the few beyond it bounded by the
+    ORACLE's own summation error in the same run (reference order against double accumulation), and the device no farther from the
+    double-accumulated twin than the oracle is."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity_report import stats
+    from oracle import SumSpec, SUM_FP64_ACC
+    n, na, steps = 65536, 32768, 1000
+    pos, vel = oracle.initial_state(n, seed=1)
+    prm = Params(mass=70000.0 / n)
+    with mapn.Compute(n, mass=70000.0 / n, seed=1) as c:
+        draw(c, steps, na)
+        assert c.kernel_stats().split_active == na
+        p, v = c.download_state()
+    ref = OracleSim(oracle, pos, vel, params=prm); ref.simulate(num_active=na, steps=steps)
+    acc = OracleSim(oracle, pos, vel, params=prm, sum_spec=SumSpec(SUM_FP64_ACC)); acc.simulate(num_active=na, steps=steps)
+    dev_ref, own, dev_acc = stats(p[:na], ref.latest[0][:na]), stats(ref.latest[0][:na], acc.latest[0][:na]), stats(p[:na], acc.latest[0][:na])
+    print("split form, 1000 steps, 32 768 of 65 536 active: device vs ref", dev_ref, "| ref vs acc64", own, "| device vs acc64", dev_acc)
+    assert dev_ref["median"] <= 1e-5 and dev_ref["rms"] <= 5e-5 and dev_ref["frac_within_1e-4"] >= 0.999
+    assert dev_ref["n_over_1e-4"] <= own["n_over_1e-4"] + 4 and dev_ref["max"] <= 1.5 * own["max"] + 1e-6, (dev_ref, own)
+    assert dev_acc["median"] <= 1.5 * own["median"] and dev_acc["rms"] <= 1.5 * own["rms"] and dev_acc["max"] <= 1.5 * own["max"] + 1e-6, (dev_acc, own)
+    np.testing.assert_array_equal(p[na:], pos[na:]); np.testing.assert_array_equal(v[na:], vel[na:])      # a thousand steps later the frozen half is where it was
+
+
 @pytest.mark.timing
 def test_split_form_is_faster_than_the_one_sided_step_at_half_active(monkeypatch):
     """num_active = N / 2 at 65 536 bodies: the split form against the one-sided step the same context ran until round 4 (the

@@ -795,10 +795,14 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
             if (p.phase == 0u) {
                 // A rank whose rows never validated must not go on as if they had: until round 4 it integrated the incomplete sum,
                 // published the result with valid checksums and counted itself complete -- only IT reported, the peers held bit-identical
-                // wrong replicas.  Now the failing thread POISONS this rank's position counter at every peer (a value 1.5 x 2^30 short of what
+                // wrong replicas.  The failing thread POISONS this rank's position counter at every peer (a value 1.5 x 2^30 short of what
                 // this publication must reach: no number of shares makes that up, and every later launch of the dead rank poisons again), so
-                // the peers' bounded waits for this rank's slice give up too and every rank of the job reports.  All of it sits in this cold
-                // branch (same box: exchange launch 11.98 -> 12.14 us; a workgroup flag that withholds the share instead: 11.80 -> 12.16).
+                // the peers' bounded waits for this rank's slice give up too and every rank of the job reports -- and (round 6) the BODY is
+                // left alone: not integrated, neither stored here nor pushed, no checksum word for its group (`continue` below; until then it
+                // fell through and the incomplete sum landed in every peer's replica behind valid checksums).  Bodies of the slice whose rows
+                // DID validate are published as ever (they are right, and were on their way long before this thread gave up); what keeps the
+                // peers from consuming the slice is the poisoned counter.  All of it sits in this cold branch (same box: exchange launch
+                // 11.98 -> 12.14 us; a workgroup flag that withholds the share instead: 11.80 -> 12.16).
                 __hip_atomic_store(p.flags_mine + SYM_DEAD_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (p.pos_step) {
                     const uint32_t poison = p.pos_step * SYM_COUNT_PER_LAUNCH - 0x60000000u;
@@ -807,6 +811,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
                             __hip_atomic_store(p.flags_peer[q] + SYM_POS_BASE + p.rank, poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
+            continue;                                      // nothing of this body is published (phase 2, rows delivered by RCCL: reported, not stored either)
         }
         ax *= p.mass; ay *= p.mass; az *= p.mass;
         const uint32_t i = p.rank * p.count + il;

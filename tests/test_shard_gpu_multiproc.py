@@ -118,10 +118,15 @@ def test_corrupted_pushed_position_is_reported_by_the_receiving_rank(tmp_path):
 
 @pytest.mark.parametrize("algo", [5, 4])
 def test_a_rank_whose_rows_never_validate_does_not_publish_and_every_rank_reports(tmp_path, algo):
-    """in the self-validating-rows form a receiver whose rows never validated used to integrate the incomplete sum, store
-    and push the result with valid checksums and add its share to the position counters -- only the failing rank saw MAPN_ERR_COMM,
-    its peers held bit-identical but wrong replicas.  Now that body is not integrated, nothing of it is published and the workgroup
-    withholds its counter share: the peers' bounded waits for the slice give up too.  Two processes, pushed (5) and pulled (4) positions."""
+    """ADVICE r4 / VERDICT r5 #1: in the self-validating-rows form a receiver whose rows never validated used to integrate the incomplete
+    sum, store and push the result with valid checksums and add its share to the position counters -- only the failing rank saw
+    MAPN_ERR_COMM, its peers held bit-identical but wrong replicas.  What the code does now: the failing thread marks the rank dead and
+    POISONS its position counter at every peer (the workgroup's share is still added -- on top of a value no share can make up), so the
+    peers' bounded waits for the slice give up too and every rank reports; and the body itself is skipped -- not integrated, not stored,
+    not pushed, no checksum.  Asserted in the worker on the raw device buffers after the failure: the failed body holds, on BOTH ranks,
+    what the buffer held before the step; with pulled positions (4) nothing of the failing rank's slice landed at its peer at all; with
+    pushed positions (5) the slice's other bodies (validated rows, pushed long before the failing thread gave up) are a healthy step's.
+    Two processes."""
     port = 29600 + (os.getpid() % 2000) + 23 + algo
     worker = os.path.join(ROOT, "tests", "shard_gpu_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), "8192", "3", str(tmp_path), "symrow_corrupt", str(algo)],

@@ -17,7 +17,8 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define MAPN_TUNING_ABI_VERSION 1   /* 1 (round 5): split off mapn.h (ABI 3); new: mapn_get_split_plan, mapn_step_form_describe, mapn_kernel_stats.split_active, mapn_shard_describe */
+#define MAPN_TUNING_ABI_VERSION 2   /* 1 (round 5): split off mapn.h (ABI 3); new: mapn_get_split_plan, mapn_step_form_describe, mapn_kernel_stats.split_active, mapn_shard_describe
+                                       2 (round 6): mapn_kernel_stats.split_plans_built + reserved (the struct grew by 8 bytes) */
 int mapn_tuning_abi_version(void);
 
 /* Force-kernel statistics accumulated by mapn_simulate: every step records HIP events on the
@@ -38,6 +39,10 @@ typedef struct mapn_kernel_stats {
     uint32_t split_active;       /* != 0: the step enqueued last was a PARTIALLY ACTIVE one in its split form -- these many bodies met each other under
                                     the symmetric kernel (a plan of the active blocks alone), the frozen ones acted on them through one one-sided
                                     launch in front (kernel_name "force_sym_kernel", grid of the symmetric launch) */
+    uint32_t split_plans_built;  /* host plans built for the split form since the context was created: the last four counts keep theirs, so a slider
+                                    moving between a few values stops building (and a NEW count never blocks mapn_simulate: its plan is uploaded
+                                    stream-ordered into its own table buffer) */
+    uint32_t reserved;
 } mapn_kernel_stats;
 int mapn_get_kernel_stats(mapn_ctx *ctx, int reset, mapn_kernel_stats *out);
 /* The individual samples behind those means: for every step since the last reset that carried timer events (every T-th,

@@ -68,6 +68,7 @@ class KernelStats(C.Structure):
         ("grid_x", C.c_uint32), ("grid_y", C.c_uint32), ("block_x", C.c_uint32),
         ("bodies_per_lane", C.c_uint32), ("j_splits", C.c_uint32), ("fused", C.c_uint32),
         ("grid_z", C.c_uint32), ("epilogue", C.c_uint32), ("force_launches_per_step", C.c_uint32), ("split_active", C.c_uint32),
+        ("split_plans_built", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 

@@ -191,14 +191,14 @@ int ensure_partial(mapn_ctx *c, size_t slots, size_t stride)
 {
     const size_t need = slots * stride * sizeof(float4);
     if (need <= c->partial_bytes) return MAPN_OK;
-    // (the buffer moves: steps still in flight read the old one, and a captured step of the OTHER ping-pong parity holds its address --
-    //  num_active changing between two replays could otherwise replay a graph onto freed memory)
-    HIP_TRY(hipStreamSynchronize(c->compute));
+    // (the buffer moves: steps still queued -- possibly parked behind the consumer's fence -- read the old one, and captured steps hold its
+    //  address.  Nothing is waited for here (mapn_simulate only enqueues, Compute.cpp:1009-1055): the old buffer and the graphs are RETIRED and
+    //  freed once the stream has run dry, collect_retired)
+    float4 *fresh = nullptr;
+    HIP_TRY(hipMalloc(&fresh, need));
+    retire(c, c->partial, nullptr, nullptr);
     drop_graphs(c);
-    if (c->partial) HIP_TRY(hipFree(c->partial));
-    c->partial = nullptr;
-    c->partial_bytes = 0;
-    HIP_TRY(hipMalloc(&c->partial, need));
+    c->partial = fresh;
     c->partial_bytes = need;
     return MAPN_OK;
 }
@@ -309,8 +309,8 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
     if (i_count > 0 && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS && !flow) {
         form = sym_step_form(c, active);
         if (form == FORM_SYM_SPLIT) {
-            if (int rc = prepare_sym_active(c, active)) return rc;    // (the first step with this num_active makes the plan; afterwards a no-op)
-            if (c->act.active != active) form = sym_step_form(c, active);   // it could not be made (act_failed): the chooser now names another form
+            if (int rc = prepare_sym_active(c, active)) return rc;    // (a lookup among the cached plans; a new count makes its plan -- without waiting for the device)
+            if (!act_ready(c, active)) form = sym_form_without_split(c, active);   // it could not be made (act_failed remembers): another form, whatever the A/B hook says
         }
     }
     c->last_split_active = 0;
@@ -406,48 +406,63 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
     return MAPN_OK;
 }
 
+// (deferred: a replay may still be queued -- the executables are destroyed once the stream has run dry, collect_retired)
 void drop_graphs(mapn_ctx *c)
 {
-    for (int b = 0; b < 2; b++) {
-        if (c->graph_exec[b]) (void)hipGraphExecDestroy(c->graph_exec[b]);
-        c->graph_exec[b] = nullptr;
-        c->graph_active[b] = -1;
-    }
+    for (int b = 0; b < 2; b++)
+        for (mapn_ctx::StepGraph &g : c->graphs[b]) {
+            retire(c, nullptr, nullptr, g.exec);
+            g = mapn_ctx::StepGraph{};
+        }
 }
 
-// MAPN_FLAG_USE_GRAPH: the step's launches (force [+ reduce/integrate]) are captured once per
-// ping-pong parity and replayed with one hipGraphLaunch.  Scratch memory is sized before the
-// capture (no allocation inside it; the symmetric kernel's was made when the context was created).  A step that carries timer events runs eagerly.
+// MAPN_FLAG_USE_GRAPH: the step's launches (force [+ reduce/integrate]) are captured once per ping-pong parity and KEY -- the count,
+// the form the step takes for it (the A/B hook or a plan that could not be made change the form of the same count) and, split form,
+// which plan (a slot of the plan cache is reused) -- and replayed with one hipGraphLaunch; the last kGraphs keys per parity are kept, so
+// a slider moving between a few values replays.  Scratch memory is sized before the capture (no allocation inside it; the symmetric
+// kernel's was made when the context was created).  A step that carries timer events runs eagerly.
 int enqueue_step_graph(mapn_ctx *c, uint32_t active)
 {
     const uint32_t w = c->buffer_index;
-    if (!c->graph_exec[w] || c->graph_active[w] != (int)active) {
-        if (c->graph_exec[w]) { (void)hipGraphExecDestroy(c->graph_exec[w]); c->graph_exec[w] = nullptr; }
-        const uint32_t lo = c->first, hi = std::min(c->first + c->count, active);
-        if (hi > lo && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS) {
-            StepForm form = sym_step_form(c, active);
-            if (form == FORM_SYM_SPLIT) {                   // its plan and scratch, outside the capture
-                if (int rc = prepare_sym_active(c, active)) return rc;
-                form = sym_step_form(c, active);
-            }
-            if (form == FORM_ONE_SIDED) {
-                mapn::ForcePlan plan = choose_plan(c, hi - lo, c->n, 1, true);
-                if (plan.epi != mapn::EPI_FUSED)
-                    if (int rc = ensure_partial(c, plan.sb, ((hi - lo) + 63u) & ~63u)) return rc;
-            }
+    int form = -1;
+    uint64_t generation = 0;
+    const uint32_t lo = c->first, hi = std::min(c->first + c->count, active);
+    if (hi > lo && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS) {
+        StepForm f = sym_step_form(c, active);
+        if (f == FORM_SYM_SPLIT) {                          // its plan and scratch, outside the capture
+            if (int rc = prepare_sym_active(c, active)) return rc;
+            if (act_ready(c, active)) generation = c->act_plans[c->act_cur].generation;
+            else f = sym_form_without_split(c, active);
         }
+        if (f == FORM_ONE_SIDED) {
+            mapn::ForcePlan plan = choose_plan(c, hi - lo, c->n, 1, true);
+            if (plan.epi != mapn::EPI_FUSED)
+                if (int rc = ensure_partial(c, plan.sb, ((hi - lo) + 63u) & ~63u)) return rc;
+        }
+        form = (int)f;
+    }
+    mapn_ctx::StepGraph *g = nullptr, *victim = nullptr;   // victim: a free slot, else the least recently replayed one
+    for (mapn_ctx::StepGraph &e : c->graphs[w]) {
+        if (e.exec && e.active == active && e.form == form && e.generation == generation) { g = &e; break; }
+        if (!victim || (victim->exec && (!e.exec || e.used < victim->used))) victim = &e;
+    }
+    if (!g) {
+        retire(c, nullptr, nullptr, victim->exec);
+        *victim = mapn_ctx::StepGraph{};
         hipGraph_t graph = nullptr;
         HIP_TRY(hipStreamBeginCapture(c->compute, hipStreamCaptureModeThreadLocal));
         int rc = enqueue_step(c, active, nullptr);
         hipError_t e = hipStreamEndCapture(c->compute, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess) return fail(MAPN_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-        e = hipGraphInstantiate(&c->graph_exec[w], graph, nullptr, nullptr, 0);
+        e = hipGraphInstantiate(&victim->exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) { c->graph_exec[w] = nullptr; return fail(MAPN_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
-        c->graph_active[w] = (int)active;
+        if (e != hipSuccess) { victim->exec = nullptr; return fail(MAPN_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+        victim->active = active; victim->form = form; victim->generation = generation;
+        g = victim;
     }
-    HIP_TRY(hipGraphLaunch(c->graph_exec[w], c->compute));
+    g->used = ++c->graph_clock;
+    HIP_TRY(hipGraphLaunch(g->exec, c->compute));
     return MAPN_OK;
 }
 
@@ -661,8 +676,9 @@ int mapn_destroy(mapn_ctx *c)
     if (c->fence_host_word) (void)hipHostFree(c->fence_host_word);
     if (c->async_status) (void)hipHostFree(c->async_status);
     if (c->fence_dev_block) (void)hipFree(c->fence_dev_block);
+    drop_graphs(c);
+    collect_retired(c, true);                                          // (the streams have been drained above)
     for (int b = 0; b < 2; b++) {
-        if (c->graph_exec[b]) (void)hipGraphExecDestroy(c->graph_exec[b]);
         if (c->vel[b]) (void)hipFree(c->vel[b]);
         if (c->gather_done[b]) (void)hipEventDestroy(c->gather_done[b]);
     }
@@ -694,6 +710,7 @@ int mapn_simulate(mapn_ctx *c, int num_active, uint64_t wait_value)
         return fail(MAPN_ERR_STATE, "sharded context (world_size %d): call mapn_comm_init or "
                     "mapn_set_external_gather before simulate", c->cfg.world_size);
     if (int rc = check_async_errors(c)) return rc;                     // a device-side wait of an earlier step gave up
+    collect_retired(c, false);                                         // (what a growth or a re-plan replaced, once nothing queued can still use it)
     if (int rc = wait_for_consumer(c, wait_value)) return rc;          // Compute.cpp:1012
     const uint32_t active = active_bodies(num_active, c->n);
 
@@ -757,6 +774,7 @@ int mapn_wait_idle(mapn_ctx *c)
     const uint64_t v = c->fence_value++;
     HIP_TRY(hipStreamSynchronize(c->compute));
     HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    collect_retired(c, true);
     c->completed = std::max(c->completed, v);
     if (int rc = resolve_timers(c, true)) return rc;
     return check_async_errors(c);
@@ -1003,6 +1021,7 @@ int mapn_get_kernel_stats(mapn_ctx *c, int reset, mapn_kernel_stats *out)
         out->grid_x = (i_count + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK; out->grid_y = p.sb; out->j_splits = p.sb * p.waves; out->fused = 0; out->epilogue = 3;   // grid (I-blocks, parts)
     }
     out->split_active = c->last_split_active;
+    out->split_plans_built = c->split_plans_built;
     if (reset) { c->force_launches = 0; c->force_seconds_sum = 0.0; c->steps_since_reset = 0; c->samples.clear(); }
     return MAPN_OK;
 }

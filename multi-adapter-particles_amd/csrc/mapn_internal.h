@@ -103,18 +103,37 @@ struct mapn_ctx {
     uint32_t sym_parts = 0, sym_waves = 0;
     // A PARTIALLY ACTIVE step (num_active < N: Particles.cpp:391-394's slider, Compute.cpp:1041): the active bodies [0, A) meet each
     // other under the symmetric kernel with a plan of THEIR blocks, the frozen bodies [A, N) act on them through the one-sided kernel
-    // (enqueue_sym_split).  The plan and its scratch are made by the first step with a new A (and kept: capacity only grows), not per step.
+    // (enqueue_sym_split).  The last kActPlans counts keep their plans (LRU): a slider that moves between a few values never re-plans,
+    // and a NEW count never blocks the host either (Compute.cpp:1009-1055 only ever enqueues): every plan has its OWN table buffer,
+    // uploaded stream-ordered from its own pinned copy, the rows are one grow-only set shared by all plans (steps are stream-ordered),
+    // and whatever a growth replaces is freed later, once the stream has run dry (retire / collect_retired).
     struct SymActive {
-        uint32_t active = 0;                  // the A this set was prepared for (0: none)
+        uint32_t active = 0;                  // the A this plan was made for (0: slot unused)
+        uint64_t used = 0;                    // LRU stamp (act_clock at the last step that ran it)
+        uint64_t generation = 0;              // distinguishes two plans that lived in this slot (captured graphs are keyed by it)
         mapn::SymPlanHost plan;
+        uint32_t *tab = nullptr;              // device tables of THIS plan
+        uint32_t *stage = nullptr;            // pinned host copy the stream-ordered upload reads
+        size_t cap_tab = 0, cap_stage = 0;    // bytes allocated
+        hipEvent_t uploaded = nullptr;        // recorded behind the upload: the pinned copy may be rewritten once it has fired
+        mapn::ForcePlan frozen{};             // the one-sided launch over the frozen j-segment (EPI_ROWS)
+    };
+    static constexpr int kActPlans = 4;
+    SymActive act_plans[kActPlans];
+    int act_cur = -1;                         // the plan of the step being enqueued / enqueued last in the split form (-1: none)
+    uint64_t act_clock = 0, act_generation = 0;
+    uint32_t split_plans_built = 0;           // host plans built for the split form since creation (mapn_kernel_stats)
+    struct SymActiveRows {                    // rows and running sum of the split form: shared by the cached plans, capacity only grows
         mapn::SymRow *arow = nullptr, *brow = nullptr, *brow1 = nullptr;
         float4 *acc = nullptr;
-        uint32_t *tab = nullptr;
-        size_t cap_arow = 0, cap_brow = 0, cap_brow1 = 0, cap_acc = 0, cap_tab = 0;   // bytes allocated
-        mapn::ForcePlan frozen{};             // the one-sided launch over the frozen j-segment (EPI_ROWS)
-    } act;
-    uint32_t act_failed = 0;                  // the split form could not be prepared for this many active bodies (plan / memory): not tried again
+        size_t cap_arow = 0, cap_brow = 0, cap_brow1 = 0, cap_acc = 0;
+    } act_rows;
+    std::vector<uint32_t> act_failed;         // counts whose split plan / scratch could not be had: not tried again (at most 16 remembered)
     uint32_t last_split_active = 0;           // the step enqueued last ran the split form for this many active bodies (0: it did not)
+    // what a growth or a re-plan replaced while steps that use it may still be queued (even PARKED behind the consumer's fence): freed
+    // by collect_retired once the compute stream has run dry -- hipFree waits for the device, so it is never called before that
+    struct Retired { void *dev = nullptr; void *host = nullptr; hipGraphExec_t graph = nullptr; };
+    std::vector<Retired> retired;
     bool p2p_shared_device = false;          // a peer rank runs on THIS GPU (several processes on one device: tests)
     uint32_t p2p_ranks_on_device = 1;        // ranks of the job that run on this GPU, this one included
     uint32_t sym_exchange_cap = 0;            // workgroups of sym_shard_exchange_kernel the device holds at once
@@ -197,9 +216,11 @@ struct mapn_ctx {
     bool p2p_loopback = false;                // MAPN_P2P_LOOPBACK=1 (timing on a 1-GPU box only): every peer maps to this rank
     uint32_t *flow_block = nullptr;           // ordinary device memory: [0..15] arrived[q], [16] tiles_done (flow mode)
 
-    // graph replay
-    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
-    int graph_active[2] = {-1, -1};
+    // graph replay: per ping-pong parity the last kGraphs captured steps, keyed by what a capture depends on
+    struct StepGraph { hipGraphExec_t exec = nullptr; uint32_t active = 0; int form = -1; uint64_t generation = 0, used = 0; };
+    static constexpr int kGraphs = 4;
+    StepGraph graphs[2][kGraphs];
+    uint64_t graph_clock = 0;
 };
 
 namespace mapn {
@@ -226,8 +247,13 @@ int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer);
 enum StepForm { FORM_ONE_SIDED = 0, FORM_SYM_FULL = 1, FORM_SYM_SPLIT = 2 };
 StepForm sym_form_by_cost(uint32_t n, uint32_t active);      // the cost model alone: a pure function of (N, roundup64(num_active))
 StepForm sym_step_form(const mapn_ctx *c, uint32_t active);   // which of the three forms an unsharded all-pairs step of `active` bodies runs
-int prepare_sym_active(mapn_ctx *c, uint32_t active);         // plan + scratch of the split form (no-op when already made for this A)
+int prepare_sym_active(mapn_ctx *c, uint32_t active);         // plan + scratch of the split form (a lookup when one of the cached plans is for this A); never blocks
+bool act_ready(const mapn_ctx *c, uint32_t active);           // the current split plan is the one for `active`
+void retire(mapn_ctx *c, void *dev, void *host, hipGraphExec_t graph);
+void collect_retired(mapn_ctx *c, bool drained);              // frees what was retired once the compute stream has run dry (drained: the caller has just synchronised it)
 void release_sym_active(mapn_ctx *c);
+void forget_sym_active(mapn_ctx *c);
+StepForm sym_form_without_split(const mapn_ctx *c, uint32_t active);
 int enqueue_sym_split(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer);
 bool sym_shard_eligible(const mapn_ctx *c, uint32_t active);
 bool sym_push_check();

@@ -8,6 +8,9 @@ using namespace mapn::host;
 namespace mapn {
 namespace host {
 
+// set around the creation of calibrate_for_shard's bounded stand-in context: take its reading without the creation-time A/B
+static thread_local bool g_calibration_without_ab = false;
+
 void release_sym(mapn_ctx *c)
 {
     if (c->sym_arow) (void)hipFree(c->sym_arow);
@@ -137,7 +140,7 @@ int prepare_sym(mapn_ctx *c, bool sharded)
 {
     release_sym(c);
     c->sym_note.clear();
-    c->act.active = 0; c->act_failed = 0;                  // (the split form's plan follows this one's weights: made again by the next partially active step)
+    forget_sym_active(c);                                  // (the split form's plans follow this one's weights: made again by the next partially active step)
     if (!sym_applies(c, sharded)) return MAPN_OK;
     const bool must = c->cfg.kernel == MAPN_KERNEL_SYMMETRIC || c->sym_user_plan;
     const uint32_t nb = (c->n + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK, nbl = sharded ? c->count / mapn::SYM_BLOCK : nb;
@@ -251,9 +254,13 @@ StepForm sym_step_form(const mapn_ctx *c, uint32_t active)
         if (f[0] == 's' && active >= 2u * mapn::SYM_BLOCK) return FORM_SYM_SPLIT;
     }
     const StepForm form = sym_form_by_cost(c->n, active);
-    if (form == FORM_SYM_SPLIT && c->act_failed == active) return full_ok ? FORM_SYM_FULL : FORM_ONE_SIDED;   // (its plan or scratch could not be had for this count)
+    if (form == FORM_SYM_SPLIT && std::find(c->act_failed.begin(), c->act_failed.end(), active) != c->act_failed.end())
+        return full_ok ? FORM_SYM_FULL : FORM_ONE_SIDED;   // (its plan or scratch could not be had for this count)
     return form;
 }
+
+// the form a partially active step takes when its split plan could not be made (also when the A/B hook asked for the split form)
+StepForm sym_form_without_split(const mapn_ctx *c, uint32_t active) { return (uint64_t)active * 4u >= (uint64_t)c->n * 3u ? FORM_SYM_FULL : FORM_ONE_SIDED; }
 
 // this STEP runs the symmetric kernel over the whole job (all bodies active, or so many that the frozen ones are not worth a split)
 bool sym_eligible(const mapn_ctx *c, uint32_t active) { return sym_step_form(c, active) == FORM_SYM_FULL; }
@@ -352,27 +359,80 @@ int enqueue_sym(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
 // rows (EPI_ROWS) that the first window's reduce launch adds, in ascending row order, in front of its own rows.  Summation order
 // (what the order-matched checker restates): frozen rows as in mapn_set_force_plan's comment with the j-range [A, N), then the
 // symmetric plan's order over the bodies [0, A); the mass multiplies the total.
+// (destruction: the streams have been drained)
 void release_sym_active(mapn_ctx *c)
 {
-    mapn_ctx::SymActive &s = c->act;
-    if (s.arow) (void)hipFree(s.arow);
-    if (s.brow) (void)hipFree(s.brow);
-    if (s.brow1) (void)hipFree(s.brow1);
-    if (s.acc) (void)hipFree(s.acc);
-    if (s.tab) (void)hipFree(s.tab);
-    s = mapn_ctx::SymActive{};
+    for (mapn_ctx::SymActive &s : c->act_plans) {
+        if (s.tab) (void)hipFree(s.tab);
+        if (s.stage) (void)hipHostFree(s.stage);
+        if (s.uploaded) (void)hipEventDestroy(s.uploaded);
+        s = mapn_ctx::SymActive{};
+    }
+    mapn_ctx::SymActiveRows &r = c->act_rows;
+    if (r.arow) (void)hipFree(r.arow);
+    if (r.brow) (void)hipFree(r.brow);
+    if (r.brow1) (void)hipFree(r.brow1);
+    if (r.acc) (void)hipFree(r.acc);
+    r = mapn_ctx::SymActiveRows{};
+    c->act_cur = -1;
 }
 
-// Plan and scratch for `active` bodies (a no-op when they are the ones of the last call).  Runs on the FIRST step with a new
-// num_active -- a host-side plan, a table upload and, when the scratch has to grow, allocations behind a drained stream -- never on
-// the steps after it.  Failure is not an error: act.active stays 0, act_failed remembers the count, and the caller takes another form.
+// the context's own plan has changed (weights, shape): the cached split plans were made under the old one -- their buffers stay
+void forget_sym_active(mapn_ctx *c)
+{
+    for (mapn_ctx::SymActive &s : c->act_plans) s.active = 0;
+    c->act_cur = -1;
+    c->act_failed.clear();
+}
+
+bool act_ready(const mapn_ctx *c, uint32_t active) { return c->act_cur >= 0 && c->act_plans[c->act_cur].active == active; }
+
+void retire(mapn_ctx *c, void *dev, void *host, hipGraphExec_t graph)
+{
+    if (!dev && !host && !graph) return;
+    mapn_ctx::Retired r;
+    r.dev = dev; r.host = host; r.graph = graph;
+    c->retired.push_back(r);
+}
+
+void collect_retired(mapn_ctx *c, bool drained)
+{
+    if (c->retired.empty()) return;
+    if (!drained && hipStreamQuery(c->compute) != hipSuccess) { (void)hipGetLastError(); return; }   // steps that may use them are still queued
+    for (mapn_ctx::Retired &r : c->retired) {
+        if (r.graph) (void)hipGraphExecDestroy(r.graph);
+        if (r.dev) (void)hipFree(r.dev);
+        if (r.host) (void)hipHostFree(r.host);
+    }
+    c->retired.clear();
+}
+
+// Plan and scratch for `active` bodies: a LOOKUP among the cached plans (the last kActPlans counts), else a host-side plan into the
+// least recently used slot, uploaded STREAM-ORDERED into the slot's own table buffer.  Never waits for the device (Compute.cpp:1009-1055
+// only enqueues; the compute stream may be parked behind the consumer's fence, and the caller may be the thread that signals it): rows
+// that have to grow are allocated anew and the old ones retired, nothing is freed or synchronised here.  Failure is not an error:
+// act_cur stays -1, act_failed remembers the count, and the caller takes another form.
 int prepare_sym_active(mapn_ctx *c, uint32_t active)
 {
-    mapn_ctx::SymActive &s = c->act;
-    if (s.active == active) return MAPN_OK;
-    HIP_TRY(hipStreamSynchronize(c->compute));             // steps still in flight read the tables and rows this replaces
-    drop_graphs(c);
-    s.active = 0;
+    if (act_ready(c, active)) { c->act_plans[c->act_cur].used = ++c->act_clock; return MAPN_OK; }
+    c->act_cur = -1;
+    int slot = -1;
+    int slots = mapn_ctx::kActPlans;
+    if (const char *hk = test_hook("MAPN_ACT_PLANS")) slots = std::max(1, std::min(slots, atoi(hk)));   // (A/B: 1 = round 5's one remembered count)
+    for (int k = 0; k < slots; k++)
+        if (c->act_plans[k].active == active) { c->act_cur = k; c->act_plans[k].used = ++c->act_clock; return MAPN_OK; }
+    for (int k = 0; k < slots; k++) {
+        if (c->act_plans[k].active == 0) { slot = k; break; }
+        if (slot < 0 || c->act_plans[k].used < c->act_plans[slot].used) slot = k;
+    }
+    auto give_up = [&](const std::string &why) {
+        if (std::find(c->act_failed.begin(), c->act_failed.end(), active) == c->act_failed.end()) {
+            if (c->act_failed.size() >= 16) c->act_failed.erase(c->act_failed.begin());
+            c->act_failed.push_back(active);
+        }
+        g_last_error = why;
+        return MAPN_OK;
+    };
     const uint32_t nb = (active + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK;
     const uint32_t gsym = (nb - 1u) / 2u + ((nb & 1u) ? 0u : 1u);
     const char *e = getenv("MAPN_SYM_MAX_MB");
@@ -382,51 +442,74 @@ int prepare_sym_active(mapn_ctx *c, uint32_t active)
     if (fit < gsym) gpw = (uint32_t)fit;
     std::string err;
     bool built = false;
+    mapn::SymPlanHost pl;
     for (const Shape &sh : candidate_shapes(c, false, nb, nb, gsym, gpw, false))
-        if ((built = mapn::build_sym_plan(nb, gpw, sh.parts, sh.t1, sh.t2, sh.waves, sh.hi, sh.lo, c->sym_xcd_weighted ? c->sym_xcd_w : nullptr, nb, 0u, 0u, s.plan, err))) break;
-    if (!built) { c->act_failed = active; g_last_error = "partially active step: " + err + "; another form runs"; return MAPN_OK; }
-    const mapn::SymPlanHost &pl = s.plan;
+        if ((built = mapn::build_sym_plan(nb, gpw, sh.parts, sh.t1, sh.t2, sh.waves, sh.hi, sh.lo, c->sym_xcd_weighted ? c->sym_xcd_w : nullptr, nb, 0u, 0u, pl, err))) break;
+    if (!built) return give_up("partially active step: " + err + "; another form runs");
+    c->split_plans_built++;
     // the one-sided launch over the frozen bodies: the default plan of an active x (N - active) launch, partial rows instead of the integrator
-    s.frozen = choose_plan(c, active, c->n - active, 1, false);
-    env_plan("MAPN_FROZEN_PLAN", s.frozen);                // (hook: "k,waves,sb" -- the sweep behind the default)
-    s.frozen.epi = mapn::EPI_ROWS;
-    auto grow = [](void **p, size_t &have, size_t need) -> hipError_t {
+    mapn::ForcePlan frozen = choose_plan(c, active, c->n - active, 1, false);
+    env_plan("MAPN_FROZEN_PLAN", frozen);                  // (hook: "k,waves,sb" -- the sweep behind the default)
+    frozen.epi = mapn::EPI_ROWS;
+    bool moved = false;                                    // a buffer captured graphs hold the address of was replaced
+    auto grow = [&](void **p, size_t &have, size_t need) -> hipError_t {
         if (need <= have) return hipSuccess;
-        if (*p) (void)hipFree(*p);
-        *p = nullptr; have = 0;
-        const hipError_t e2 = hipMalloc(p, need);
-        if (e2 == hipSuccess) have = need;
-        return e2;
+        void *fresh = nullptr;
+        const hipError_t e2 = hipMalloc(&fresh, need);
+        if (e2 != hipSuccess) return e2;
+        retire(c, *p, nullptr, nullptr);                   // (steps still queued read the old one)
+        *p = fresh; have = need; moved = true;
+        return hipSuccess;
     };
+    mapn_ctx::SymActiveRows &r = c->act_rows;
+    mapn_ctx::SymActive &s = c->act_plans[slot];
     const size_t ab = (size_t)nb * pl.parts * mapn::SYM_BLOCK * sizeof(mapn::SymRow);
     const size_t bb = (size_t)nb * mapn::SYM_BLOCK * pl.brows * sizeof(mapn::SymRow);
     const size_t hb = (size_t)nb * pl.parts * 64 * sizeof(mapn::SymRow);
     const size_t cb = pl.windows.size() > 1 ? (size_t)nb * mapn::SYM_BLOCK * sizeof(float4) : 0;
     const size_t tb = pl.tables.size() * sizeof(uint32_t);
     hipError_t he = test_hook("MAPN_SYM_FAIL_ALLOC") ? hipErrorOutOfMemory : hipSuccess;
-    if (he == hipSuccess) he = grow(reinterpret_cast<void **>(&s.arow), s.cap_arow, ab);
-    if (he == hipSuccess) he = grow(reinterpret_cast<void **>(&s.brow), s.cap_brow, bb);
-    if (he == hipSuccess) he = grow(reinterpret_cast<void **>(&s.brow1), s.cap_brow1, hb);
-    if (he == hipSuccess && cb) he = grow(reinterpret_cast<void **>(&s.acc), s.cap_acc, cb);
+    if (he == hipSuccess) he = grow(reinterpret_cast<void **>(&r.arow), r.cap_arow, ab);
+    if (he == hipSuccess) he = grow(reinterpret_cast<void **>(&r.brow), r.cap_brow, bb);
+    if (he == hipSuccess) he = grow(reinterpret_cast<void **>(&r.brow1), r.cap_brow1, hb);
+    if (he == hipSuccess && cb) he = grow(reinterpret_cast<void **>(&r.acc), r.cap_acc, cb);
+    s.active = 0;                                          // (from here on the slot's old plan is gone)
     if (he == hipSuccess) he = grow(reinterpret_cast<void **>(&s.tab), s.cap_tab, tb);
-    if (he == hipSuccess) he = hipMemcpy(s.tab, pl.tables.data(), tb, hipMemcpyHostToDevice);
-    if (he == hipSuccess && ensure_partial(c, s.frozen.sb, ((size_t)active + 63u) & ~(size_t)63u) != MAPN_OK) he = hipErrorOutOfMemory;
+    if (he == hipSuccess && !s.uploaded) he = hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming);
+    if (he == hipSuccess && (tb > s.cap_stage || (s.stage && hipEventQuery(s.uploaded) != hipSuccess))) {
+        // the slot's pinned copy is too small, or an upload out of it is still queued (a parked stream): a fresh one, the old one retired
+        (void)hipGetLastError();
+        void *fresh = nullptr;
+        he = hipHostMalloc(&fresh, std::max(tb, s.cap_stage), hipHostMallocDefault);
+        if (he == hipSuccess) { retire(c, nullptr, s.stage, nullptr); s.stage = static_cast<uint32_t *>(fresh); s.cap_stage = std::max(tb, s.cap_stage); }
+    }
+    if (he == hipSuccess) {
+        memcpy(s.stage, pl.tables.data(), tb);
+        he = hipMemcpyAsync(s.tab, s.stage, tb, hipMemcpyHostToDevice, c->compute);   // behind the steps that still read the slot's old tables
+        if (he == hipSuccess) he = hipEventRecord(s.uploaded, c->compute);
+    }
+    if (he == hipSuccess && ensure_partial(c, frozen.sb, ((size_t)active + 63u) & ~(size_t)63u) != MAPN_OK) he = hipErrorOutOfMemory;
+    if (moved) drop_graphs(c);
     if (he != hipSuccess) {
         (void)hipGetLastError();
-        c->act_failed = active;
         char msg[256];
         snprintf(msg, sizeof msg, "partially active step: %.1f MiB of scratch for %u active bodies could not be allocated (%s); another form runs",
                  (double)(ab + bb + hb + cb + tb) / 1048576.0, active, hipGetErrorString(he));
-        g_last_error = msg;
-        return MAPN_OK;
+        return give_up(msg);
     }
+    s.plan = std::move(pl);
+    s.frozen = frozen;
     s.active = active;
+    s.used = ++c->act_clock;
+    s.generation = ++c->act_generation;
+    c->act_cur = slot;
     return MAPN_OK;
 }
 
 int enqueue_sym_split(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
 {
-    const mapn_ctx::SymActive &s = c->act;
+    const mapn_ctx::SymActive &s = c->act_plans[c->act_cur];   // (enqueue_step has made sure of it: act_ready)
+    const mapn_ctx::SymActiveRows &rows = c->act_rows;
     const mapn::SymPlanHost &pl = s.plan;
     const uint32_t A = s.active;
     // (1) what the frozen bodies [A, N) do to the active ones: partial rows, one per block row of the launch
@@ -434,15 +517,15 @@ int enqueue_sym_split(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     f.i_first = 0; f.i_count = A;
     fill_segment(f, 0, A, c->n - A, 0, s.frozen.sb * s.frozen.waves);
     f.partial_stride = (A + 63u) & ~63u;
-    if (int rc = ensure_partial(c, s.frozen.sb, f.partial_stride)) return rc;     // (made by prepare_sym_active: a no-op here)
+    if (int rc = ensure_partial(c, s.frozen.sb, f.partial_stride)) return rc;     // (sized by prepare_sym_active: a no-op here)
     f.partial = c->partial; f.ticket = c->ticket; f.ticket_total = s.frozen.sb;
     HIP_TRY(mapn::launch_force(s.frozen, f, c->compute));
     // (2) the active bodies among themselves, window by window; the first reduce launch takes the frozen rows in
     const size_t nwin = pl.windows.size();
     for (size_t k = 0; k < nwin; k++) {
-        mapn::SymArgs a = sym_args_of(pl, s.arow, s.brow, s.brow1, s.tab, A, base, k);
-        a.acc_in = k ? s.acc : nullptr;
-        a.acc_out = k + 1 < nwin ? s.acc : nullptr;
+        mapn::SymArgs a = sym_args_of(pl, rows.arow, rows.brow, rows.brow1, s.tab, A, base, k);
+        a.acc_in = k ? rows.acc : nullptr;
+        a.acc_out = k + 1 < nwin ? rows.acc : nullptr;
         if (k == 0) { a.extra = c->partial; a.extra_rows = s.frozen.sb; a.extra_stride = f.partial_stride; }
         HIP_TRY(mapn::launch_force_sym(a, pl.waves, c->compute));
         if (timer && nwin == 1) { HIP_TRY(hipEventRecord(timer->force_done, c->compute)); timer->has_force = true; }   // (the frozen launch and the symmetric one)
@@ -632,12 +715,16 @@ int calibrate_for_shard(mapn_ctx *c)
     mapn_ctx *tmp = nullptr;
     const std::string keep = g_last_error;
     std::string note;
+    // (the bounded stand-in is ANOTHER job shape -- an unsharded 64-block launch, not this rank's -- so its creation-time A/B
+    //  says nothing about this job: before, a job of more than 262 144 bodies had no A/B at all, and it keeps its weights as then)
+    g_calibration_without_ab = t.num_particles != c->n;
     const int rc = mapn_create(&t, &tmp);
+    g_calibration_without_ab = false;
     if (rc == MAPN_OK && tmp->sym_ready && tmp->sym_plan.xcd_mode != 0u) {
         for (int k = 0; k < 8; k++) c->sym_xcd_w[k] = tmp->sym_plan.xcd_weight[k];
         c->sym_xcd_weighted = true;
     } else {
-        note = "MAPN_FLAG_XCD_CALIBRATE (sharded): no die weights -- " + (rc != MAPN_OK ? "the temporary calibration context could not be created: " + g_last_error
+        note = "MAPN_FLAG_XCD_CALIBRATE (sharded; the dies were measured by a temporary UNSHARDED context of " + std::to_string(t.num_particles) + " bodies): no die weights -- " + (rc != MAPN_OK ? "the temporary calibration context could not be created: " + g_last_error
                                                                                          : (g_last_error.empty() ? std::string("the calibrated plan was not kept") : g_last_error)) + "; the default plan runs";
     }
     if (tmp) (void)mapn_destroy(tmp);
@@ -692,7 +779,7 @@ int calibrate_at_creation(mapn_ctx *c)
     uint32_t w[8];
     std::string note;
     const char *vf = test_hook("MAPN_XCD_VERIFY");
-    const bool verify = c->n <= 262144u && !(vf && vf[0] == '0');
+    const bool verify = c->n <= 262144u && !(vf && vf[0] == '0') && !g_calibration_without_ab;
     if (rc) { note = "MAPN_FLAG_XCD_CALIBRATE: " + g_last_error + "; the default plan runs"; }     // (the clock ramp's steps failed: nothing is calibrated)
     for (int attempt = 0; attempt < 2 && !rc; attempt++) {
         rc = mapn_calibrate_sym_xcds(c, c->n <= 131072u ? 8 : c->n <= 262144u ? 4 : 1, w);
@@ -923,15 +1010,15 @@ int mapn_get_split_plan(mapn_ctx *c, mapn_split_info *split, mapn_sym_plan_info 
     if (!c || !split || !info) return fail(MAPN_ERR_INVALID_ARGUMENT, "null argument");
     memset(info, 0, sizeof *info);
     memset(split, 0, sizeof *split);
-    if (!c->act.active) {
+    if (c->act_cur < 0 || !c->act_plans[c->act_cur].active) {
         snprintf(info->error, sizeof info->error, "no partially active step has run in its split form yet");
         return fail(MAPN_ERR_STATE, "get_split_plan: %s", info->error);
     }
-    const mapn_ctx::SymActive &s = c->act;
+    const mapn_ctx::SymActive &s = c->act_plans[c->act_cur];
     split->active = s.active; split->frozen = c->n - s.active;
     split->frozen_kernel = s.frozen.kind == mapn::KERNEL_LDS ? MAPN_KERNEL_LDS : MAPN_KERNEL_SCALAR;
     split->frozen_bodies_per_lane = s.frozen.k; split->frozen_waves = s.frozen.waves; split->frozen_sb = s.frozen.sb;
-    info->scratch_bytes = s.cap_arow + s.cap_brow + s.cap_brow1 + s.cap_acc + s.cap_tab;
+    info->scratch_bytes = c->act_rows.cap_arow + c->act_rows.cap_brow + c->act_rows.cap_brow1 + c->act_rows.cap_acc + s.cap_tab;
     return export_plan(s.plan, "get_split_plan", info, windows, windows_capacity, tables, tables_capacity);
 }
 

@@ -63,9 +63,9 @@ def test_the_two_headers_split_the_boundary_from_the_tuning_surface():
 
 
 def test_abi_version_and_timer_name(lib):
-    assert lib.mapn_abi_version() == 4 and lib.mapn_tuning_abi_version() == 1
+    assert lib.mapn_abi_version() == 4 and lib.mapn_tuning_abi_version() == 2
     hdr = open(os.path.join(ROOT, "include", "mapn.h")).read() + open(os.path.join(ROOT, "include", "mapn_tuning.h")).read()
-    assert "#define MAPN_ABI_VERSION 4" in hdr and "#define MAPN_TUNING_ABI_VERSION 1" in hdr
+    assert "#define MAPN_ABI_VERSION 4" in hdr and "#define MAPN_TUNING_ABI_VERSION 2" in hdr
     assert lib.mapn_timer_name() == b"simulate ms"          # Compute.cpp:446
 
 
@@ -162,12 +162,28 @@ def test_product_does_not_link_or_reference_the_oracle():
                     text = open(os.path.join(dirpath, f)).read()
                     assert "import oracle" not in text and "from oracle" not in text and "mapn_oracle" not in text, f
     assert "oracle" not in open(os.path.join(ROOT, "mapn.py")).read()
-    # bench.py may touch the oracle only inside cpu_baseline()
-    bench = open(os.path.join(ROOT, "bench.py")).read()
-    head, rest = bench.split("def cpu_baseline", 1)
+    # the bench may touch the oracle only inside cpu_baseline() (bench_legs.py since round 6; bench.py and bench_ranks.py not at all)
+    for f in ("bench.py", "bench_ranks.py"):
+        text = open(os.path.join(ROOT, f)).read()
+        assert "from oracle" not in text and "import oracle" not in text, f
+    legs = open(os.path.join(ROOT, "bench_legs.py")).read()
+    head, rest = legs.split("def cpu_baseline", 1)
     body, tail = rest.split("\ndef ", 1)
+    assert "from oracle" in body
     assert "from oracle" not in head and "import oracle" not in head
     assert "from oracle" not in tail and "import oracle" not in tail
+
+
+def test_bench_py_is_the_timed_region_and_the_line_and_stays_readable():
+    """bench.py (the file the driver runs and hashes) holds the arguments, the timed region and the JSON line -- at most 500
+    lines; the legs beside the region live in bench_legs.py, the launcher / exchange trial / fallback in bench_ranks.py."""
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert len(bench.splitlines()) <= 500, len(bench.splitlines())
+    assert "def run_steps(" in bench and "def parse(" in bench and "json.dumps(out)" in bench
+    for name, home in (("def launch_ranks(", "bench_ranks.py"), ("def exchange_trial(", "bench_ranks.py"), ("def fall_back(", "bench_ranks.py"),
+                       ("def cpu_baseline(", "bench_legs.py"), ("def power_leg(", "bench_legs.py"), ("def central_well_leg(", "bench_legs.py"),
+                       ("def partial_active_leg(", "bench_legs.py"), ("def roofline_all_pairs(", "bench_legs.py"), ("def survey_8d(", "bench_legs.py")):
+        assert name in open(os.path.join(ROOT, home)).read() and name not in bench, name
 
 
 def test_force_kernel_keeps_its_scalar_loads(tmp_path):

@@ -115,6 +115,11 @@ def test_bench_json_contract():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e8 and "sample" in cb
     rep = d["config"]["repeats"]            # five regions of K steps, listed with their median, for every K; SURVEY 8(d)'s count needs K >= 100
     assert len(rep["ms_per_step"]) == 5 and rep["meets_survey_8d"] is False and abs(rep["ms_per_step"][0] - d["ms_per_step"]) < 1e-4
+    # ... and SURVEY 8(d)'s statistic itself whatever K is: K = 40 < 100, so five more regions of 100 steps ran behind the timed one
+    s8 = d["config"]["survey_8d"]
+    assert s8["steps"] == 100 and s8["repeats"] == 5 and s8["meets_survey_8d"] is True and s8["min"] <= s8["median_ms_per_step"] <= s8["max"]
+    assert 0.4 < s8["median_ms_per_step"] < 1.0 and s8["max"] / s8["min"] < 1.15 and abs(s8["interactions_per_s"] - 65536.0 ** 2 / (s8["median_ms_per_step"] * 1e-3)) < 1e-3 * s8["interactions_per_s"]
+    assert abs(s8["median_ms_per_step"] / d["ms_per_step"] - 1.0) < 0.15      # (the K-step region the driver asked for is no outlier against it)
     assert d["value"] > 3.0e12            # the 40 %-of-peak target is 3.15e12 at kernel level
     # the HBM-bound mode in the same line: CSMain as shipped at 4 Mi bodies (defines.h:45) and at 16 Mi, GB/s = 56 N / t
     cw = d["config"]["central_well"]
@@ -168,6 +173,8 @@ def test_bench_reports_a_median_of_five_repeats_from_100_steps_on():
     assert len(rep["ms_per_step"]) == 5 and rep["meets_survey_8d"] is True and abs(rep["ms_per_step"][0] - d["ms_per_step"]) < 1e-4
     assert sorted(rep["ms_per_step"])[2] == rep["median_ms_per_step"] and 0.4 < rep["median_ms_per_step"] < 1.0
     assert max(rep["ms_per_step"]) / min(rep["ms_per_step"]) < 1.15, rep      # one box, one clock state: the regions agree (2 - 3 % typically)
+    s8 = d["config"]["survey_8d"]           # K >= 100: those five regions ARE the statistic
+    assert s8["steps"] == 100 and s8["repeats"] == 5 and s8["meets_survey_8d"] is True and s8["median_ms_per_step"] == rep["median_ms_per_step"]
 
 
 @pytest.mark.gpu

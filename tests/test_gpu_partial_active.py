@@ -233,6 +233,112 @@ def test_split_form_falls_back_when_its_scratch_cannot_be_had(oracle, monkeypatc
         assert c.kernel_stats().split_active == 0              # not tried again for this count
 
 
+def test_a_slider_between_two_counts_builds_two_plans_and_gives_the_bits_of_a_context_that_replans_every_step(monkeypatch):
+    """mapn_simulate remembered ONE split plan, so a slider alternating between two counts re-planned -- behind a drained
+    stream -- on every step.  The last four counts now keep their plans: 40 steps alternating 32 768 / 40 960 active bodies build exactly two
+    (mapn_kernel_stats.split_plans_built), and the trajectory is bit for bit that of a context held to one remembered plan (the
+    MAPN_ACT_PLANS=1 hook: it builds forty) -- a plan is a pure function of the count, wherever it is kept."""
+    n, seq = 65536, [32768, 40960] * 20
+    res = {}
+    for slots in ("4", "1"):
+        monkeypatch.setenv("MAPN_TEST_HOOKS", "1"); monkeypatch.setenv("MAPN_ACT_PLANS", slots)
+        with mapn.Compute(n, mass=70000.0 / n) as c:
+            for na in seq:
+                c.Simulate(na, c.GetFenceValue())
+                assert c.kernel_stats().split_active == na
+            res[slots] = ([c.download_buffer(b) for b in (0, 1)], c.kernel_stats().split_plans_built)
+    assert res["4"][1] == 2 and res["1"][1] == len(seq), (res["4"][1], res["1"][1])
+    for b in (0, 1):
+        np.testing.assert_array_equal(res["4"][0][b][0], res["1"][0][b][0]); np.testing.assert_array_equal(res["4"][0][b][1], res["1"][0][b][1])
+
+
+def test_more_counts_than_cached_plans_evict_and_rebuild_to_the_same_bits():
+    """Six counts cycled twice through a cache of four plans: every count is evicted before it comes round again (twelve plans built),
+    a slot's table buffer is re-uploaded stream-ordered behind the steps that still read its old contents, and the shared rows grow
+    while steps are queued -- nothing is waited for; the run must equal, bit for bit, one with a WaitForGpu after every step."""
+    n = 65536
+    seq = [24576, 32768, 40960, 49152, 28672, 36864] * 2
+    res = []
+    for drain in (False, True):
+        with mapn.Compute(n, mass=70000.0 / n) as c:
+            for na in seq:
+                c.Simulate(na, c.GetFenceValue())
+                if drain:
+                    c.WaitForGpu()
+            st = c.kernel_stats()
+            assert st.split_active == seq[-1] and st.split_plans_built == len(seq), (st.split_active, st.split_plans_built)
+            res.append([c.download_buffer(b) for b in (0, 1)])
+    for b in (0, 1):
+        np.testing.assert_array_equal(res[0][b][0], res[1][b][0]); np.testing.assert_array_equal(res[0][b][1], res[1][b][1])
+
+
+def test_a_new_count_behind_a_parked_step_neither_blocks_nor_outruns_the_consumer():
+    """the first step with a new num_active used to synchronise the compute stream INSIDE mapn_simulate -- after the wait
+    on the consumer's fence (Compute.cpp:1012) had been queued.  With the stream parked behind that fence the calling thread (the one
+    that signals, Particles.cpp:446-448) stalled for the consumer time-out, the wait gave up and the step ran over the buffer the
+    consumer might still be reading.  Now: Simulate(n / 2, fence) before the consumer's signal returns at once with the step parked; a
+    SECOND new count queued behind it (another plan, rows that grow, the one-sided row buffer that moves) returns at once too; after the
+    signals both complete, and the result is bit for bit that of a context without a consumer."""
+    import time
+    n, a1, a2 = 65536, 32768, 49152
+    with mapn.Compute(n, mass=70000.0 / n) as ref:
+        ref.Simulate(a1, 0); ref.Simulate(a2, 0)
+        want = [ref.download_buffer(b) for b in (0, 1)]
+    with mapn.Compute(n, mass=70000.0 / n) as c:
+        c.GetSharedHandles()                               # attaches the consumer's fence
+        c.set_timeouts(consumer_ms=4000)
+        f1 = c.GetFenceValue()
+        t0 = time.perf_counter()
+        c.Simulate(a1, f1)                                 # parked: the consumer has not signalled f1 - 1
+        f2 = c.GetFenceValue()
+        c.Simulate(a2, f2)                                 # a second new count behind the parked step
+        host_s = time.perf_counter() - t0
+        assert host_s < 0.5, f"Simulate blocked the calling thread for {host_s:.2f} s with the stream parked behind the consumer's fence"
+        time.sleep(0.05)
+        assert c.GetCompletedValue() < f1                  # parked: nothing of the first step has completed
+        c.ConsumerSignal(f2 - 1)                           # (f2 - 1 = f1 covers both waits)
+        c.WaitForGpu()                                     # would raise MAPN_ERR_STATE had a wait given up
+        assert c.GetCompletedValue() >= f2 and c.kernel_stats().split_plans_built == 2
+        got = [c.download_buffer(b) for b in (0, 1)]
+    for b in (0, 1):
+        np.testing.assert_array_equal(got[b][0], want[b][0]); np.testing.assert_array_equal(got[b][1], want[b][1])
+
+
+def test_a_captured_step_is_keyed_by_the_form_it_runs_not_by_the_count_alone(monkeypatch):
+    """the graph cache was keyed by num_active alone, so flipping the MAPN_PARTIAL_FORM hook for the same count (what
+    bench.py's partial-active leg does) replayed the OTHER form's graph.  The key now carries the form (and the plan's generation):
+    split, one-sided, split again for one count must give the bits of the same sequence run eagerly, and the kernel statistics must name
+    the form that ran."""
+    n, na = 65536, 32768
+    res = []
+    for flags in (0, mapn.FLAG_USE_GRAPH):
+        monkeypatch.setenv("MAPN_TEST_HOOKS", "1")
+        with mapn.Compute(n, mass=70000.0 / n, flags=flags) as c:
+            c.set_timers(0)
+            for form in ("split", "one", "split", "one"):
+                monkeypatch.setenv("MAPN_PARTIAL_FORM", form)
+                draw(c, 2, na)
+                assert (c.kernel_stats().split_active != 0) == (form == "split"), form
+            res.append([c.download_buffer(b) for b in (0, 1)])
+        monkeypatch.delenv("MAPN_PARTIAL_FORM")
+    for b in (0, 1):
+        np.testing.assert_array_equal(res[0][b][0], res[1][b][0]); np.testing.assert_array_equal(res[0][b][1], res[1][b][1])
+
+
+def test_the_split_hook_falls_back_when_the_plan_cannot_be_made(oracle, monkeypatch):
+    """with MAPN_PARTIAL_FORM=split a failed preparation still named the split form and the step launched a plan of
+    zero bodies (hipErrorInvalidConfiguration).  It now runs another form, like the cost model's own choice does."""
+    n, na = 65536, 16384
+    monkeypatch.setenv("MAPN_TEST_HOOKS", "1"); monkeypatch.setenv("MAPN_PARTIAL_FORM", "split"); monkeypatch.setenv("MAPN_SYM_FAIL_ALLOC", "1")
+    pos, vel = oracle.initial_state(n, seed=1)
+    sim = OracleSim(oracle, pos, vel, params=Params(mass=70000.0 / n)); sim.simulate(num_active=na)
+    with mapn.Compute(n, mass=70000.0 / n) as c:
+        draw(c, 1, na)
+        st = c.kernel_stats()
+        assert st.kernel_name.decode() == "force_sgpr_kernel" and st.split_active == 0
+        assert errs(c.download_state()[0][:, :3], sim.latest[0][:, :3], SPREAD)[0] < 1e-6
+
+
 @pytest.mark.slow
 def test_split_form_at_4mi_bodies_half_active(oracle):
     """The reference's default size (defines.h:45) with the slider at half: 2 097 152 active bodies in 2048 blocks (several windows
@@ -306,3 +412,28 @@ def test_split_form_is_faster_than_the_one_sided_step_at_half_active(monkeypatch
             assert (c.kernel_stats().split_active != 0) == (form == "split")
     print(f"65 536 bodies, 32 768 active: one-sided {ms['one']:.4f} ms per step, split {ms['split']:.4f} ms ({ms['one'] / ms['split']:.3f} x)")
     assert ms["one"] / ms["split"] > 1.08
+
+
+@pytest.mark.timing
+def test_simulate_stays_an_enqueue_while_the_slider_alternates():
+    """VERDICT r5 #4, the host side: 200 steps alternating 32 768 / 40 960 active bodies of 65 536 -- after the second step (both plans
+    made) no call of Simulate may take the host 200 us (round 5: a drained stream + a host plan + a blocking upload on EVERY step,
+    0.4 - 0.6 ms each), and two plans are all that were built."""
+    import time
+    n = 65536
+    with mapn.Compute(n, mass=70000.0 / n) as c:
+        c.set_timers(0)
+        host = []
+        for k in range(200):
+            na = 32768 if k % 2 == 0 else 40960
+            f = c.GetFenceValue()
+            t0 = time.perf_counter()
+            c.Simulate(na, f)
+            host.append(time.perf_counter() - t0)
+            if k % 8 == 7:
+                c.WaitForGpu()                             # (keep the queue short: a full hardware queue blocks any launch, whatever the library does)
+        c.WaitForGpu()
+        st = c.kernel_stats()
+    later = np.array(host[2:]) * 1e6
+    print(f"Simulate host time, slider alternating 32768 / 40960: first two calls {host[0] * 1e6:.0f} / {host[1] * 1e6:.0f} us, then median {np.median(later):.1f} us, max {later.max():.1f} us; plans built {st.split_plans_built}")
+    assert st.split_plans_built == 2 and later.max() < 200.0, (st.split_plans_built, later.max())

@@ -61,15 +61,17 @@ typedef enum mapn_kernel {
     MAPN_KERNEL_LDS = 1,        /* j-tiles staged through LDS, broadcast ds_read */
     MAPN_KERNEL_SCALAR = 2,     /* j-bodies through the scalar cache into SGPRs */
     MAPN_KERNEL_SYMMETRIC = 3   /* Newton's third law: every unordered pair evaluated once, feeding both bodies
-                                   (csrc/mapn_sym.hip).  Applies to the unsharded step with N >= 1024 and at least
-                                   three quarters of the bodies active (the frozen ones still exert force); any other
-                                   step of such a context runs the scalar-cache kernel.  Its
+                                   (csrc/mapn_sym.hip).  Applies to the unsharded step with N >= 1024 (and to the sharded
+                                   step under gather algorithms 4 / 5 / 6).  A step with num_active < N takes whichever of
+                                   THREE forms is cheapest for that count -- the full symmetric step (the reduce launch stops
+                                   at the active bodies), the split form (active x active symmetric, active x frozen
+                                   one-sided) or the one-sided kernel over active x N: mapn_simulate below,
+                                   mapn_step_form_describe.  Its
                                    scratch is O(N): a step is made in as many launches (windows of partner distance) as
                                    keep the reaction rows within MAPN_SYM_MAX_MB (default 1024), and is allocated by
                                    mapn_create -- which fails if the memory is not to be had.  Under
                                    MAPN_KERNEL_AUTO the same failure only selects the one-sided kernel
-                                   (mapn_get_sym_plan, mapn_tuning.h, tells why).  A step with num_active < N runs whichever of three
-                                   forms is cheapest for that count: see mapn_simulate. */
+                                   (mapn_get_sym_plan, mapn_tuning.h, tells why). */
     /* No MFMA variant (BASELINE configs[4] A/B; re-measured by `pytest -m gpu` on every run since round 4:
        tests/test_gpu_mfma_ab.py): on gfx950 the f32 MFMA shapes do NOT run beside the packed fp32 VALU stream
        of the same SIMD -- their times add (16 v_pk_fma_f32 + one v_mfma_f32_16x16x4_f32: 106 cycles against
@@ -174,8 +176,10 @@ int mapn_destroy(mapn_ctx *ctx);
  * A PARTIALLY ACTIVE all-pairs step (num_active < N) runs the cheapest of three forms for that (N, num_active) -- always the same one,
  * so results stay bit-reproducible: the full symmetric step whose reduce launch stops early; the one-sided kernel over active x N; or
  * the SPLIT form (active x active under the symmetric kernel with a plan of the active blocks alone + active x frozen one-sided: measured
- * 1.14 - 1.47 x the one-sided step from half the bodies active upwards).  The FIRST step with a new count builds the split form's plan
- * and scratch (a host-side plan, a table upload, allocations behind a drained stream); the steps after it do not allocate.
+ * 1.16 x the one-sided step at half of the bodies active -- the bound there is 1.18 x -- to 1.34 x at 7/8).  The split form's plans are
+ * kept for the last four counts; a NEW count builds its plan on the host and uploads it stream-ordered into its own table buffer, rows that
+ * have to grow are allocated anew and the old ones freed later, once the stream has run dry: the call never waits for the device, also
+ * while a step is parked behind the consumer's fence (mapn_kernel_stats.split_plans_built counts the plans built).
  * Afterwards the fence value is +1 and the buffer index flipped (MoveToNextFrame,
  * Compute.cpp:993-1004).  A device-side wait that timed out in an EARLIER step (peer-to-peer
  * exchange, consumer fence) makes this call fail with MAPN_ERR_COMM / MAPN_ERR_STATE.

@@ -212,6 +212,7 @@ struct mapn_ctx {
     float4 *sym_send = nullptr, *sym_recv = nullptr;   // gather algorithm 6: reaction rows [world][count] packed for / delivered by RCCL
     bool step_pulled = false;                 // this step's exchange launch already moved the positions (algorithms 4 / 5)
     bool push_pending = false;                // algorithm 5: the peers' pushes of the latest step have not been waited for yet
+    uint32_t push_active = 0;                 // ... and that step advanced (pushed) the bodies [0, push_active) of the whole job
     uint32_t sym_send_mask = 0, sym_recv_mask = 0;
     bool p2p_loopback = false;                // MAPN_P2P_LOOPBACK=1 (timing on a 1-GPU box only): every peer maps to this rank
     uint32_t *flow_block = nullptr;           // ordinary device memory: [0..15] arrived[q], [16] tiles_done (flow mode)

@@ -106,6 +106,7 @@ struct SymArgs {
     // integrating positions that are stale, torn or misplaced (the reaction rows carry a tag, the positions cannot)
     const uint32_t *verify_sums;     // this rank's checksum rows [publication parity][sender][count / 32] (uncached region)
     uint32_t      verify_epoch, verify_count;    // publication number the checksums must carry; bodies per rank
+    uint32_t      verify_active;                 // bodies [0, verify_active) of the whole job were pushed by that publication (N: all; fewer: a partially active step)
     uint32_t      stage_iblock;   // the workgroup's waves share the I-block's global loads through LDS
     uint32_t      row_wt;     // rows are stored write-through (sc1) as they are produced instead of waiting in L2 for the end-of-kernel write-back
     float         mass, soft2, dt, damping;
@@ -188,7 +189,10 @@ struct SymShardArgs {
                                               // or stale row cannot pass, whatever the order in which its bytes arrive
     uint32_t     *status;                     // host-visible word: non-zero = a wait timed out
     uint32_t      rank, world, count;         // count = bodies per rank (a multiple of SYM_BLOCK)
-    uint32_t      nb, nbl, a0, half_d, parts, nwaves, max_meetings, sets;
+    uint32_t      active, count_active;       // the bodies [0, active) of the whole job advance (N: all of them), count_active of them are this rank's (its first ones)
+    const float4 *extra;                      // a PARTIALLY ACTIVE step: [extra_rows][extra_stride] partial force rows of the one-sided launch over this rank's FROZEN bodies
+    uint32_t      extra_rows, extra_stride;   // (force_*_kernel, EPI_ROWS; indexed by the body's number in the whole job), added per destination body in front of the reactions (null: none)
+    uint32_t      nb, nbl, a0, half_d, parts, nwaves, max_meetings, sets;   // nb: blocks of the (active) job's ring; nbl / a0: this rank's blocks in it (nbl 0: it runs no meetings)
     uint32_t      send_mask, recv_mask;       // bit q: this rank produces reactions for / receives reactions from rank q
     uint32_t      step;                       // monotonically increasing (>= 1): number of the reaction exchange
     uint32_t      pos_step;                   // number of this publication of new positions by a sharded symmetric step (0: they travel in another launch)
@@ -208,7 +212,8 @@ int probe_active_compute_units(hipStream_t st);                             // c
 // stream operation: wait (bounded) until every peer's publication counter has reached `need` (positions pushed by the peers)
 // ... and, when verify_sums is given, check the pushed slices of `replica` against the pushers' checksums (as the force launch does)
 hipError_t launch_p2p_wait(const uint32_t *counters, uint32_t need, uint32_t world, uint32_t rank, uint32_t self, uint64_t timeout_ticks,
-                           uint32_t *status, uint32_t *dead, const float4 *replica, const uint32_t *verify_sums, uint32_t verify_epoch, uint32_t count, hipStream_t st);
+                           uint32_t *status, uint32_t *dead, const float4 *replica, const uint32_t *verify_sums, uint32_t verify_epoch, uint32_t count,
+                           uint32_t verify_active, hipStream_t st);
 
 bool force_plan_supported(const ForcePlan &plan);
 hipError_t launch_force(const ForcePlan &plan, const StepArgs &a, hipStream_t st);

@@ -125,14 +125,16 @@ __device__ __forceinline__ uint32_t xor_reduce32(uint32_t h)
 // Gather algorithm 5, receiver side: re-compute the checksums of what the peers PUSHED into `replica` (read past the caches, after
 // their counters) and compare them with the words the pushers stored behind the data.  Called by whole waves: half-wave h of wave
 // `wv` (of `nw`) takes the 32-body groups 2 wv + h, 2 wv + h + 2 nw, ... of the (world - 1) x count / 32 pushed groups.
+// `active`: the publication was that of a PARTIALLY ACTIVE step -- only the bodies [0, active) of the whole job were pushed (a multiple of 64: whole groups).
 __device__ __forceinline__ void verify_pushed(const float4 *replica, const uint32_t *sums, uint32_t epoch, uint32_t count, uint32_t world, uint32_t rank,
-                                              uint32_t self, uint32_t wv, uint32_t nw, uint32_t lane, uint32_t *status, uint32_t *dead)
+                                              uint32_t self, uint32_t wv, uint32_t nw, uint32_t lane, uint32_t *status, uint32_t *dead, uint32_t active)
 {
     const uint32_t per = count / 32u, ng = (world - 1u) * per;            // (count is a multiple of 1024: ng is even)
     for (uint32_t base = 2u * wv; base < ng; base += 2u * nw) {
         const uint32_t gi = base + (lane >> 5), k = gi / per, grp = gi - k * per;
         const uint32_t qp = k < rank ? k : k + 1u, q = self ? rank : qp;   // (loopback timing: the "peers" are this rank -- the data is its own slice,
         const uint32_t body = q * count + grp * 32u + (lane & 31u);        //  the checksum row the one it stored for "peer" qp)
+        if (body >= active) continue;                                      // (a frozen body: nobody pushed it)
         const uint32_t want = __hip_atomic_load(sums + ((size_t)(epoch & 1u) * world + qp) * per + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const float4 v = load_sys(replica + body);
         uint32_t h = sym_push_checksum(__builtin_bit_cast(uint32_t, v.x), __builtin_bit_cast(uint32_t, v.y), __builtin_bit_cast(uint32_t, v.z),
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void force_sym_kernel(const SymArgs 
         //  overwrite "peer q is late" with "peer q pushed corrupted data": ADVICE r4)
         if (p.verify_sums && arrived)
             verify_pushed(pos, p.verify_sums, p.verify_epoch, p.verify_count, p.wait_world, p.wait_rank, p.wait_self,
-                          (la * p.parts + s) * WAVES + w, gridDim.x * gridDim.y * WAVES, lane, p.wait_status, p.wait_dead);
+                          (la * p.parts + s) * WAVES + w, gridDim.x * gridDim.y * WAVES, lane, p.wait_status, p.wait_dead, p.verify_active);
     };
     SymBodies b;
     if (p.stage_iblock) {
@@ -623,10 +625,27 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     const uint32_t total = p.phase == 2u ? 0u : p.world * p.count;
     for (uint32_t t = bid * 256u + threadIdx.x; t < total; t += nblk * 256u) {
         const uint32_t q = t / p.count, jl = t - q * p.count;
-        if (!((p.send_mask >> q) & 1u)) continue;
-        const uint32_t b = t / SYM_BLOCK, jb = t >> 6, tt = jb % SYM_JPI;     // t is the body's index in the whole job
+        if (!((p.send_mask >> q) & 1u) || t >= p.active) continue;            // (t is the body's index in the whole job; a frozen body collects nothing)
+        const uint32_t b = t / SYM_BLOCK, jb = t >> 6, tt = jb % SYM_JPI;
         const SymRow *rows = p.brow + (size_t)jb * p.nbl * 64u + (t & 63u);
         float fx = 0.f, fy = 0.f, fz = 0.f;
+        if (p.extra) {
+            // a PARTIALLY ACTIVE step: what this rank's FROZEN bodies do to body t -- the partial rows of the one-sided launch in front of this
+            // one, in ascending row order from zero (eight loads in flight); the reactions of this rank's active blocks follow
+            const float4 *xr = p.extra + t;
+            uint32_t r = 0;
+            for (; r + 8u <= p.extra_rows; r += 8u) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = xr[(size_t)(r + u) * p.extra_stride];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { fx += v[u].x; fy += v[u].y; fz += v[u].z; }
+            }
+            for (; r < p.extra_rows; r++) {
+                const float4 v = xr[(size_t)r * p.extra_stride];
+                fx += v.x; fy += v.y; fz += v.z;
+            }
+        }
         for (uint32_t la = 0; la < p.nbl; la += 8u) {      // eight meetings in flight, added in ascending block order
             SymRow v[8], h[8];
             uint32_t gg[8], sp[8];
@@ -670,7 +689,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     const uint32_t bl = threadIdx.x % B, g = threadIdx.x / B;
     auto own_rows = [&](uint32_t il, float &ax, float &ay, float &az) {
         ax = ay = az = 0.f;
-        if (il >= p.count) return;
+        if (il >= p.count_active) return;
         const uint32_t la = il / SYM_BLOCK;
         const SymRow *ar = p.arow + (size_t)la * p.parts * SYM_BLOCK + (il - la * SYM_BLOCK);
         const uint32_t s0 = (uint32_t)(((uint64_t)p.parts * g) / G), s1 = (uint32_t)(((uint64_t)p.parts * (g + 1u)) / G);
@@ -732,9 +751,9 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     if (!ok) return;
     if (!p.chunk_flags && !p.poll_rows) stamp(3);          // the peers' rows are here
 
-    for (uint32_t base = bid * B; base < p.count; base += nblk * B) {
+    for (uint32_t base = bid * B; base < p.count_active; base += nblk * B) {     // (count_active: this rank's bodies that advance -- all of them, or fewer in a partially active step)
         const uint32_t il = base + bl;
-        const bool live = il < p.count;
+        const bool live = il < p.count_active;
         if (base != bid * B) own_rows(il, ax, ay, az);
         if (p.chunk_flags && !p.poll_rows && p.phase == 0u && threadIdx.x < 64u) {
             // the senders' flags of THIS chunk (one lane per sender; bounded)
@@ -883,8 +902,9 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
 #pragma unroll
         for (uint32_t u = 0; u < 8u; u++) {
             const uint32_t eu = e + u * nblk * 256u;
-            const bool live = eu < others;
-            const uint32_t k = live ? eu / p.count : 0u, q = k < p.rank ? k : k + 1u;      // skip self
+            const bool in = eu < others;
+            const uint32_t k = in ? eu / p.count : 0u, q = k < p.rank ? k : k + 1u;        // skip self
+            const bool live = in && q * p.count + (eu - k * p.count) < p.active;           // (a partially active step: the frozen bodies did not move)
             at[u] = live ? q * p.count + (eu - k * p.count) : 0xffffffffu;
             const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p.pos_peer[q] + (live ? at[u] : 0u));
             lo[u] = live ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
@@ -904,20 +924,21 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
 // ... and (verify_sums != null) checks their slices against the pushers' checksums like the force launch does; grid = waves that share the check
 __global__ __launch_bounds__(64) void p2p_wait_kernel(const uint32_t *counters, uint32_t need, uint32_t world, uint32_t rank, uint32_t self,
                                                       uint64_t timeout_ticks, uint32_t *status, uint32_t *dead, const float4 *replica, const uint32_t *verify_sums,
-                                                      uint32_t verify_epoch, uint32_t count)
+                                                      uint32_t verify_epoch, uint32_t count, uint32_t verify_active)
 {
     const uint32_t q = threadIdx.x;
     const uint32_t good = wait_counters(counters, self ? rank : q, q < world && q != rank, need, timeout_ticks, status, 1u + q, dead);
-    if (verify_sums && good) verify_pushed(replica, verify_sums, verify_epoch, count, world, rank, self, blockIdx.x, gridDim.x, threadIdx.x, status, dead);
+    if (verify_sums && good) verify_pushed(replica, verify_sums, verify_epoch, count, world, rank, self, blockIdx.x, gridDim.x, threadIdx.x, status, dead, verify_active);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
 hipError_t launch_p2p_wait(const uint32_t *counters, uint32_t need, uint32_t world, uint32_t rank, uint32_t self, uint64_t timeout_ticks,
-                           uint32_t *status, uint32_t *dead, const float4 *replica, const uint32_t *verify_sums, uint32_t verify_epoch, uint32_t count, hipStream_t st)
+                           uint32_t *status, uint32_t *dead, const float4 *replica, const uint32_t *verify_sums, uint32_t verify_epoch, uint32_t count,
+                           uint32_t verify_active, hipStream_t st)
 {
     const uint32_t groups = verify_sums ? (world - 1u) * (count / 32u) : 0u;
     const uint32_t grid = std::max(1u, std::min(64u, groups / 2u));
-    hipLaunchKernelGGL(p2p_wait_kernel, dim3(grid), dim3(64), 0, st, counters, need, world, rank, self, timeout_ticks, status, dead, replica, verify_sums, verify_epoch, count);
+    hipLaunchKernelGGL(p2p_wait_kernel, dim3(grid), dim3(64), 0, st, counters, need, world, rank, self, timeout_ticks, status, dead, replica, verify_sums, verify_epoch, count, verify_active);
     return hipGetLastError();
 }
 

@@ -564,7 +564,8 @@ int settle_push(mapn_ctx *c)
     // (the latest step wrote buffer 1 - index: that is where the peers pushed; their checksums are verified as the force launch would)
     HIP_TRY(mapn::launch_p2p_wait(c->p2p_flags + mapn::SYM_POS_BASE, c->sym_pos_epoch * mapn::SYM_COUNT_PER_LAUNCH, (uint32_t)c->cfg.world_size, (uint32_t)c->cfg.rank, c->p2p_loopback ? 1u : 0u,
                                   c->p2p_timeout_ticks, c->async_status, c->p2p_flags + mapn::SYM_DEAD_WORD, c->pos[1 - c->buffer_index],
-                                  sym_push_check() ? c->p2p_flags + mapn::sym_region_pos_sums_word((uint32_t)c->cfg.world_size, c->count) : nullptr, c->sym_pos_epoch, c->count, c->compute));
+                                  sym_push_check() ? c->p2p_flags + mapn::sym_region_pos_sums_word((uint32_t)c->cfg.world_size, c->count) : nullptr, c->sym_pos_epoch, c->count,
+                                  c->push_active, c->compute));
     return MAPN_OK;
 }
 
@@ -594,7 +595,7 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
         a.wait_need = c->sym_pos_epoch * mapn::SYM_COUNT_PER_LAUNCH; a.wait_world = world; a.wait_rank = rank; a.wait_self = c->p2p_loopback ? 1u : 0u;
         a.wait_dead = c->p2p_flags + mapn::SYM_DEAD_WORD;
         if (c->push_pending && sym_push_check()) {         // pushes nobody has checked yet (not after an upload: that data is not the peers')
-            a.verify_sums = c->p2p_flags + mapn::sym_region_pos_sums_word(world, c->count); a.verify_epoch = c->sym_pos_epoch; a.verify_count = c->count;
+            a.verify_sums = c->p2p_flags + mapn::sym_region_pos_sums_word(world, c->count); a.verify_epoch = c->sym_pos_epoch; a.verify_count = c->count; a.verify_active = c->push_active;
         }
         c->push_pending = false;
     }
@@ -631,6 +632,7 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     h.pos_sums = push && sym_push_check() ? (uint32_t)mapn::sym_region_pos_sums_word(world, c->count) : 0u;
     h.status = c->async_status;
     h.rank = rank; h.world = world; h.count = c->count;
+    h.active = c->n; h.count_active = c->count;            // (all bodies advance: the partially active step is enqueue_sym_shard_split)
     h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = pl.parts; h.nwaves = pl.nwaves; h.max_meetings = pl.max_meetings; h.sets = pl.sets;
     h.send_mask = c->sym_send_mask; h.recv_mask = c->sym_recv_mask;
     h.step = ++c->sym_shard_step;
@@ -644,6 +646,7 @@ int enqueue_sym_shard(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer)
     }
     c->step_pulled = pull;
     c->push_pending = push;
+    c->push_active = c->n;
     h.pull_self = c->p2p_loopback ? 1u : 0u;
     h.timeout_ticks = c->p2p_timeout_ticks;
     h.mass = a.mass; h.dt = a.dt; h.damping = a.damping;
@@ -681,6 +684,7 @@ int enqueue_sym_shard_rccl(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *t
     h.recv_mine = c->sym_recv;
     h.status = c->async_status;
     h.rank = rank; h.world = world; h.count = c->count;
+    h.active = c->n; h.count_active = c->count;
     h.nb = a.nb; h.nbl = a.shard_nbl; h.a0 = a.a0; h.half_d = a.half_d; h.parts = pl.parts; h.nwaves = pl.nwaves; h.max_meetings = pl.max_meetings; h.sets = pl.sets;
     h.send_mask = c->sym_send_mask; h.recv_mask = c->sym_recv_mask;
     h.step = ++c->sym_rccl_step;

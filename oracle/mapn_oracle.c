@@ -300,6 +300,9 @@ static void all_pairs_block_acc64(const ap_job *J, uint32_t b0, uint32_t nb)
     const float *pj = J->old_pos;
     for (uint32_t j = 0; j < J->n_total; j++, pj += 4) {
         const float xj = pj[0], yj = pj[1], zj = pj[2];
+        /* (two loops: the fp32 pair term at the full vector width, then the widening adds -- one mixed loop is vectorised at the
+         *  DOUBLE width throughout, the square root and the division included: 2.9 x the time of the reference-order leg, same bits) */
+        float tx[IB], ty[IB], tz[IB];
 #pragma GCC ivdep
         for (int k = 0; k < IB; k++) {
             float rx = xj - xi[k];
@@ -311,10 +314,13 @@ static void all_pairs_block_acc64(const ap_job *J, uint32_t b0, uint32_t nb)
             float inv = 1.0f / sqrtf(d);
             float inv3 = inv * inv * inv;
             float s = mass * inv3 * 1.0f;
-            float tx = rx * s, ty = ry * s, tz = rz * s;     /* the fp32 products of hlsl:56 */
-            ax[k] = ax[k] + (double)tx;
-            ay[k] = ay[k] + (double)ty;
-            az[k] = az[k] + (double)tz;
+            tx[k] = rx * s; ty[k] = ry * s; tz[k] = rz * s;  /* the fp32 products of hlsl:56 */
+        }
+#pragma GCC ivdep
+        for (int k = 0; k < IB; k++) {
+            ax[k] = ax[k] + (double)tx[k];
+            ay[k] = ay[k] + (double)ty[k];
+            az[k] = az[k] + (double)tz[k];
         }
     }
     for (uint32_t k = 0; k < nb; k++) {

@@ -141,8 +141,12 @@ typedef struct mapn_split_info {
     uint32_t active, frozen;
     uint32_t frozen_kernel;          /* mapn_kernel of the launch over the frozen bodies (MAPN_KERNEL_SCALAR / MAPN_KERNEL_LDS) */
     uint32_t frozen_bodies_per_lane, frozen_waves, frozen_sb;
-    uint32_t reserved[2];
+    uint32_t frozen_first;           /* first body of the one-sided launch's j-range: `active` unsharded; SHARDED: the first frozen body THIS rank owns
+                                        (`frozen` of them: a rank computes what ITS frozen bodies do to all active ones, and sends the sums to their owners) */
+    uint32_t has_plan;               /* 1: info / windows / tables describe the symmetric launch; 0 (sharded only): this rank owns no active body and runs no meetings */
 } mapn_split_info;
+/* SHARDED context (round 6): the plan of THIS rank's blocks in the active ring (info->a0 / nbl; split->has_plan 0 and no plan where the rank owns
+ * no active body), and split->frozen / frozen_first = the frozen bodies this rank owns: see mapn_shard_split_describe. */
 int mapn_get_split_plan(mapn_ctx *ctx, mapn_split_info *split, mapn_sym_plan_info *info, uint32_t *windows, uint64_t windows_capacity,
                         uint32_t *tables, uint64_t tables_capacity);
 /*
@@ -175,6 +179,25 @@ typedef struct mapn_shard_info {
     uint32_t reserved[2];
 } mapn_shard_info;
 int mapn_shard_describe(uint32_t num_particles, int32_t rank, int32_t world_size, int32_t num_active, mapn_shard_info *out);
+/*
+ * ... and of a PARTIALLY ACTIVE step of a sharded job in its split form (gather algorithms 4 / 5, round 6; Particles.cpp:391-394's slider on P ranks):
+ * the bodies [0, active) of the whole job, active = roundup64(num_active), advance and form a ring of `ring_blocks` 1024-body blocks of
+ * their own.  Rank `rank` runs the meetings of ITS blocks in that ring (`blocks` of them from block `first_block`; 0: its slice is
+ * frozen) under the plan mapn_sym_plan_describe(ring_blocks, ..., launch_blocks = blocks, launch_a0 = first_block) gives, and integrates
+ * its `active_count` active bodies; the `frozen_count` FROZEN bodies it owns (from `frozen_first`) still exert force, and their OWNER
+ * computes it -- one one-sided launch over active x (its frozen bodies) -- and sends the sums to the active bodies' owners in the same
+ * rows as the reactions (summation order per destination body: its frozen rows ascending from zero, then the reactions of its blocks as in
+ * the all-active sharded step).  send_mask / recv_mask: whom it sends rows to / receives rows from.  `applies`: 1 when the step takes this
+ * form for the shape (a pure function of N, P and the count: every rank decides alike), 0: it runs the one-sided kernel and pulls.
+ */
+typedef struct mapn_shard_split_info {
+    uint32_t applies, active;
+    uint32_t ring_blocks, blocks, first_block, active_count;
+    uint32_t frozen_first, frozen_count;
+    uint32_t send_mask, recv_mask;
+    uint32_t reserved[2];
+} mapn_shard_split_info;
+int mapn_shard_split_describe(uint32_t num_particles, int32_t rank, int32_t world_size, int32_t num_active, mapn_shard_split_info *out);
 
 /* Sharded mode: switch the own/remote overlap structure (MAPN_FLAG_SHARD_OVERLAP) at run time, so a
  * launcher can time both structures on the node it runs on; all ranks must agree. */

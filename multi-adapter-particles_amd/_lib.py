@@ -88,9 +88,14 @@ class ShardInfo(C.Structure):
     _fields_ = [(k, C.c_uint32) for k in ("first", "count", "active_first", "active_count", "sym_applies", "nb", "nbl", "a0", "send_mask", "recv_mask")] + [("reserved", C.c_uint32 * 2)]
 
 
+class ShardSplitInfo(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("applies", "active", "ring_blocks", "blocks", "first_block", "active_count", "frozen_first", "frozen_count",
+                                          "send_mask", "recv_mask")] + [("reserved", C.c_uint32 * 2)]
+
+
 class SplitInfo(C.Structure):
     _fields_ = [("active", C.c_uint32), ("frozen", C.c_uint32), ("frozen_kernel", C.c_uint32), ("frozen_bodies_per_lane", C.c_uint32),
-                ("frozen_waves", C.c_uint32), ("frozen_sb", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+                ("frozen_waves", C.c_uint32), ("frozen_sb", C.c_uint32), ("frozen_first", C.c_uint32), ("has_plan", C.c_uint32)]
 
 
 # every symbol include/mapn.h and include/mapn_tuning.h declare: (name, restype, argtypes)
@@ -155,6 +160,7 @@ SIGNATURES = {
     "mapn_set_shard_overlap": (C.c_int, [_ctx, C.c_int]),
     "mapn_step_form_describe": (C.c_int, [C.c_uint32, C.c_int32]),
     "mapn_shard_describe": (C.c_int, [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(ShardInfo)]),
+    "mapn_shard_split_describe": (C.c_int, [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(ShardSplitInfo)]),
     "mapn_calibrate_sym_xcds": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_uint32 * 8)]),
     "mapn_set_sym_xcd_weights": (C.c_int, [_ctx, C.POINTER(C.c_uint32 * 8)]),
     "mapn_sym_plan_describe": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32 * 8), C.c_uint32, C.c_uint32, C.c_uint32,

@@ -404,6 +404,13 @@ def describe_shard(num_particles: int, rank: int, world_size: int, num_active: i
     return info
 
 
+def describe_shard_split(num_particles: int, rank: int, world_size: int, num_active: int) -> "_lib.ShardSplitInfo":
+    """This rank's part of a PARTIALLY ACTIVE step of a sharded job in its split form, without a device (mapn_shard_split_describe)."""
+    info = _lib.ShardSplitInfo()
+    check(load_library().mapn_shard_split_describe(int(num_particles), int(rank), int(world_size), int(num_active), C.byref(info)))
+    return info
+
+
 def describe_sym_plan(nb: int, groups_per_window: int = 0, parts: int = 32, taper1: int | None = None, taper2: int = 0, waves: int = 4,
                       xcd_weights=None, launch_blocks: int = 0, wave_bias=(1, 1), launch_a0: int = 0, xcd_mode: int = 0) -> SymPlan:
     """The plan of a shape, computed on the host without a device (csrc/mapn_sym_plan.cpp)."""

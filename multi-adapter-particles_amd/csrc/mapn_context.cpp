@@ -301,7 +301,10 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
         a.xcd_remap = 0;                                   // dispatch order = row order: own rows first
     }
 
-    if (c->push_pending && !(i_count > 0 && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS && sym_shard_eligible(c, active) && c->gather_algo == 5))
+    // a PARTIALLY ACTIVE step of a sharded job in its split form: every rank takes part, also one whose slice is frozen (i_count == 0)
+    const bool shard_split = c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS && !flow && sym_shard_split_eligible(c, active);
+    if (shard_split) { if (int rc = prepare_sym_active(c, active)) return rc; }   // (this rank's plan for the count: a lookup after the first step with it; an error if it cannot be had)
+    if (c->push_pending && !shard_split && !(i_count > 0 && c->cfg.force_mode == MAPN_FORCE_ALL_PAIRS && sym_shard_eligible(c, active) && c->gather_algo == 5))
         if (int rc = settle_push(c)) return rc;            // this step's launch does not wait for the peers' pushes itself
 
     // an unsharded all-pairs step: full symmetric, split (active x active symmetric + active x frozen one-sided) or one-sided
@@ -317,7 +320,9 @@ int enqueue_step(mapn_ctx *c, uint32_t active, StepTimer *timer)
 
     if (timer) HIP_TRY(hipEventRecord(timer->start, c->compute));
 
-    if (i_count > 0 && c->cfg.force_mode == MAPN_FORCE_CENTRAL_WELL) {
+    if (shard_split) {
+        if (int rc = enqueue_sym_shard_split(c, a, timer)) return rc;
+    } else if (i_count > 0 && c->cfg.force_mode == MAPN_FORCE_CENTRAL_WELL) {
         mapn::StepArgs w0 = a;
         w0.flow_arrived = nullptr;                         // plain stores: the flag goes out behind the kernel boundary
         HIP_TRY(mapn::launch_central_well(w0, c->compute));
@@ -459,8 +464,12 @@ int enqueue_step_graph(mapn_ctx *c, uint32_t active)
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { victim->exec = nullptr; return fail(MAPN_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
         victim->active = active; victim->form = form; victim->generation = generation;
+        victim->plan = c->last_plan; victim->i_count = c->last_i_count; victim->launches = c->last_launches; victim->split_active = c->last_split_active;
+        victim->act_slot = c->act_cur;
         g = victim;
     }
+    c->last_plan = g->plan; c->last_i_count = g->i_count; c->last_launches = g->launches; c->last_split_active = g->split_active;
+    if (g->split_active) c->act_cur = g->act_slot;        // (the plan mapn_get_split_plan describes: the replayed step's)
     g->used = ++c->graph_clock;
     HIP_TRY(hipGraphLaunch(g->exec, c->compute));
     return MAPN_OK;

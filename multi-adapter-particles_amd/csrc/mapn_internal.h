@@ -51,6 +51,15 @@ constexpr int kTimerRing = 64;             // in-flight step timers
 constexpr int kAverageOver = 20;           // D3D12GpuTimer.h averageOver (Compute.cpp:445)
 constexpr uint64_t kHeapAlign = 64 * 1024; // Compute.cpp:185-194: 64 KiB placement alignment
 
+// this rank's part of a partially active step of a sharded job (mapn_sym_host.cpp: shard_split_describe)
+struct ShardSplit {
+    uint32_t nba = 0;                        // blocks of the ring the ACTIVE bodies form
+    uint32_t nbl = 0, a0 = 0;                // this rank's blocks in it (0: its slice is frozen)
+    uint32_t ac = 0;                         // active bodies it owns (its first ones) and integrates
+    uint32_t fz_first = 0, fz_count = 0;     // frozen bodies it owns: the j-range of its one-sided launch
+    uint32_t send_mask = 0, recv_mask = 0;   // ranks it sends rows to / receives rows from (reactions and frozen bodies' forces)
+};
+
 struct StepTimer {
     hipEvent_t start = nullptr, force_done = nullptr, stop = nullptr;
     uint64_t step_index = 0;     // which step since the last reset of the statistics carried these events
@@ -117,6 +126,7 @@ struct mapn_ctx {
         size_t cap_tab = 0, cap_stage = 0;    // bytes allocated
         hipEvent_t uploaded = nullptr;        // recorded behind the upload: the pinned copy may be rewritten once it has fired
         mapn::ForcePlan frozen{};             // the one-sided launch over the frozen j-segment (EPI_ROWS)
+        mapn::host::ShardSplit role{};        // who does what (unsharded: all active blocks, all frozen bodies)
     };
     static constexpr int kActPlans = 4;
     SymActive act_plans[kActPlans];
@@ -218,7 +228,10 @@ struct mapn_ctx {
     uint32_t *flow_block = nullptr;           // ordinary device memory: [0..15] arrived[q], [16] tiles_done (flow mode)
 
     // graph replay: per ping-pong parity the last kGraphs captured steps, keyed by what a capture depends on
-    struct StepGraph { hipGraphExec_t exec = nullptr; uint32_t active = 0; int form = -1; uint64_t generation = 0, used = 0; };
+    struct StepGraph {
+        hipGraphExec_t exec = nullptr; uint32_t active = 0; int form = -1; uint64_t generation = 0, used = 0;
+        mapn::ForcePlan plan{}; uint32_t i_count = 0, launches = 0, split_active = 0; int act_slot = -1;   // what the captured step reported (kernel stats, mapn_get_split_plan): a replay reports the same
+    };
     static constexpr int kGraphs = 4;
     StepGraph graphs[2][kGraphs];
     uint64_t graph_clock = 0;
@@ -257,6 +270,9 @@ void forget_sym_active(mapn_ctx *c);
 StepForm sym_form_without_split(const mapn_ctx *c, uint32_t active);
 int enqueue_sym_split(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer);
 bool sym_shard_eligible(const mapn_ctx *c, uint32_t active);
+ShardSplit shard_split_describe(uint32_t n, uint32_t world, uint32_t rank, uint32_t active);
+bool sym_shard_split_eligible(const mapn_ctx *c, uint32_t active);
+int enqueue_sym_shard_split(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *timer);
 bool sym_push_check();
 int settle_push(mapn_ctx *c);
 bool sym_shard_pull_folded();

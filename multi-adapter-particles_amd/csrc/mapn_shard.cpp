@@ -293,6 +293,24 @@ int mapn_shard_describe(uint32_t num_particles, int32_t rank, int32_t world_size
     return MAPN_OK;
 }
 
+int mapn_shard_split_describe(uint32_t num_particles, int32_t rank, int32_t world_size, int32_t num_active, mapn_shard_split_info *out)
+{
+    if (!out) return fail(MAPN_ERR_INVALID_ARGUMENT, "shard_split_describe: null argument");
+    memset(out, 0, sizeof *out);
+    if (num_particles == 0 || world_size < 2 || world_size > mapn::P2P_MAX_RANKS || rank < 0 || rank >= world_size)
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "rank %d / world_size %d", rank, world_size);
+    if (num_particles % (uint32_t)world_size || (num_particles / (uint32_t)world_size) % mapn::SYM_BLOCK)
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "a rank's slice must be whole 1024-body blocks (%u bodies over %d ranks)", num_particles, world_size);
+    const uint32_t active = active_bodies(num_active, num_particles);
+    out->active = active;
+    out->applies = (active < num_particles && active >= 2u * mapn::SYM_BLOCK) ? 1u : 0u;      // (sym_shard_split_eligible's part that depends on the shape)
+    if (!out->applies) return MAPN_OK;
+    const ShardSplit r = shard_split_describe(num_particles, (uint32_t)world_size, (uint32_t)rank, active);
+    out->ring_blocks = r.nba; out->blocks = r.nbl; out->first_block = r.a0; out->active_count = r.ac;
+    out->frozen_first = r.fz_first; out->frozen_count = r.fz_count; out->send_mask = r.send_mask; out->recv_mask = r.recv_mask;
+    return MAPN_OK;
+}
+
 int mapn_set_external_gather(mapn_ctx *c, int enabled)
 {
     if (!c) return fail(MAPN_ERR_INVALID_ARGUMENT, "null context");

@@ -96,6 +96,9 @@ class Oracle:
         lib.mapn_oracle_step_all_pairs_sym_sharded.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.POINTER(Params), C.c_int, C.c_uint32,
                                                                C.POINTER(SymShape), _u32p, _u32p, _u64p, C.c_uint32, C.c_int32]
         lib.mapn_oracle_step_all_pairs_sym_sharded.restype = C.c_int
+        lib.mapn_oracle_step_all_pairs_sym_sharded_split.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int, C.c_uint32,
+                                                                     C.POINTER(SymShape), _u32p, _u32p, _u64p, C.c_uint32, _u32p, _u32p]
+        lib.mapn_oracle_step_all_pairs_sym_sharded_split.restype = C.c_int
         lib.mapn_oracle_step_all_pairs_f64.argtypes = [_f64p, _f64p, _f64p, _f64p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int]
         lib.mapn_oracle_step_all_pairs_f64.restype = C.c_int
         lib.mapn_oracle_accel_all_pairs.argtypes = [_f32p, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
@@ -216,6 +219,38 @@ def step_sym_sharded(oracle, pos, vel, params, rank_plans, threads=0, only_rank=
     pos = np.ascontiguousarray(pos, np.float32); vel = np.ascontiguousarray(vel, np.float32)
     npos, nvel = pos.copy(), vel.copy()
     rc = oracle.lib.mapn_oracle_step_all_pairs_sym_sharded(pos, vel, npos, nvel, n, C.byref(params), threads, world, shapes, wins, tab, offs, G, int(only_rank))
+    assert rc == 0, rc
+    return npos, nvel
+
+
+def step_sym_sharded_split(oracle, pos, vel, params, n_active, rank_plans, rank_frozen, threads=0):
+    """One PARTIALLY ACTIVE step of a job SHARDED over len(rank_plans) ranks in the device's summation order (ORDER_MATCHED_SHARDED_SPLIT):
+    the bodies [0, n_active) of the whole job advance.  rank_plans[r] = the plan of rank r's blocks in the ACTIVE ring (as
+    mapn_get_split_plan returned it on that rank) or None where the rank owns no active body; rank_frozen[r] = (waves, sb) of the
+    one-sided launch over the frozen bodies rank r owns, or None where it owns none.  Returns (new_pos, new_vel); the frozen bodies are
+    returned as they came."""
+    world = len(rank_plans)
+    n = pos.shape[0]
+    args = [sym_plan_args(pl) if pl is not None else None for pl in rank_plans]
+    shapes = (SymShape * world)(*[a[0] if a is not None else SymShape() for a in args])
+    wins = np.zeros(4 * world, np.uint32)
+    offs = np.zeros(world, np.uint64)
+    tabs, at = [np.zeros(1, np.uint32)], 1
+    for r, a in enumerate(args):
+        if a is None:
+            continue
+        assert a[1].shape[0] == 1, "the sharded step is made in one window"
+        wins[4 * r:4 * r + 4] = a[1].reshape(-1)
+        offs[r] = at
+        tabs.append(a[2]); at += a[2].size
+    tab = np.ascontiguousarray(np.concatenate(tabs), np.uint32)
+    fw = np.array([f[0] if f is not None else 0 for f in rank_frozen], np.uint32)
+    fs = np.array([f[1] if f is not None else 0 for f in rank_frozen], np.uint32)
+    count = n // world
+    G = 8 if count <= 16384 else 4 if count <= 65536 else 1          # exchange_threads_per_body (csrc/mapn_sym.hip)
+    pos = np.ascontiguousarray(pos, np.float32); vel = np.ascontiguousarray(vel, np.float32)
+    npos, nvel = pos.copy(), vel.copy()
+    rc = oracle.lib.mapn_oracle_step_all_pairs_sym_sharded_split(pos, vel, npos, nvel, n, int(n_active), C.byref(params), threads, world, shapes, wins, tab, offs, G, fw, fs)
     assert rc == 0, rc
     return npos, nvel
 

@@ -1016,6 +1016,7 @@ typedef struct {
     float *acc;                 /* [3][np] */
     size_t np;
     uint32_t tid, nthreads;
+    uint32_t j_first, j_count;  /* the frozen j-range (unsharded: [n_active, n_total); sharded: the frozen bodies ONE rank owns) */
 } frozen_job;
 
 __attribute__((target_clones("avx512f", "fma", "default")))
@@ -1029,7 +1030,7 @@ static void frozen_block(const frozen_job *F, uint32_t b0, uint32_t nbod)
         tx[k] = ty[k] = tz[k] = 0.0f;
     }
     const uint32_t waves = F->waves, sb = F->sb, S = waves * sb;
-    const uint32_t j_first = F->n_active, j_count = F->n_total - F->n_active;
+    const uint32_t j_first = F->j_first, j_count = F->j_count;
     const uint32_t tiles = (j_count + 63u) / 64u, base = tiles / S, rem = tiles % S;
     for (uint32_t row = 0; row < sb; row++) {
         for (int k = 0; k < IB; k++) wx[k] = wy[k] = wz[k] = 0.0f;
@@ -1097,7 +1098,7 @@ int mapn_oracle_step_all_pairs_sym_split(const float *old_pos, const float *old_
         pthread_t *th = (pthread_t *)calloc((size_t)ft, sizeof(pthread_t));
         if (!jobs || !th) rc = -1;
         for (int t = 0; t < ft && rc == 0; t++) {
-            jobs[t] = (frozen_job){old_pos, n_total, n_active, frozen_waves, frozen_sb, p->soft2, acc, np, (uint32_t)t, (uint32_t)ft};
+            jobs[t] = (frozen_job){old_pos, n_total, n_active, frozen_waves, frozen_sb, p->soft2, acc, np, (uint32_t)t, (uint32_t)ft, n_active, n_total - n_active};
             if (t > 0 && pthread_create(&th[t], NULL, frozen_worker, &jobs[t]) != 0) { frozen_worker(&jobs[t]); th[t] = 0; }
         }
         if (rc == 0) {
@@ -1237,5 +1238,150 @@ int mapn_oracle_step_all_pairs_sym_sharded(const float *old_pos, const float *ol
     }
     for (uint32_t r = 0; r < world; r++) free(arows ? arows[r] : NULL);
     free(arows); free(recv); free(brow); free(brow1);
+    return rc;
+}
+
+/* =================================================================================================
+ * ORDER_MATCHED_SHARDED_SPLIT: the device's PARTIALLY ACTIVE step of a SHARDED job (csrc/mapn_sym_host.cpp, enqueue_sym_shard_split;
+ * Compute.cpp:1041: the bodies [0, n_active) of the whole job advance, the frozen ones still exert force), all ranks restated in one
+ * process.  The active bodies form a ring of nba = ceil(n_active / 1024) blocks; rank r owns count = n / world bodies:
+ *   * its ACTIVE ones (its first ac_r) lie in nbl_r = ceil(ac_r / 1024) blocks of the ring from block r * count / 1024: it runs their
+ *     meetings under ITS plan (shapes[r]; a job of n_active bodies, the rest far-away stand-ins) exactly as ORDER_MATCHED_SHARDED;
+ *   * its FROZEN ones [fz_first_r, (r + 1) count): per active body t of the whole job the one-sided kernel's partial rows over that
+ *     j-range (frozen_waves[r] x frozen_sb[r] chunks: ORDER_MATCHED_SPLIT's frozen rows with this j-range), added ascending to zero;
+ *   * SENDS per destination body: the frozen sum (zero if it owns no frozen body), then the rows of its blocks that met the body's block
+ *     as ORDER_MATCHED_SHARDED adds them;
+ *   * INTEGRATES its ac_r active bodies: the G partial sums of its a-rows, then the rows received nearest sender first; the frozen
+ *     bodies of the new buffers are left as they are.
+ * shapes[r].nb == 0: rank r owns no active body (no plan).  frozen_waves[r] == 0: it owns no frozen body.
+ * ================================================================================================= */
+int mapn_oracle_step_all_pairs_sym_sharded_split(const float *old_pos, const float *old_vel, float *new_pos, float *new_vel, uint32_t n, uint32_t n_active,
+                                                 const mapn_oracle_params *p, int threads, uint32_t world, const mapn_oracle_sym_shape *shapes,
+                                                 const uint32_t *windows, const uint32_t *tables, const uint64_t *table_offset, uint32_t G,
+                                                 const uint32_t *frozen_waves, const uint32_t *frozen_sb)
+{
+    if (!shapes || !windows || !tables || !table_offset || !frozen_waves || !frozen_sb || world < 2u || world > SHARD_MAX_RANKS || n % world ||
+        (n / world) % SYM_IB || G == 0u || n_active == 0u || n_active >= n || n_active % 64u) return -2;
+    if (threads <= 0) threads = mapn_oracle_hardware_threads();
+    const uint32_t count = n / world, cblk = count / SYM_IB, nba = (n_active + SYM_IB - 1u) / SYM_IB, half = (nba & 1u) ? 0u : nba / 2u;
+    uint32_t ac[SHARD_MAX_RANKS], nbl[SHARD_MAX_RANKS], fz_first[SHARD_MAX_RANKS], fz_count[SHARD_MAX_RANKS], nbl_max = 0;
+    for (uint32_t r = 0; r < world; r++) {
+        const uint32_t first = r * count, hi = first + count < n_active ? first + count : n_active;
+        ac[r] = hi > first ? hi - first : 0u;
+        nbl[r] = (ac[r] + SYM_IB - 1u) / SYM_IB;
+        fz_first[r] = first + ac[r];
+        fz_count[r] = count - ac[r];
+        if (nbl[r] > nbl_max) nbl_max = nbl[r];
+        if (nbl[r] && (shapes[r].nb != nba || shapes[r].windows != 1u || shapes[r].waves == 0 || shapes[r].parts == 0 || (shapes[r].sets != 2u && shapes[r].sets != 16u))) return -2;
+        if (fz_count[r] && (frozen_waves[r] == 0u || frozen_sb[r] == 0u)) return -2;
+    }
+    const size_t np = (size_t)nba * SYM_IB;
+    /* recv[q][r][body of q]: what rank r sends rank q */
+    float *recv = (float *)calloc((size_t)world * world * count * 3u, sizeof(float));
+    uint32_t sends[SHARD_MAX_RANKS][SHARD_MAX_RANKS];
+    memset(sends, 0, sizeof sends);
+    for (uint32_t a = 0; a < nba; a++)
+        for (uint32_t b = 0; b < nba; b++)
+            if (sym_group_of(a, b, nba, half)) sends[a / cblk][b / cblk] = 1u;
+    for (uint32_t r = 0; r < world; r++)
+        for (uint32_t q = 0; q < world; q++)
+            if (fz_count[r] && ac[q]) sends[r][q] = 1u;
+    size_t parts_max = 1;
+    for (uint32_t r = 0; r < world; r++) if (nbl[r] && shapes[r].parts > parts_max) parts_max = shapes[r].parts;
+    float **arows = (float **)calloc(world, sizeof(float *));
+    float *brow = (float *)malloc(sizeof(float) * 192u * (np / 64u) * (nbl_max ? nbl_max : 1u));
+    float *brow1 = (float *)malloc(sizeof(float) * 192u * (size_t)(nbl_max ? nbl_max : 1u) * parts_max);
+    float *facc = (float *)malloc(sizeof(float) * 3u * np);
+    int rc = (recv && arows && brow && brow1 && facc) ? 0 : -1;
+    for (uint32_t r = 0; r < world && rc == 0; r++) {
+        const mapn_oracle_sym_shape *sh = &shapes[r];
+        const uint32_t a0 = r * cblk;
+        sym_job J = {old_pos, old_vel, new_pos, new_vel, n_active, p, sh, windows + 4u * r, tables + table_offset[r], NULL, brow, brow1, NULL, 1, 1, 0, 0, a0, nbl[r]};
+        if (nbl[r]) {
+            arows[r] = (float *)malloc(sizeof(float) * 3u * SYM_IB * (size_t)nbl[r] * sh->parts);
+            if (!arows[r]) { rc = -1; break; }
+            J.arow = arows[r];
+            const uint32_t items = nbl[r] * sh->parts;
+            rc = sym_run(sym_force_worker, &J, (uint32_t)threads > items ? (int)items : threads);
+            if (rc) break;
+        }
+        if (fz_count[r]) {
+            /* what rank r's frozen bodies do to every active body of the job */
+            const uint32_t nblocks = (n_active + IB - 1) / IB;
+            const int ft = (uint32_t)threads > nblocks ? (int)nblocks : threads;
+            frozen_job *jobs = (frozen_job *)calloc((size_t)ft, sizeof(frozen_job));
+            pthread_t *th = (pthread_t *)calloc((size_t)ft, sizeof(pthread_t));
+            if (!jobs || !th) { free(jobs); free(th); rc = -1; break; }
+            for (int t = 0; t < ft; t++) {
+                jobs[t] = (frozen_job){old_pos, n, n_active, frozen_waves[r], frozen_sb[r], p->soft2, facc, np, (uint32_t)t, (uint32_t)ft, fz_first[r], fz_count[r]};
+                if (t > 0 && pthread_create(&th[t], NULL, frozen_worker, &jobs[t]) != 0) { frozen_worker(&jobs[t]); th[t] = 0; }
+            }
+            frozen_worker(&jobs[0]);
+            for (int t = 1; t < ft; t++) if (th[t]) pthread_join(th[t], NULL);
+            free(jobs); free(th);
+        }
+        /* SEND: per destination q and ACTIVE body t of q */
+        const uint32_t *splits = nbl[r] ? J.tab + sh->sets * (sh->parts * sh->waves + 1u) : NULL;
+        for (uint32_t q = 0; q < world; q++) {
+            if (!sends[r][q]) continue;
+            for (uint32_t jl = 0; jl < ac[q]; jl++) {
+                const uint32_t t = q * count + jl, b = t / SYM_IB, jb = t >> 6, tt = jb % SYM_JPI, l = t & 63u;
+                float fx = 0.0f, fy = 0.0f, fz = 0.0f;
+                if (fz_count[r]) { fx = facc[t]; fy = facc[np + t]; fz = facc[2 * np + t]; }
+                for (uint32_t la0 = 0; la0 < nbl[r]; la0 += 8u)
+                    for (uint32_t u = 0; u < 8u; u++) {                    /* batches of eight like the device: a missing row is a zero that is still added */
+                        const uint32_t la = la0 + u;
+                        float vx = 0.0f, vy = 0.0f, vz = 0.0f, hx = 0.0f, hy = 0.0f, hz = 0.0f;
+                        const uint32_t gg = la < nbl[r] ? sym_group_of(a0 + la, b, nba, half) : 0u;
+                        if (gg) {
+                            const float *r0 = brow + ((size_t)jb * nbl[r] + la) * 192u;
+                            vx = r0[l]; vy = r0[64 + l]; vz = r0[128 + l];
+                            const uint32_t set = (sym_runs_half(a0 + la, half) ? 0u : 1u) + (sh->sets > 2u ? 2u * (la & 7u) : 0u);
+                            const uint32_t sp = (splits + (size_t)set * sh->max_meetings)[gg * SYM_JPI + tt];
+                            if (sp != SYM_NONE) {
+                                const float *h0 = brow1 + ((size_t)la * sh->parts + sp) * 192u;
+                                hx = h0[l]; hy = h0[64 + l]; hz = h0[128 + l];
+                            }
+                        }
+                        fx = fx + vx; fy = fy + vy; fz = fz + vz;
+                        fx = fx + hx; fy = fy + hy; fz = fz + hz;
+                    }
+                float *dst = recv + (((size_t)q * world + r) * count + jl) * 3u;
+                dst[0] = fx; dst[1] = fy; dst[2] = fz;
+            }
+        }
+    }
+    /* INTEGRATE: every rank its own ACTIVE bodies */
+    for (uint32_t r = 0; r < world && rc == 0; r++) {
+        const mapn_oracle_sym_shape *sh = &shapes[r];
+        for (uint32_t il = 0; il < ac[r]; il++) {
+            const uint32_t la = il / SYM_IB, e = il - la * SYM_IB, i = r * count + il;
+            float ax = 0.0f, ay = 0.0f, az = 0.0f;
+            for (uint32_t g = 0; g < G; g++) {
+                const uint32_t s0 = (uint32_t)(((uint64_t)sh->parts * g) / G), s1 = (uint32_t)(((uint64_t)sh->parts * (g + 1u)) / G);
+                float px = 0.0f, py = 0.0f, pz = 0.0f;
+                for (uint32_t s = s0; s < s1; s++) {
+                    const float *row = arows[r] + ((size_t)la * sh->parts + s) * 3u * SYM_IB + e;
+                    px = px + row[0]; py = py + row[SYM_IB]; pz = pz + row[2u * SYM_IB];
+                }
+                ax = ax + px; ay = ay + py; az = az + pz;
+            }
+            for (uint32_t k = 0; k < SHARD_MAX_RANKS; k++) {
+                float rx = 0.0f, ry = 0.0f, rz = 0.0f;
+                if (k < world) {
+                    const uint32_t q = r >= k ? r - k : r + world - k;
+                    if (sends[q][r]) {
+                        const float *src = recv + (((size_t)r * world + q) * count + il) * 3u;
+                        rx = src[0]; ry = src[1]; rz = src[2];
+                    }
+                }
+                ax = ax + rx; ay = ay + ry; az = az + rz;
+            }
+            integrate_fused(old_pos + 4 * (size_t)i, old_vel + 3 * (size_t)i, ax * p->mass, ay * p->mass, az * p->mass, p,
+                            new_pos + 4 * (size_t)i, new_vel + 3 * (size_t)i);
+        }
+    }
+    for (uint32_t r = 0; r < world; r++) free(arows ? arows[r] : NULL);
+    free(arows); free(recv); free(brow); free(brow1); free(facc);
     return rc;
 }

@@ -10,14 +10,15 @@ from oracle import Oracle, OracleSim, OracleSim64, Params, SumSpec, SUM_FP64_ACC
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+threads = int(sys.argv[3]) if len(sys.argv) > 3 else 0                     # 0: all hardware threads
 o = Oracle()
 pos, vel = o.initial_state(n, seed=1)
 prm = Params(mass=70000.0 / n)
-legs = {"ref": lambda: OracleSim(o, pos, vel, params=prm),
-        "acc64": lambda: OracleSim(o, pos, vel, params=prm, sum_spec=SumSpec(SUM_FP64_ACC)),
-        "matched(8x8)": lambda: OracleSim(o, pos, vel, params=prm, sum_spec=SumSpec(SUM_ORDER_MATCHED, 8, 8)),
-        "f64": lambda: OracleSim64(o, pos, vel, params=prm)}
-print(f"{n} bodies, {o.hardware_threads()} threads, {steps} steps per leg (after one warm-up step)")
+legs = {"ref": lambda: OracleSim(o, pos, vel, params=prm, threads=threads),
+        "acc64": lambda: OracleSim(o, pos, vel, params=prm, sum_spec=SumSpec(SUM_FP64_ACC), threads=threads),
+        "matched(8x8)": lambda: OracleSim(o, pos, vel, params=prm, sum_spec=SumSpec(SUM_ORDER_MATCHED, 8, 8), threads=threads),
+        "f64": lambda: OracleSim64(o, pos, vel, params=prm, threads=threads)}
+print(f"{n} bodies, {threads or o.hardware_threads()} of {o.hardware_threads()} threads, {steps} steps per leg (after one warm-up step)")
 for name, make in legs.items():
     sim = make()
     sim.simulate(steps=1)

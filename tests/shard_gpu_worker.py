@@ -176,11 +176,34 @@ def main():
             c.Simulate(num_active if not (mixed and k % 3 == 1) else num_active // 2 + 100, c.GetFenceValue())
         c.WaitForGpu()
         assert c.p2p_status() == 0, f"p2p wait timed out: status {c.p2p_status()}"
+        # a PARTIALLY ACTIVE step of the sharded symmetric forms takes the split form (round 6) where mapn_shard_split_describe says so
+        split_form = False
+        if mode in ("sym", "sympush") and count % 1024 == 0 and num_active < n and not os.environ.get("MAPN_SHARD_PARTIAL_FORM"):
+            from mapn.compute import describe_shard_split
+            split_form = bool(describe_shard_split(n, rank, world, num_active).applies)
         if mode in ("sym", "sympush") and not mixed:
-            want = "force_sym_kernel" if (num_active == n and count % 1024 == 0) else "force_sgpr_kernel"
-            assert c.kernel_stats().kernel_name.decode() == want, c.kernel_stats().kernel_name
+            st = c.kernel_stats()
+            want = "force_sym_kernel" if ((num_active == n or split_form) and count % 1024 == 0) else "force_sgpr_kernel"
+            assert st.kernel_name.decode() == want, st.kernel_name
+            assert (st.split_active != 0) == split_form, (st.split_active, split_form)
         pos, vel = c.download_state()
         other = c.download_buffer(c.buffer_index)[0]
+        if split_form and not mixed:
+            # this rank's part of the step, for the order-matched restatement (oracle: ORDER_MATCHED_SHARDED_SPLIT) -- and what the device-less
+            # description promised must be what the context ran
+            role = describe_shard_split(n, rank, world, num_active)
+            split, pl = c.split_plan()
+            assert (split.active, split.frozen, split.frozen_first, split.has_plan) == (role.active, role.frozen_count, role.frozen_first, 1 if role.blocks else 0), (split.active, split.frozen)
+            if role.blocks:
+                assert (pl.nb, pl.a0, pl.nbl) == (role.ring_blocks, role.first_block, role.blocks), (pl.nb, pl.a0, pl.nbl)
+                np.savez(os.path.join(out_dir, f"split_rank{rank}.npz"), windows=pl.windows, tables=pl.tables, frozen=np.array([split.frozen_waves, split.frozen_sb], np.uint32),
+                         shape=np.array([pl.nb, pl.groups, pl.parts, pl.waves, pl.brows, pl.max_meetings, pl.table_stride, pl.sets, pl.a0, pl.nbl], np.uint32))
+            else:
+                np.savez(os.path.join(out_dir, f"split_rank{rank}.npz"), frozen=np.array([split.frozen_waves, split.frozen_sb], np.uint32), shape=np.zeros(10, np.uint32))
+            # the frozen bodies: untouched in BOTH buffers of this rank's replica (the seeded state put them there)
+            pos0, _ = mapn.generate_initial_state(n, seed=1)
+            a = role.active
+            assert np.array_equal(pos[a:], pos0[a:]) and np.array_equal(other[a:], pos0[a:]), f"rank {rank}: a frozen body moved"
         if mode in ("sym", "sympush") and not mixed and num_active == n and count % 1024 == 0:
             # this rank's launch plan, for the order-matched restatement of the sharded step (oracle: ORDER_MATCHED_SHARDED)
             pl = c.sym_plan()

@@ -121,11 +121,12 @@ def sym_block_class(nb: int, a: int) -> int:
     return 0 if sym_runs_half(nb, a) else 1
 
 
-def sym_shard_masks(nb: int, world: int, rank: int) -> tuple[int, int]:
+def sym_shard_masks(nb: int, world: int, rank: int, blocks_per_rank: int | None = None) -> tuple[int, int]:
     """Gather algorithm 4 (mapn_context.cpp sym_shard_masks): bit q of `send` = this rank produces
     reactions for bodies of rank q, bit q of `recv` = rank q produces reactions for this rank's bodies;
-    blocks are owned in contiguous runs of nb // world."""
-    nbl = nb // world
+    blocks are owned in contiguous runs of nb // world (blocks_per_rank: the ring of the ACTIVE blocks of a partially active
+    step -- nb of them, still owned in runs of a rank's slice, so the last ranks may own none)."""
+    nbl = blocks_per_rank if blocks_per_rank is not None else nb // world
     send = recv = 0
     for a, b, d, symmetric in sym_meetings(nb):
         if not symmetric:

@@ -53,9 +53,9 @@ def test_the_two_headers_split_the_boundary_from_the_tuning_surface():
               "mapn_adopt_position_buffers", "mapn_reset_from_async", "mapn_last_step_seconds", "mapn_comm_init", "mapn_set_gather_algorithm"):
         assert n in core, n
     for n in ("mapn_get_sym_plan", "mapn_set_sym_plan", "mapn_sym_plan_describe", "mapn_get_split_plan", "mapn_calibrate_sym_xcds", "mapn_set_sym_xcd_weights",
-              "mapn_get_kernel_stats", "mapn_set_force_plan", "mapn_measure_clock", "mapn_set_timers", "mapn_shard_describe", "mapn_tuning_abi_version"):
+              "mapn_get_kernel_stats", "mapn_set_force_plan", "mapn_measure_clock", "mapn_set_timers", "mapn_shard_describe", "mapn_shard_split_describe", "mapn_tuning_abi_version"):
         assert n in tuning, n
-    assert len(tuning) == 15 and len(core) == 52, (len(tuning), len(core))
+    assert len(tuning) == 16 and len(core) == 52, (len(tuning), len(core))
     shim = open(os.path.join(ROOT, "multi-adapter-particles_amd", "compat", "Compute.hpp")).read()
     assert '#include "mapn.h"' in shim and "mapn_tuning.h" not in shim
     used = set(re.findall(r"\b(mapn_[a-z_0-9]+)\s*\(", shim))

@@ -131,3 +131,71 @@ def test_two_rank_gloo_sharded_steps_equal_single_rank(tmp_path, oracle, num_act
     np.testing.assert_array_equal(got["other"], sim.pos[sim.buffer_index])
     na = active_bodies(num_active, n)
     np.testing.assert_array_equal(got["vel"][:na], sim.latest[1][:na])
+
+
+def _split_roles(n, world, num_active):
+    from mapn.compute import describe_shard_split
+    return [describe_shard_split(n, r, world, num_active) for r in range(world)]
+
+
+def test_partially_active_sharded_step_roles_tile_the_job_and_the_masks_mirror_each_other():
+    """mapn_shard_split_describe (product, no device): the active bodies form a ring of their own whose blocks are dealt to their owners in
+    order; every frozen body is owned -- and its force computed -- by exactly one rank; the masks are each other's mirror and hold exactly
+    (a) the ring's meetings between the ranks' blocks and (b) frozen owner -> active owner."""
+    import shard_model as shard
+    for n, world, na in [(65536, 8, 32768), (65536, 8, 40960), (65536, 8, 33000), (65536, 4, 20000), (8192, 2, 4096), (8192, 4, 5120), (8192, 4, 5000),
+                         (16384, 8, 2048), (16384, 8, 16320), (9216, 3, 4096), (65536, 2, 32768), (1048576, 8, 524288 + 64)]:
+        roles = _split_roles(n, world, na)
+        A, count, cblk = active_bodies(na, n), n // world, n // world // 1024
+        assert all(r.applies == 1 and r.active == A for r in roles), (n, world, na)
+        nba = (A + 1023) // 1024
+        assert all(r.ring_blocks == nba for r in roles)
+        # the ring's blocks, in order, without gaps; the active bodies likewise
+        blocks = [b for r in roles for b in range(r.first_block, r.first_block + r.blocks)]
+        assert blocks == list(range(nba)), (n, world, na, blocks)
+        assert sum(r.active_count for r in roles) == A and sum(r.frozen_count for r in roles) == n - A
+        for q, r in enumerate(roles):
+            assert r.first_block == q * cblk and r.blocks == (r.active_count + 1023) // 1024
+            assert r.active_count == ShardPlan(n, q, world).active_slice(na)[1]
+            assert r.frozen_first == q * count + r.active_count and r.frozen_first + r.frozen_count == (q + 1) * count
+        for a, ra in enumerate(roles):
+            for b, rb in enumerate(roles):
+                assert ((ra.send_mask >> b) & 1) == ((rb.recv_mask >> a) & 1), (n, world, na, a, b)
+                ring_send, _ = shard.sym_shard_masks(nba, world, a, blocks_per_rank=cblk) if nba else (0, 0)
+                want = bool((ring_send >> b) & 1) or (ra.frozen_count > 0 and rb.active_count > 0)
+                assert bool((ra.send_mask >> b) & 1) == want, (n, world, na, a, b)
+    # where the form does not apply: all bodies active, a handful, nothing
+    for na in (65536, 70000, 1024, 64, 0):
+        assert all(r.applies == 0 for r in _split_roles(65536, 8, na))
+    with pytest.raises(mapn.MapnError):
+        _split_roles(6144, 4, 3000)                              # a rank's slice must be whole blocks
+
+
+@pytest.mark.parametrize("n,world,num_active", [(8192, 4, 5120), (8192, 4, 4500), (8192, 2, 4096), (12288, 3, 7168), (16384, 8, 9216)])
+def test_sharded_split_restatement_follows_the_reference_order_oracle(oracle, n, world, num_active):
+    """The order-matched restatement of the PARTIALLY ACTIVE sharded step (oracle: ORDER_MATCHED_SHARDED_SPLIT), driven entirely by what the
+    PRODUCT reports without a device -- every rank's roles (mapn_shard_split_describe) and the plan of its blocks in the active ring
+    (mapn_sym_plan_describe) -- against the oracle proper: another summation order of the same pair terms, so one step agrees to rounding
+    (a row sent to the wrong rank, a frozen body counted twice or not at all, a block missing from the ring would show at 1e-3 and more),
+    and the frozen bodies come back bit for bit.  Shapes: whole ranks active + whole ranks frozen, a rank that is both, a count that is
+    not whole blocks, one block per rank."""
+    from mapn.compute import describe_sym_plan
+    from oracle import OracleSim, Params, step_sym_sharded_split
+    roles = _split_roles(n, world, num_active)
+    A = roles[0].active
+    plans, frozen = [], []
+    for r in roles:
+        plans.append(describe_sym_plan(r.ring_blocks, parts=8, waves=4, launch_blocks=r.blocks, launch_a0=r.first_block) if r.blocks else None)
+        frozen.append((4, 2) if r.frozen_count else None)
+    pos, vel = oracle.initial_state(n, seed=3)
+    prm = Params(mass=70000.0 / n)
+    p, v = step_sym_sharded_split(oracle, pos, vel, prm, A, plans, frozen)
+    sim = OracleSim(oracle, pos, vel, params=prm); sim.simulate(num_active=num_active)
+    rp, rv = sim.latest
+    rel = np.linalg.norm(p[:A, :3].astype(np.float64) - rp[:A, :3], axis=1) / 400.0
+    assert rel.max() < 1e-6, rel.max()
+    assert np.linalg.norm(v[:A].astype(np.float64) - rv[:A], axis=1).max() / 15.0 < 2e-5
+    np.testing.assert_array_equal(p[A:], pos[A:]); np.testing.assert_array_equal(v[A:], vel[A:])
+    # ... and the force on an active body does not depend on how the frozen bodies' work is cut (another launch shape: same sum to rounding)
+    p2, _ = step_sym_sharded_split(oracle, pos, vel, prm, A, plans, [(8, 1) if f else None for f in frozen])
+    assert np.linalg.norm(p2[:A, :3].astype(np.float64) - rp[:A, :3], axis=1).max() / 400.0 < 1e-6

@@ -234,16 +234,65 @@ def test_exchange_launch_is_sized_for_the_compute_units_the_process_really_gets(
 
 
 def test_symmetric_sharded_step_falls_back_bit_identically(tmp_path):
-    """Where the sharded symmetric step does not apply (some bodies frozen; a slice that is not whole
-    1024-body blocks) algorithm 4 runs the step exactly as algorithm 2 does."""
+    """Where the sharded symmetric step does not apply (a handful of active bodies; a slice that is not whole 1024-body blocks; a partially
+    active step with the A/B hook that selects rounds 1 - 5's form) algorithm 4 runs the step exactly as algorithm 2 does."""
     import os as _os
-    for tag, world, n, active in (("frozen", 2, 8192, 5000), ("ragged", 4, 6144, 6144)):
+    for tag, world, n, active, env in (("few", 2, 8192, 1500, None), ("ragged", 4, 6144, 6144, None), ("hook", 2, 8192, 5000, {"MAPN_TEST_HOOKS": "1", "MAPN_SHARD_PARTIAL_FORM": "one"})):
         d2, d4 = tmp_path / (tag + "_p2p"), tmp_path / (tag + "_sym")
         _os.makedirs(d2); _os.makedirs(d4)
         a = _run_ranks(d2, world, n, 4, "p2p", str(active))
-        b = _run_ranks(d4, world, n, 4, "sym", str(active))
+        b = _run_ranks(d4, world, n, 4, "sym", str(active), env=env)
         for k in ("pos", "vel", "other"):
             np.testing.assert_array_equal(a[k], b[k])
+
+
+def _rank_split_plans(tmp_path, world):
+    import types
+    plans, frozen = [], []
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"split_rank{r}.npz"))
+        nb, groups, parts, waves, brows, max_meetings, table_stride, sets, a0, nbl = (int(x) for x in d["shape"])
+        plans.append(types.SimpleNamespace(nb=nb, groups=groups, parts=parts, waves=waves, brows=brows, max_meetings=max_meetings, table_stride=table_stride,
+                                           sets=sets, windows=d["windows"], tables=d["tables"]) if nbl else None)
+        fw, fs = (int(x) for x in d["frozen"])
+        frozen.append((fw, fs) if fw else None)
+    return plans, frozen
+
+
+@pytest.mark.parametrize("mode,world,n,num_active", [("sympush", 8, 65536, 32768), ("sym", 4, 65536, 40960), ("sympush", 2, 65536, 32768), ("sympush", 4, 8192, 5000),
+                                                      ("sym", 8, 16384, 9216), ("sympush", 3, 9216, 4096), ("sympush", 8, 65536, 40960 + 64)])
+def test_partially_active_sharded_step_against_the_oracle_and_its_order_matched_restatement(tmp_path, oracle, mode, world, n, num_active):
+    """num_active < N on P ranks (Particles.cpp:391-394's slider, Compute.cpp:1041) under gather algorithms 4 / 5 -- until
+    round 5 the one-sided kernel over (a rank's active bodies) x N plus a pull.  Now the active bodies form a ring of their own whose
+    blocks their owners run under the symmetric kernel, and the ranks that own FROZEN bodies compute what those do to every active body
+    (one one-sided launch each) and send the sums in the same rows as the reactions.  `world` real processes on one GPU: whole ranks
+    active + whole ranks frozen (N / 2 and 5 N / 8 of 65 536 over 8, 4 and 2), a rank that is both, a count that is not whole blocks, a
+    world that does not divide 8.  Free-running for two steps: against the oracle proper by tolerance; against the step's ORDER-MATCHED
+    restatement (every rank's plan and frozen launch as it dumped them) bit for bit but for v_rsq_f32; the frozen bodies untouched in both
+    buffers of every rank's replica and all replicas identical (checked in the workers)."""
+    from oracle import OracleSim, Params, step_sym_sharded_split
+    steps = 2
+    got = _run_ranks(tmp_path, world, n, steps, mode, str(num_active))
+    A = oracle.active_bodies(num_active, n)
+    pos0, vel0 = oracle.initial_state(n, seed=1)
+    prm = Params(mass=70000.0 / n)
+    sim = OracleSim(oracle, pos0, vel0, params=prm)
+    sim.simulate(num_active=num_active, steps=steps)
+    dx = np.linalg.norm(got["pos"][:A, :3].astype(np.float64) - sim.latest[0][:A, :3], axis=1).max() / 400.0
+    dv = np.linalg.norm(got["vel"][:A].astype(np.float64) - sim.latest[1][:A], axis=1).max() / 15.0
+    assert dx < 3e-6 and dv < 6e-5, (dx, dv)
+    np.testing.assert_array_equal(got["pos"][A:], pos0[A:]); np.testing.assert_array_equal(got["other"][A:], pos0[A:])
+    plans, frozen = _rank_split_plans(tmp_path, world)
+    pos, vel = pos0, vel0
+    for _ in range(steps):
+        pos, vel = step_sym_sharded_split(oracle, pos, vel, prm, A, plans, frozen)
+    p = got["pos"]
+    rel = np.linalg.norm(p[:A, :3].astype(np.float64) - pos[:A, :3], axis=1) / np.maximum(np.linalg.norm(pos[:A, :3].astype(np.float64), axis=1), 1e-30)
+    same = float((p[:A, :3] == pos[:A, :3]).all(axis=1).mean())
+    shapes = [f"{pl.waves}x{pl.parts}" if pl else "-" for pl in plans]
+    print(f"{mode} world={world} n={n} active={A}: plans {shapes}, frozen launches {frozen}: vs the order-matched restatement after {steps} steps: max rel {rel.max():.2e}, bit-identical bodies {same:.5f}")
+    assert rel.max() <= 3e-7 and same >= 0.999
+    assert np.linalg.norm(got["vel"][:A].astype(np.float64) - vel[:A], axis=1).max() / 15.0 < 1e-6
 
 
 def test_config3_sharded_symmetric_step_with_eight_processes(tmp_path, oracle):

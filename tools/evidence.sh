@@ -11,6 +11,8 @@
 #   ab <other-tree>              same-box A/B of another checkout (e.g. ab/old: `git archive <rev> | tar -x -C ab/old && make -C ...`)
 #   timeline N WORLD RANK ALGO   per-wave timeline of one sharded symmetric force launch in loopback (tools/shard_timeline.py)
 #   shardstep [N WORLD [TREE]]   kernel trace of the loopback step, ranks 0 and WORLD/2, algorithms 4 and 5: durations, gaps, period
+#   shardpartial [N WORLD]       the same for PARTIALLY ACTIVE steps (num_active = N/2, 5N/8): the split form (algorithm 5) on an active and on a frozen
+#                                rank against algorithm 2's step (one-sided kernel over the rank's active bodies x N + pull) -> shard_partial_timeline.txt
 #   loopback [N]                 rank 0's compute per step at the shard size, one-sided against symmetric, WORLD = 2, 4, 8
 #   sizes                        symmetric against one-sided kernel at 65 536 ... 4 194 304 bodies
 #   parity1000                   tests/parity_report.py at 65 536 bodies, 1000 steps, all legs -> JSON
@@ -170,6 +172,54 @@ for algo in (5, 4, 2, 6, 0, 10):
         starts = starts[::per]
         d = [b - a for a, b in zip(starts, starts[1:])]
         print("  step period %.2f us  (mean %.2f)" % (med(d) / 1e3, sum(d) / len(d) / 1e3))
+PY
+  ;;
+shardpartial)
+  n=${1:-65536}; world=${2:-8}; rm -rf $O/trace_*; cd /tmp
+  cat > /tmp/loopstep_partial.py <<'PY'
+import os, sys
+os.environ["MAPN_TEST_HOOKS"] = "1"; os.environ["MAPN_P2P_LOOPBACK"] = "1"
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+import mapn
+n, world, algo, rank, na = (int(x) for x in sys.argv[1:6])
+with mapn.Compute(n, device=0, mass=70000.0 / n, rank=rank, world_size=world) as c:
+    blob = c.p2p_export(); c.p2p_import([blob] * world); c.set_gather_algorithm(algo); c.set_timers(0)
+    for _ in range(2000):
+        c.Simulate(na, c.GetFenceValue())
+    c.WaitForGpu()
+    print("split_active", c.kernel_stats().split_active, c.kernel_stats().kernel_name.decode())
+PY
+  for na in $((n / 2)) $((n * 5 / 8)); do for cfg in "5 0" "5 $((world - 1))" "2 0"; do
+    set -- $cfg; algo=$1; rank=$2
+    rocprofv3 --kernel-trace --output-format csv -d $O/trace_${na}_${algo}_$rank -- python3 /tmp/loopstep_partial.py $n $world $algo $rank $na > $O/trace_${na}_${algo}_$rank.out 2> $O/trace_${na}_${algo}_$rank.err
+  done; done
+  cd $R; python - "$O" $n $world <<'PY' | tee $O/shard_partial_timeline.txt
+import csv, glob, collections, sys
+O, n, world = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+print(f"# PARTIALLY ACTIVE steps of the {n}-body job over {world} ranks, one rank at a time in loopback (every peer mapped to the rank itself): rocprofv3 --kernel-trace,")
+print("# second half of 2000 steps, MEDIAN (mean) durations and gaps.  Algorithm 5 = the split form (round 6): an ACTIVE rank runs its blocks of the active ring under the symmetric")
+print("# kernel, a FROZEN rank the one-sided launch over active x (its frozen bodies); both run the exchange launch.  Algorithm 2 = rounds 1 - 5's step: the one-sided kernel over")
+print("# (the rank's active bodies) x N (the pull launch is skipped in loopback).  The JOB's step is its slowest rank's.")
+for na in (n // 2, n * 5 // 8):
+    periods = {}
+    for algo, rank, what in ((5, 0, "split form, rank 0 (all its bodies active)"), (5, world - 1, f"split form, rank {world - 1} (all its bodies frozen)"), (2, 0, "algorithm 2, rank 0")):
+        f = glob.glob(f"{O}/trace_{na}_{algo}_{rank}/**/*kernel_trace.csv", recursive=True)
+        if not f: continue
+        rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Start_Timestamp"]))
+        rows = rows[len(rows) // 2:]
+        dur = collections.defaultdict(list)
+        for a in rows: dur[a["Kernel_Name"].split("(")[0][-40:]].append(int(a["End_Timestamp"]) - int(a["Start_Timestamp"]))
+        med = lambda v: sorted(v)[len(v) // 2]
+        print(f"== num_active {na}: {what}")
+        for k, v in dur.items(): print("  %-48s %7.2f us  (mean %.2f, x%d)" % (k, med(v) / 1e3, sum(v) / len(v) / 1e3, len(v)))
+        top = collections.Counter(r["Kernel_Name"] for r in rows if "force" in r["Kernel_Name"]).most_common(1)[0][0]
+        starts = [int(r["Start_Timestamp"]) for r in rows if r["Kernel_Name"] == top]
+        d = [b - a for a, b in zip(starts, starts[1:])]
+        periods[(algo, rank)] = med(d) / 1e3
+        print("  step period %.2f us  (mean %.2f)" % (med(d) / 1e3, sum(d) / len(d) / 1e3))
+    if (5, 0) in periods and (5, world - 1) in periods and (2, 0) in periods:
+        job = max(periods[(5, 0)], periods[(5, world - 1)])
+        print(f"## num_active {na}: the job's step in the split form = max({periods[(5, 0)]:.2f}, {periods[(5, world - 1)]:.2f}) = {job:.2f} us against {periods[(2, 0)]:.2f} us for algorithm 2: {periods[(2, 0)] / job:.3f} x")
 PY
   ;;
 loopback)

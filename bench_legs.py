@@ -24,7 +24,18 @@ def cpu_baseline(n, seed, target_seconds):
     k = min(n, 256 * cores)
     t0 = time.perf_counter(); o.step_slice(pos, vel, 0, k, params=prm); t = time.perf_counter() - t0
     if (k * n / t) * target_seconds >= 2.0 * n * n:    # a whole step fits the budget comfortably
-        sim = OracleSim(o, pos, vel, params=prm)
+        # the thread count the port runs FASTEST at on this host (round 6): it spawns its workers anew every step and stops scaling well
+        # before 256 threads (2 x EPYC 9575F, 65 536 bodies: 30 ms per step on 64 threads, 47 on 128, 42 on 256) -- the baseline is the
+        # best of all / half / a quarter of the hardware threads, and `cores` says which
+        best = None
+        for th in sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True):
+            trial = OracleSim(o, pos, vel, params=prm, threads=th)
+            trial.simulate(steps=1)
+            t0 = time.perf_counter(); trial.simulate(steps=2); dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, th)
+        cores = best[1]
+        sim = OracleSim(o, pos, vel, params=prm, threads=cores)
         sim.simulate(steps=1)                          # warm up threads / caches
         # time-bounded, not count-bounded: a two-step calibration underestimated the steady step time 3x
         # on the 256-thread box (965 steps, 39.8 s for a 12 s target)

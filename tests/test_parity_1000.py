@@ -30,7 +30,8 @@ csrc/mapn_sym.hip) and "device1s" = the one-sided scalar-cache kernel whose summ
 "device_weighted": the symmetric kernel under an XCD-WEIGHTED launch plan (fixed lopsided die weights, class-aware), the kind of
 plan bench.py's headline number runs (until round 4 only the unweighted plan went through the long legs).
 
-The oracle legs take ~4 minutes on the GPU box's host cores (ref 42 s, matched 37 s, acc64 122 s, f64 to 100 steps 43 s).
+The oracle legs take ~4.5 minutes on the GPU box's host cores (per 1000 steps: ref 42 s, acc64 131 s, matched_sym ~40 s; to 100 steps: f64 46 s,
+matched and matched_symw 4 s each -- tests/oracle_leg_times.py measures them).
 """
 import json
 import os
@@ -47,7 +48,9 @@ def report():
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from parity_report import run_report
-    rep = run_report(65536, (1, 10, 100, 1000), f64_max_steps=100, log=lambda s: print(s, flush=True))
+    # (the order-matched legs of the one-sided kernel and of the weighted plan stop at 100 steps since round 6 -- the default kernel's runs all
+    #  1000: profiles/r05_parity_1000_65536_all_legs.json holds their 1000-step rows, tests/parity_report.py as a script reproduces them)
+    rep = run_report(65536, (1, 10, 100, 1000), f64_max_steps=100, matched_max_steps=100, log=lambda s: print(s, flush=True))
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         json.dump(rep, open(os.path.join(out, "parity_1000_65536.json"), "w"), indent=1)
@@ -105,10 +108,13 @@ def test_t3_device_is_no_farther_from_the_yardsticks_than_the_oracle_is(report, 
 
 @pytest.mark.parametrize("leg,yardstick", [("device1s", "matched"), ("device", "matched_sym"), ("device_weighted", "matched_symw")])
 def test_t4_device_vs_order_matched_oracle_differs_by_rsq_only(report, leg, yardstick):
-    r1, r100, r1000 = (_row(report, s, leg, yardstick) for s in (1, 100, 1000))
-    print(leg, "vs", yardstick, ":", r1, r100, r1000, report.get("device_sym_plan"))
+    r1, r100 = (_row(report, s, leg, yardstick) for s in (1, 100))
+    print(leg, "vs", yardstick, ":", r1, r100, report.get("device_sym_plan"))
     assert r1["max"] <= 1.3e-7                 # one step: <= 1 ulp of the position
     assert r100["max"] <= 1e-6 and r100["median"] <= 3e-8
-    assert r1000["median"] <= 5e-6 and r1000["rms"] <= 3e-5
-    d_ref = _row(report, 1000, leg, "ref")
-    assert r1000["median"] <= d_ref["median"]   # tighter than against the reference-order oracle
+    assert r100["median"] <= _row(report, 100, leg, "ref")["median"]   # tighter than against the reference-order oracle
+    if yardstick == "matched_sym":             # the default kernel's restatement runs all 1000 steps (the other two stop at 100: see the fixture)
+        r1000 = _row(report, 1000, leg, yardstick)
+        print(leg, "vs", yardstick, "@1000:", r1000)
+        assert r1000["median"] <= 5e-6 and r1000["rms"] <= 3e-5
+        assert r1000["median"] <= _row(report, 1000, leg, "ref")["median"]

@@ -44,7 +44,7 @@ def _run_ranks(tmp_path, world, n, steps, *extra, env=None):
     return np.load(os.path.join(str(tmp_path), "gpu_sharded.npz"))
 
 
-@pytest.mark.parametrize("world,num_active", [(2, 4096), (4, 4096), (8, 4096), (4, 2500), (8, 700)])
+@pytest.mark.parametrize("world,num_active", [(2, 4096), (8, 4096), (4, 2500), (8, 700)])
 def test_flow_mode_exchange_inside_the_force_launch(tmp_path, oracle, world, num_active):
     """Gather algorithm 3 (VERDICT r1 #3b): no exchange step at all -- the pull kernel runs beside the
     force launch on the comm stream, the launch starts on its own slice (block rows rotated), its
@@ -69,7 +69,7 @@ def test_flow_mode_exchange_inside_the_force_launch(tmp_path, oracle, world, num
     assert dx < 8e-6, dx
 
 
-@pytest.mark.parametrize("world,num_active", [(2, 4096), (4, 4096), (8, 4096), (4, 2500)])
+@pytest.mark.parametrize("world,num_active", [(2, 4096), (8, 4096), (4, 2500)])
 def test_direct_p2p_exchange_between_processes(tmp_path, oracle, world, num_active):
     """The in-library peer-to-peer exchange (hipIpc-mapped peer buffers, device-side publish /
     wait / pull kernel) between `world` real processes, all on device 0: the free-running sharded
@@ -137,8 +137,10 @@ def test_a_rank_whose_rows_never_validate_does_not_publish_and_every_rank_report
         assert os.path.exists(os.path.join(str(tmp_path), f"row_failure_reported_by_rank{r}"))
 
 
-@pytest.mark.parametrize("mode", ["sym", "sympush"])
-@pytest.mark.parametrize("world,n", [(2, 8192), (4, 8192), (8, 8192), (3, 9216), (2, 6144), (8, 16384)])
+# (round 6, VERDICT r5 #2: six shapes, each under ONE of the two transports -- until then every shape ran under both, twelve cases; that the two
+#  transports give the same bits is test_pushed_positions_give_the_same_bits_as_pulled_ones' statement, and the same order is re-proved
+#  bit for bit by test_sharded_symmetric_step_against_its_order_matched_oracle)
+@pytest.mark.parametrize("mode,world,n", [("sym", 2, 8192), ("sympush", 4, 8192), ("sym", 8, 8192), ("sympush", 3, 9216), ("sym", 2, 6144), ("sympush", 2, 6144), ("sympush", 8, 16384)])
 def test_symmetric_step_sharded_over_processes(tmp_path, oracle, world, n, mode):
     """Gather algorithm 4: every unordered pair of the whole job evaluated once.  Each rank runs the
     meetings of its own 1024-body blocks, stores the reactions it produced for every rank's bodies (summed
@@ -159,8 +161,8 @@ def test_symmetric_step_sharded_over_processes(tmp_path, oracle, world, n, mode)
     assert dx < 8e-6 and dv < 1e-4, (dx, dv)
 
 
-@pytest.mark.parametrize("mode,world,n,xcd_w", [("sympush", 2, 8192, None), ("sym", 4, 8192, None), ("sympush", 8, 16384, None), ("sympush", 3, 9216, None), ("sympush", 2, 65536, None),
-                                               ("sympush", 2, 16384, "1024,900,1000,950,1024,880,990,1010"), ("sym", 4, 65536, "1024,900,1000,950,1024,880,990,1010")])
+@pytest.mark.parametrize("mode,world,n,xcd_w", [("sym", 4, 8192, None), ("sympush", 8, 16384, None), ("sympush", 3, 9216, None), ("sympush", 2, 65536, None),
+                                               ("sym", 4, 65536, "1024,900,1000,950,1024,880,990,1010")])
 def test_sharded_symmetric_step_against_its_order_matched_oracle(tmp_path, oracle, mode, world, n, xcd_w):
     """The sharded symmetric step's summation order restated on the CPU from the plans the RANKS report (every rank dumps
     mapn_get_sym_plan): each rank's force rows, the reactions summed per destination over the sender's blocks, the receiver's G partial

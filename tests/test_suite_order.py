@@ -27,3 +27,20 @@ def test_parity_tests_are_collected_before_every_timing_asserting_test():
     for i in ids:
         if "faster_than" in i or "wins_its_a_b" in i or i.split("::")[0].endswith(("test_bench_contract.py", "test_gpu_mfma_ab.py")):
             assert i in timing, i
+
+
+def test_the_last_recorded_gpu_suite_ran_in_well_under_its_time_limit():
+    """`pytest -m gpu` is killed at 1200 s, and a kill is a red round whatever the tests say; the suite had grown 30 -> 349 ->
+    461 -> 480 -> 686 s.  The latest `pytest -m gpu --durations` record committed under profiles/ (one per round from round 6 on, made on
+    the GPU box by tools/evidence.sh suite full) must show a total of at most 600 s -- whoever adds a minute of tests sees it here, on the
+    CPU, before the driver's box does -- and must be a record of a green run."""
+    import glob
+    import re
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pytest_gpu_durations.txt")))
+    assert recs, "no profiles/rNN_pytest_gpu_durations.txt on record"
+    text = open(recs[-1]).read()
+    m = re.findall(r"(\d+) passed(?:, (\d+) skipped)?(?:, \d+ deselected)? in ([0-9.]+)s", text)
+    assert m and " failed" not in text.splitlines()[-1], (recs[-1], text.splitlines()[-1:])
+    passed, total = int(m[-1][0]), float(m[-1][2])
+    assert passed >= 230 and total <= 600.0, f"{recs[-1]}: {passed} passed in {total:.0f} s (limit of this check 600 s; the driver's 1200 s)"
+    assert "slowest" in text           # (the --durations table is part of the record: it says where the time goes)

@@ -49,16 +49,6 @@
 #define MAPN_ORACLE_BLOCK 64 /* defines.h:37 BLOCK_SIZE */
 #define IB 16                /* i-bodies per vector block */
 
-/* Run fn(jobs + t * stride) for t = 0 .. n - 1, one job per worker, and wait for all of them.  The workers are OpenMP's persistent team
- * (round 6): until then every step created and joined its own pthreads -- 256 of them per step on the GPU box's host, which cost more than
- * the step's arithmetic (65 536 bodies: 42 ms per step on 256 threads against 30 ms on 64; five legs side by side slowed each other sixfold
- * on the process's mmap lock).  Every job carries its own (tid, nthreads), so the results do not depend on how the runtime deals them out. */
-static void spawn_join(void *(*fn)(void *), void *jobs, size_t stride, int n)
-{
-#pragma omp parallel for schedule(static, 1) num_threads(n)
-    for (int t = 0; t < n; t++) fn((char *)jobs + (size_t)t * stride);
-}
-
 typedef struct {
     float mass;     /* nBodyGravityCS.hlsl:38 g_fParticleMass (default 70000) */
     float soft2;    /* nBodyGravityCS.hlsl:37 softeningSquared (default 25)  */
@@ -245,12 +235,21 @@ int mapn_oracle_step_all_pairs(const float *old_pos, const float *old_vel, float
     uint32_t nblocks = (count + IB - 1) / IB;
     if ((uint32_t)threads > nblocks) threads = nblocks ? (int)nblocks : 1;
     ap_job *jobs = (ap_job *)calloc((size_t)threads, sizeof(ap_job));
-    if (!jobs) return -1;
-    for (int t = 0; t < threads; t++)
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); return -1; }
+    for (int t = 0; t < threads; t++) {
         jobs[t] = (ap_job){old_pos, old_vel, new_pos, new_vel, n_total, first, count, p,
                            (uint32_t)t, (uint32_t)threads};
-    spawn_join(all_pairs_worker, jobs, sizeof(ap_job), threads);
+        if (t > 0 && pthread_create(&th[t], NULL, all_pairs_worker, &jobs[t]) != 0) {
+            all_pairs_worker(&jobs[t]);
+            th[t] = 0;
+        }
+    }
+    all_pairs_worker(&jobs[0]);
+    for (int t = 1; t < threads; t++)
+        if (th[t]) pthread_join(th[t], NULL);
     free(jobs);
+    free(th);
     return 0;
 }
 
@@ -416,13 +415,21 @@ int mapn_oracle_step_all_pairs_ex(const float *old_pos, const float *old_vel, fl
     uint32_t nblocks = (count + IB - 1) / IB;
     if ((uint32_t)threads > nblocks) threads = nblocks ? (int)nblocks : 1;
     apx_job *jobs = (apx_job *)calloc((size_t)threads, sizeof(apx_job));
-    if (!jobs) return -1;
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); return -1; }
     for (int t = 0; t < threads; t++) {
         jobs[t].base = (ap_job){old_pos, old_vel, new_pos, new_vel, n_total, first, count, p, (uint32_t)t, (uint32_t)threads};
         jobs[t].spec = sp;
+        if (t > 0 && pthread_create(&th[t], NULL, all_pairs_worker_ex, &jobs[t]) != 0) {
+            all_pairs_worker_ex(&jobs[t]);
+            th[t] = 0;
+        }
     }
-    spawn_join(all_pairs_worker_ex, jobs, sizeof(apx_job), threads);
+    all_pairs_worker_ex(&jobs[0]);
+    for (int t = 1; t < threads; t++)
+        if (th[t]) pthread_join(th[t], NULL);
     free(jobs);
+    free(th);
     return 0;
 }
 
@@ -492,12 +499,21 @@ int mapn_oracle_step_all_pairs_f64(const double *old_pos, const double *old_vel,
     uint32_t nblocks = (count + IB64 - 1) / IB64;
     if ((uint32_t)threads > nblocks) threads = nblocks ? (int)nblocks : 1;
     ap64_job *jobs = (ap64_job *)calloc((size_t)threads, sizeof(ap64_job));
-    if (!jobs) return -1;
-    for (int t = 0; t < threads; t++)
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); return -1; }
+    for (int t = 0; t < threads; t++) {
         jobs[t] = (ap64_job){old_pos, old_vel, new_pos, new_vel, n_total, first, count,
                              (double)p->mass, (double)p->soft2, (double)p->dt, (double)p->damping, (uint32_t)t, (uint32_t)threads};
-    spawn_join(all_pairs_worker_f64, jobs, sizeof(ap64_job), threads);
+        if (t > 0 && pthread_create(&th[t], NULL, all_pairs_worker_f64, &jobs[t]) != 0) {
+            all_pairs_worker_f64(&jobs[t]);
+            th[t] = 0;
+        }
+    }
+    all_pairs_worker_f64(&jobs[0]);
+    for (int t = 1; t < threads; t++)
+        if (th[t]) pthread_join(th[t], NULL);
     free(jobs);
+    free(th);
     return 0;
 }
 
@@ -944,13 +960,16 @@ static void *sym_reduce_worker(void *arg)
 static int sym_run(void *(*fn)(void *), sym_job *proto, int threads)
 {
     sym_job *jobs = (sym_job *)calloc((size_t)threads, sizeof(sym_job));
-    if (!jobs) return -1;
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); return -1; }
     for (int t = 0; t < threads; t++) {
         jobs[t] = *proto;
         jobs[t].tid = (uint32_t)t; jobs[t].nthreads = (uint32_t)threads;
+        if (t > 0 && pthread_create(&th[t], NULL, fn, &jobs[t]) != 0) { fn(&jobs[t]); th[t] = 0; }
     }
-    spawn_join(fn, jobs, sizeof(sym_job), threads);
-    free(jobs);
+    fn(&jobs[0]);
+    for (int t = 1; t < threads; t++) if (th[t]) pthread_join(th[t], NULL);
+    free(jobs); free(th);
     return 0;
 }
 
@@ -1076,11 +1095,17 @@ int mapn_oracle_step_all_pairs_sym_split(const float *old_pos, const float *old_
         const uint32_t nblocks = (n_active + IB - 1) / IB;
         const int ft = (uint32_t)threads > nblocks ? (int)nblocks : threads;
         frozen_job *jobs = (frozen_job *)calloc((size_t)ft, sizeof(frozen_job));
-        if (!jobs) rc = -1;
-        for (int t = 0; t < ft && rc == 0; t++)
+        pthread_t *th = (pthread_t *)calloc((size_t)ft, sizeof(pthread_t));
+        if (!jobs || !th) rc = -1;
+        for (int t = 0; t < ft && rc == 0; t++) {
             jobs[t] = (frozen_job){old_pos, n_total, n_active, frozen_waves, frozen_sb, p->soft2, acc, np, (uint32_t)t, (uint32_t)ft, n_active, n_total - n_active};
-        if (rc == 0) spawn_join(frozen_worker, jobs, sizeof(frozen_job), ft);
-        free(jobs);
+            if (t > 0 && pthread_create(&th[t], NULL, frozen_worker, &jobs[t]) != 0) { frozen_worker(&jobs[t]); th[t] = 0; }
+        }
+        if (rc == 0) {
+            frozen_worker(&jobs[0]);
+            for (int t = 1; t < ft; t++) if (th[t]) pthread_join(th[t], NULL);
+        }
+        free(jobs); free(th);
     }
     /* (2) the active bodies among themselves: the symmetric plan of a job of n_active bodies, the frozen sum as the running sum */
     for (uint32_t k = 0; k < shape->windows && rc == 0; k++) {
@@ -1285,11 +1310,15 @@ int mapn_oracle_step_all_pairs_sym_sharded_split(const float *old_pos, const flo
             const uint32_t nblocks = (n_active + IB - 1) / IB;
             const int ft = (uint32_t)threads > nblocks ? (int)nblocks : threads;
             frozen_job *jobs = (frozen_job *)calloc((size_t)ft, sizeof(frozen_job));
-            if (!jobs) { rc = -1; break; }
-            for (int t = 0; t < ft; t++)
+            pthread_t *th = (pthread_t *)calloc((size_t)ft, sizeof(pthread_t));
+            if (!jobs || !th) { free(jobs); free(th); rc = -1; break; }
+            for (int t = 0; t < ft; t++) {
                 jobs[t] = (frozen_job){old_pos, n, n_active, frozen_waves[r], frozen_sb[r], p->soft2, facc, np, (uint32_t)t, (uint32_t)ft, fz_first[r], fz_count[r]};
-            spawn_join(frozen_worker, jobs, sizeof(frozen_job), ft);
-            free(jobs);
+                if (t > 0 && pthread_create(&th[t], NULL, frozen_worker, &jobs[t]) != 0) { frozen_worker(&jobs[t]); th[t] = 0; }
+            }
+            frozen_worker(&jobs[0]);
+            for (int t = 1; t < ft; t++) if (th[t]) pthread_join(th[t], NULL);
+            free(jobs); free(th);
         }
         /* SEND: per destination q and ACTIVE body t of q */
         const uint32_t *splits = nbl[r] ? J.tab + sh->sets * (sh->parts * sh->waves + 1u) : NULL;

@@ -24,17 +24,10 @@ def cpu_baseline(n, seed, target_seconds):
     k = min(n, 256 * cores)
     t0 = time.perf_counter(); o.step_slice(pos, vel, 0, k, params=prm); t = time.perf_counter() - t0
     if (k * n / t) * target_seconds >= 2.0 * n * n:    # a whole step fits the budget comfortably
-        # the thread count the port runs FASTEST at on this host (round 6): it spawns its workers anew every step and stops scaling well
-        # before 256 threads (2 x EPYC 9575F, 65 536 bodies: 30 ms per step on 64 threads, 47 on 128, 42 on 256) -- the baseline is the
-        # best of all / half / a quarter of the hardware threads, and `cores` says which
-        best = None
-        for th in sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True):
-            trial = OracleSim(o, pos, vel, params=prm, threads=th)
-            trial.simulate(steps=1)
-            t0 = time.perf_counter(); trial.simulate(steps=2); dt = time.perf_counter() - t0
-            if best is None or dt < best[0]:
-                best = (dt, th)
-        cores = best[1]
+        # the thread count the port runs FASTEST at on this host (round 6; Oracle.best_threads): it creates and joins its workers every step and
+        # the GPU box's container does not have the 256 cores it shows (65 536 bodies: 30 ms per step on 64 threads, 47 on 128, 42 on 256) --
+        # the baseline is the best of all / half / a quarter / an eighth of the hardware threads, and `cores` says which
+        cores = o.best_threads()
         sim = OracleSim(o, pos, vel, params=prm, threads=cores)
         sim.simulate(steps=1)                          # warm up threads / caches
         # time-bounded, not count-bounded: a two-step calibration underestimated the steady step time 3x
@@ -61,9 +54,12 @@ def cpu_baseline(n, seed, target_seconds):
                 model = line.split(":", 1)[1].strip(); break
     except OSError:
         pass
+    quota = o.cpu_quota_cores()
     return {"value": pairs / t, "unit": "body-pair interactions/s", "cores": cores, "kind": "port",
             "sample": f"oracle (C, fp32, exact HLSL op order, vectorised over i): {what}, {cores} threads, {t:.1f} s",
-            "cpu": model}
+            "cpu": model, "hardware_threads_shown": o.hardware_threads(), "cpu_quota_cores": quota,
+            "note": "`cores` = the threads the port ran on (its fastest count on this host); `cpu_quota_cores` = the CPU time the container is granted, in cores "
+                    "(cgroup cpu.max; null: unlimited) -- on the GPU boxes 16 of the 256 hardware threads shown, which is what bounds this figure"}
 
 
 def kernel_source_sha16():

@@ -10,7 +10,7 @@ from oracle import Oracle, OracleSim, OracleSim64, Params, SumSpec, SUM_FP64_ACC
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-threads = int(sys.argv[3]) if len(sys.argv) > 3 else 0                     # 0: all hardware threads
+threads = int(sys.argv[3]) if len(sys.argv) > 3 else 0                     # 0: all hardware threads, -1: Oracle.best_threads()
 o = Oracle()
 pos, vel = o.initial_state(n, seed=1)
 prm = Params(mass=70000.0 / n)
@@ -18,7 +18,10 @@ legs = {"ref": lambda: OracleSim(o, pos, vel, params=prm, threads=threads),
         "acc64": lambda: OracleSim(o, pos, vel, params=prm, sum_spec=SumSpec(SUM_FP64_ACC), threads=threads),
         "matched(8x8)": lambda: OracleSim(o, pos, vel, params=prm, sum_spec=SumSpec(SUM_ORDER_MATCHED, 8, 8), threads=threads),
         "f64": lambda: OracleSim64(o, pos, vel, params=prm, threads=threads)}
-print(f"{n} bodies, {threads or o.hardware_threads()} of {o.hardware_threads()} threads, {steps} steps per leg (after one warm-up step)")
+if threads < 0:
+    threads = o.best_threads()
+quota = o.cpu_quota_cores()
+print(f"{n} bodies, {threads or o.hardware_threads()} of {o.hardware_threads()} threads (affinity {len(os.sched_getaffinity(0))}, cpu quota {quota} cores), {steps} steps per leg (after one warm-up step)")
 for name, make in legs.items():
     sim = make()
     sim.simulate(steps=1)

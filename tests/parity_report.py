@@ -45,9 +45,9 @@ WEIGHTED_LEG_XCD_WEIGHTS = (1024, 900, 1000, 950, 1024, 880, 990, 1010)     # re
 
 
 def run_report(n=65536, marks=(1, 10, 100, 1000), seed=1, with_f64=True, f64_max_steps=None, log=print, weighted_leg=True, matched_max_steps=None):
-    """matched_max_steps: the order-matched legs of the one-sided kernel (`matched`) and of the XCD-weighted plan (`matched_symw`) stop there
-    (None: they run all marks).  `matched_sym` -- the default kernel's -- always runs them all.  (the gpu suite's time is
-    mostly these legs; a leg costs ~40 s per 1000 steps on the GPU box's 256 threads.)"""
+    """matched_max_steps: the three ORDER-MATCHED legs (`matched`, `matched_sym`, `matched_symw`) stop there (None: they run all marks -- what
+    `tools/evidence.sh parity1000` records under profiles/ every round).  (the gpu suite's time is mostly these legs; a leg
+    costs 30 - 40 s per 1000 steps on the 16 cores the GPU box's container is granted.)"""
     import mapn
     from oracle import Oracle, OracleSim, OracleSim64, Params, SumSpec, SUM_FP64_ACC, SUM_ORDER_MATCHED
 
@@ -110,33 +110,26 @@ def run_report(n=65536, marks=(1, 10, 100, 1000), seed=1, with_f64=True, f64_max
     if with_f64:
         sims["f64"] = OracleSim64(o, pos, vel, params=prm)
     have = set()
-    # The legs run SIDE BY SIDE, each on a quarter of the host's threads (round 6): a leg spawns its workers anew every step and does
-    # not scale past ~64 threads on the GPU box (65 536 bodies, ms per step at 64 / 128 / 256 threads: ref 30 / 47 / 42, acc64 78 / 101 /
-    # 131, f64 250 / 276 / 456: tests/oracle_leg_times.py), so one after the other on all 256 they took 4.5 minutes, side by side they take
-    # as long as the longest (acc64).  The result of a leg does not depend on its thread count (bit-identical: tests/test_oracle_models.py).
-    leg_threads = max(8, o.hardware_threads() // 4)
-    for sim in sims.values():
+    # Every leg on the thread count a step runs FASTEST at on this host (round 6; Oracle.best_threads: a step creates and joins its workers,
+    # and the GPU box's container does not have the 256 cores it shows -- 65 536 bodies, ms per step at 64 / 128 / 256 threads: ref 30 / 47 /
+    # 42, acc64 78 / 101 / 131, f64 250 / 276 / 456, tests/oracle_leg_times.py; the legs side by side on a quarter of the threads each were
+    # tried and took six times as long apiece).  The result of a leg does not depend on its thread count (tests/test_oracle_models.py).
+    leg_threads = o.best_threads()
+    for name, sim in sims.items():
         sim.threads = leg_threads
-
-    def run_leg(name):
-        sim, done, t0, got = sims[name], 0, time.perf_counter(), []
+        done, t0 = 0, time.perf_counter()
         for m in marks:
             if name == "f64" and f64_max_steps is not None and m > f64_max_steps:
                 break                                          # the double leg is ~10x the fp32 legs' cost
-            if name in ("matched", "matched_symw") and matched_max_steps is not None and m > matched_max_steps:
+            if name.startswith("matched") and matched_max_steps is not None and m > matched_max_steps:
                 break
+            have.add((name, m))
             sim.simulate(steps=m - done)
             done = m
             p, v = sim.latest
-            got.append((m, p.copy(), v.copy()))
-        return name, done, time.perf_counter() - t0, got
-    from concurrent.futures import ThreadPoolExecutor          # (the oracle's C entry points release the GIL: ctypes)
-    with ThreadPoolExecutor(max_workers=len(sims)) as pool:
-        for name, done, dt, got in pool.map(run_leg, list(sims)):
-            for m, p, v in got:
-                have.add((name, m)); snaps[(name, m)] = (p, v)
-            out["timing_s"][name] = dt
-            log(f"# oracle {name}: {dt:.1f} s for {done} steps of {n} bodies on {leg_threads} of {o.hardware_threads()} threads (beside the other legs)")
+            snaps[(name, m)] = (p.copy(), v.copy())
+        out["timing_s"][name] = time.perf_counter() - t0
+        log(f"# oracle {name}: {out['timing_s'][name]:.1f} s for {done} steps of {n} bodies on {leg_threads} of {o.hardware_threads()} threads")
     pairs = [("device", "ref"), ("device", "acc64"), ("device1s", "ref"), ("device1s", "matched"), ("device1s", "acc64"),
              ("device", "device1s"), ("ref", "acc64"), ("matched", "acc64")]
     if sym_plan is not None:

@@ -379,13 +379,9 @@ def test_split_form_1000_steps_half_active_against_the_oracle_and_its_double_acc
         draw(c, steps, na)
         assert c.kernel_stats().split_active == na
         p, v = c.download_state()
-    # (the two oracle legs side by side, each on half of the host's threads: a leg does not scale past ~64 threads -- tests/parity_report.py)
-    from concurrent.futures import ThreadPoolExecutor
-    half = max(4, oracle.hardware_threads() // 2)
-    ref = OracleSim(oracle, pos, vel, params=prm, threads=half)
-    acc = OracleSim(oracle, pos, vel, params=prm, sum_spec=SumSpec(SUM_FP64_ACC), threads=half)
-    with ThreadPoolExecutor(max_workers=2) as pool:
-        list(pool.map(lambda sim: sim.simulate(num_active=na, steps=steps), (ref, acc)))
+    th = oracle.best_threads()              # (a step's fastest thread count on this host: tests/parity_report.py)
+    ref = OracleSim(oracle, pos, vel, params=prm, threads=th); ref.simulate(num_active=na, steps=steps)
+    acc = OracleSim(oracle, pos, vel, params=prm, sum_spec=SumSpec(SUM_FP64_ACC), threads=th); acc.simulate(num_active=na, steps=steps)
     dev_ref, own, dev_acc = stats(p[:na], ref.latest[0][:na]), stats(ref.latest[0][:na], acc.latest[0][:na]), stats(p[:na], acc.latest[0][:na])
     print("split form, 1000 steps, 32 768 of 65 536 active: device vs ref", dev_ref, "| ref vs acc64", own, "| device vs acc64", dev_acc)
     assert dev_ref["median"] <= 1e-5 and dev_ref["rms"] <= 5e-5 and dev_ref["frac_within_1e-4"] >= 0.999

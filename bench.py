@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--xcd-weights", default="", help="w0,...,w7: run the symmetric kernel under THESE relative die speeds (1024 = the fastest; mapn_set_sym_xcd_weights) -- no "
                                                       "calibration, no A/B: replays the plan of an earlier run's line (config.xcd_aware_parts.weights) bit for bit")
     ap.add_argument("--no-partial-leg", action="store_true", help="skip the untimed ~0.3 s behind the run that measures partially active steps (num_active = N/2, 3N/4) against the one-sided step (single GPU)")
+    ap.add_argument("--no-survey-leg", action="store_true", help="skip the five untimed 100-step regions behind a run with K < 100 (config.survey_8d; ranks time-slicing ONE device in tests make them slow)")
     ap.add_argument("--no-central-well-leg", action="store_true", help="skip the untimed ~0.3 s behind the run that measures the HBM-bound CENTRAL_WELL step at 4 Mi and 16 Mi bodies (single GPU)")
     ap.add_argument("--overlap", action="store_true", help="sharded mode: own-segment launch overlapped with the all-gather")
     ap.add_argument("--trial-seconds", type=float, default=90.0,
@@ -379,7 +380,7 @@ def main():
         repeats = {"ms_per_step": [round(x, 5) for x in reps], "median_ms_per_step": round(sorted(reps)[len(reps) // 2], 5), "meets_survey_8d": a.steps >= 100,
                    "note": "the timed region (first entry: `ms_per_step`, `value`) and four more regions of the same K steps behind it (after the run's validity checks); "
                            "SURVEY 8(d)'s statistic proper: config.survey_8d"}
-        r8 = reps if a.steps >= 100 else (regions(100, 5) if len(reps) == 5 else [])
+        r8 = reps if a.steps >= 100 else (regions(100, 5) if len(reps) == 5 and not a.no_survey_leg else [])
         if len(r8) == 5:
             s8d = survey_8d(r8, max(a.steps, 100), pairs_per_step)
     # what the package draws under this kernel (single GPU; untimed, behind everything that is timed or checked): the symmetric kernel

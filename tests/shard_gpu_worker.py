@@ -1,8 +1,14 @@
 """One rank of tests/test_shard_gpu_multiproc.py (run as a script, one process per rank).
-torch is imported BEFORE the library so that the process holds a single HIP runtime (torch's),
-exactly like bench.py under torch.distributed.run."""
+
+How the ranks find each other is NOT what these tests are about (the product's exchanges run on the device: hipIpc-mapped buffers, device
+flags): the few host-side collectives a test needs -- hand round the hipIpc blobs, start together, compare checksums, collect the
+velocities -- go through FILES in the test's directory (FileGroup) since round 6, which spares every one of ~150 rank processes per
+suite run the import of torch.  Mode "external" keeps torch.distributed over gloo -- imported BEFORE the library, so that the
+process holds a single HIP runtime (torch's), exactly like bench.py under torch.distributed.run; the bench tests cover that combination too."""
 import os
+import pickle
 import sys
+import time
 
 import numpy as np
 
@@ -10,16 +16,92 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+class FileGroup:
+    """all_gather / barrier between the rank processes of ONE test through files in its directory: every call writes rank-numbered files
+    (atomically: write + rename) and polls for the others'.  A rank that dies leaves a marker, so the others fail at once instead of
+    waiting out the time limit."""
+
+    def __init__(self, root, rank, world, timeout=600.0):
+        self.dir, self.rank, self.world, self.timeout, self.seq = os.path.join(root, "_rendezvous"), rank, world, timeout, 0
+        os.makedirs(self.dir, exist_ok=True)
+
+    def all_gather(self, obj):
+        self.seq += 1
+        mine = os.path.join(self.dir, f"{self.seq}_{self.rank}")
+        with open(mine + ".tmp", "wb") as f:
+            pickle.dump(obj, f, protocol=pickle.HIGHEST_PROTOCOL)
+        os.replace(mine + ".tmp", mine + ".pkl")
+        out, t0 = [], time.monotonic()
+        for r in range(self.world):
+            path = os.path.join(self.dir, f"{self.seq}_{r}.pkl")
+            while not os.path.exists(path):
+                if any(os.path.exists(os.path.join(self.dir, f"FAILED_{q}")) for q in range(self.world)):
+                    raise RuntimeError(f"rank {self.rank}: another rank of this test failed")
+                if time.monotonic() - t0 > self.timeout:
+                    raise TimeoutError(f"rank {self.rank}: rank {r} never reached collective {self.seq}")
+                time.sleep(0.0005)
+            with open(path, "rb") as f:
+                out.append(pickle.load(f))
+        return out
+
+    def barrier(self):
+        self.all_gather(None)
+
+    def failed(self):
+        open(os.path.join(self.dir, f"FAILED_{self.rank}"), "w").close()
+
+    def close(self):
+        pass
+
+
+class TorchGroup:
+    """The same two collectives over torch.distributed (gloo)."""
+
+    def __init__(self, rank, world, port):
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        self.dist, self.world = dist, world
+
+    def all_gather(self, obj):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def barrier(self):
+        self.grp.barrier()
+
+    def failed(self):
+        pass
+
+    def close(self):
+        self.grp.close()
+
+
 def main():
     rank, world, port, n, steps = (int(x) for x in sys.argv[1:6])
     out_dir = sys.argv[6]
     mode = sys.argv[7] if len(sys.argv) > 7 else "external"
-    import torch
-    import torch.distributed as dist
+    if mode == "external":
+        import torch                       # noqa: F401  (first: its HIP runtime is then the one libmapn binds to)
+        grp = TorchGroup(rank, world, port)
+    else:
+        grp = FileGroup(out_dir, rank, world)
+    try:
+        run(grp, rank, world, n, steps, out_dir, mode)
+    except BaseException:
+        grp.failed()
+        raise
+
+
+def p2p_setup(c, grp):
+    """mapn_p2p_export on every rank, the blobs handed round, mapn_p2p_import (compute.py's p2p_setup_torch does the same over torch.distributed)."""
+    c.p2p_import(grp.all_gather(c.p2p_export()))
+
+
+def run(grp, rank, world, n, steps, out_dir, mode):
     import mapn
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     c = mapn.Compute(n, device=0, mass=70000.0 / n, rank=rank, world_size=world)
     first, count = c.shard_range()
     if os.environ.get("MAPN_WORKER_PLAN"):          # "kernel,k,waves,sb,fused": keep every rank's launch small enough to be co-resident
@@ -28,7 +110,7 @@ def main():
     if mode == "p2p_timeout":
         # rank 0 steps once, the other ranks never do: rank 0's wait for a peer's slice must give up
         # after the configured bound and SURFACE it (MAPN_ERR_COMM naming the peer), not pass silently
-        c.p2p_setup_torch()
+        p2p_setup(c, grp)
         c.set_gather_algorithm(2)
         c.set_timeouts(p2p_ms=100)
         if rank == 0:
@@ -45,19 +127,19 @@ def main():
             except mapn.MapnError as e:
                 assert e.status == -4
             open(os.path.join(out_dir, "timeout_reported"), "w").write("ok")
-        dist.barrier()
+        grp.barrier()
         c.close()
-        dist.destroy_process_group()
+        grp.close()
         return
     if mode == "sympush_corrupt":
         # gather algorithm 5 between two processes: rank 1's THIRD publication carries one flipped bit in one pushed position (test
         # hook); rank 0 must find it -- MAPN_ERR_COMM naming rank 1 -- when it next touches its replica, rank 1 itself is fine
         if rank == 1:
             os.environ["MAPN_TEST_HOOKS"] = "1"; os.environ["MAPN_TEST_CORRUPT_PUSH"] = "3"
-        c.p2p_setup_torch()
+        p2p_setup(c, grp)
         c.set_gather_algorithm(5)
         c.set_timeouts(p2p_ms=5000)
-        dist.barrier()
+        grp.barrier()
         for _ in range(3):
             c.Simulate(n, c.GetFenceValue())
         if rank == 0:
@@ -71,9 +153,9 @@ def main():
         else:
             c.WaitForGpu()
             assert c.p2p_status() == 0
-        dist.barrier()
+        grp.barrier()
         c.close()
-        dist.destroy_process_group()
+        grp.close()
         return
     if mode == "symrow_corrupt":
         # ADVICE r4 (medium) / VERDICT r5 #1: a rank whose reaction rows never validate must not integrate and publish as if they had.
@@ -86,11 +168,17 @@ def main():
         algo = int(sys.argv[8])
         if rank == 1:
             os.environ["MAPN_TEST_HOOKS"] = "1"; os.environ["MAPN_TEST_CORRUPT_ROW"] = "3"
-        c.p2p_setup_torch()
+        p2p_setup(c, grp)
         c.set_gather_algorithm(algo)
         c.set_timeouts(p2p_ms=400)
         handles = c.GetSharedHandles(consumer_fence=False)
-        hip = C.CDLL("libamdhip64.so")
+        hip = None
+        for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):     # (already in the process: libmapn is linked against it)
+            try:
+                hip = C.CDLL(name)
+                break
+            except OSError:
+                continue
         hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 
         def raw_positions(index):
@@ -98,7 +186,7 @@ def main():
             assert hip.hipDeviceSynchronize() == 0
             assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), C.c_void_p(handles.positions[index]), got.nbytes, 2) == 0
             return got
-        dist.barrier()
+        grp.barrier()
         for _ in range(2):
             c.Simulate(n, c.GetFenceValue())
         c.WaitForGpu()
@@ -106,7 +194,7 @@ def main():
         before = c.download_buffer(w)[0]
         healthy_latest = c.download_state()[0]
         assert np.array_equal(raw_positions(w), before)     # (the raw read sees what the library's download sees)
-        dist.barrier()
+        grp.barrier()
         failed = None
         try:
             c.Simulate(n, c.GetFenceValue())
@@ -118,7 +206,7 @@ def main():
             assert "never arrived whole" in str(failed) and 0x100 <= c.p2p_status() < 0x200, (str(failed), c.p2p_status())
         else:
             assert "rank 1" in str(failed) and c.p2p_status() == 2, (str(failed), c.p2p_status())
-        dist.barrier()                                       # both ranks have given up: nothing is in flight any more
+        grp.barrier()                                       # both ranks have given up: nothing is in flight any more
         after = raw_positions(w)
         bad = count + 5                                      # rank 1's body 5 in the whole job
         others = np.ones(n, bool); others[bad] = False
@@ -142,9 +230,9 @@ def main():
         landed = moved & others
         assert disp[landed[others]].max() < 5.0, disp.max()
         open(os.path.join(out_dir, f"row_failure_reported_by_rank{rank}"), "w").write(str(failed))
-        dist.barrier()
+        grp.barrier()
         c.close()
-        dist.destroy_process_group()
+        grp.close()
         return
     mixed = mode.endswith("_mixed")                     # every third step freezes part of the bodies: the step then runs one-sided
     if mixed:
@@ -152,7 +240,7 @@ def main():
     if mode in ("p2p", "flow", "sym", "sympush"):
         # the in-library direct exchange: hipIpc-mapped peer buffers + device flags, no caller help;
         # "flow" = the same exchange overlapped inside the force launch (gather algorithm 3)
-        c.p2p_setup_torch()
+        p2p_setup(c, grp)
         # "sym" = the symmetric step sharded over the ranks (gather algorithm 4): reactions stored into the
         # owners' receive regions, positions pulled as in "p2p"
         # "sympush" = the same with the new positions PUSHED into the peers' replicas by the exchange launch (gather algorithm 5)
@@ -171,7 +259,7 @@ def main():
         # first step, one process after the other)
         c.set_timeouts(p2p_ms=5000 if n <= 65536 else 60000)
         num_active = int(sys.argv[8]) if len(sys.argv) > 8 else n
-        dist.barrier()                   # start stepping together: process start-up skews by seconds on a cold box
+        grp.barrier()                   # start stepping together: process start-up skews by seconds on a cold box
         for k in range(steps):
             c.Simulate(num_active if not (mixed and k % 3 == 1) else num_active // 2 + 100, c.GetFenceValue())
         c.WaitForGpu()
@@ -210,38 +298,31 @@ def main():
             np.savez(os.path.join(out_dir, f"plan_rank{rank}.npz"), windows=pl.windows, tables=pl.tables,
                      shape=np.array([pl.nb, pl.groups, pl.parts, pl.waves, pl.brows, pl.max_meetings, pl.table_stride, pl.sets, pl.a0, pl.nbl], np.uint32))
         # every replica must hold the same positions, bit for bit
-        sums = [None] * world
-        dist.all_gather_object(sums, (int(np.frombuffer(pos.tobytes(), np.uint32).sum(dtype=np.uint64)),
-                                      int(np.frombuffer(other.tobytes(), np.uint32).sum(dtype=np.uint64))))
+        sums = grp.all_gather((int(np.frombuffer(pos.tobytes(), np.uint32).sum(dtype=np.uint64)),
+                               int(np.frombuffer(other.tobytes(), np.uint32).sum(dtype=np.uint64))))
         assert all(s == sums[0] for s in sums), f"position replicas differ across ranks: {sums}"
-        mine_v = torch.from_numpy(vel[first:first + count].copy())
-        fullv = torch.empty((n, 3), dtype=torch.float32)
-        dist.all_gather_into_tensor(fullv, mine_v)
+        fullv = np.concatenate(grp.all_gather(vel[first:first + count].copy()))
         if rank == 0:
-            np.savez(os.path.join(out_dir, "gpu_sharded.npz"), pos=pos, vel=fullv.numpy(), other=other)
+            np.savez(os.path.join(out_dir, "gpu_sharded.npz"), pos=pos, vel=fullv, other=other)
         c.close()
-        dist.barrier()
-        dist.destroy_process_group()
+        grp.barrier()
+        grp.close()
         return
     c.set_external_gather(True)
     for _ in range(steps):
         c.Simulate(n, c.GetFenceValue())
         pos, vel = c.download_state()                       # latest buffer: own slice is fresh
-        mine = torch.from_numpy(pos[first:first + count].copy())
-        full = torch.empty((n, 4), dtype=torch.float32)
-        dist.all_gather_into_tensor(full, mine)
+        full = np.concatenate(grp.all_gather(pos[first:first + count].copy()))
         # the caller's all-gather: upload_state writes both ping-pong buffers, which is exact for a
         # continuation with num_active == n (every body is rewritten by the next step anyway)
-        c.upload_state(full.numpy(), vel)
+        c.upload_state(full, vel)
     pos, vel = c.download_state()
-    mine_v = torch.from_numpy(vel[first:first + count].copy())
-    fullv = torch.empty((n, 3), dtype=torch.float32)
-    dist.all_gather_into_tensor(fullv, mine_v)
+    fullv = np.concatenate(grp.all_gather(vel[first:first + count].copy()))
     if rank == 0:
-        np.savez(os.path.join(out_dir, "gpu_sharded.npz"), pos=pos, vel=fullv.numpy())
+        np.savez(os.path.join(out_dir, "gpu_sharded.npz"), pos=pos, vel=fullv)
     c.close()
-    dist.barrier()
-    dist.destroy_process_group()
+    grp.barrier()
+    grp.close()
 
 
 if __name__ == "__main__":

@@ -31,7 +31,7 @@ def test_bench_launches_its_own_ranks_and_relays_their_failure_without_a_gpu():
         pytest.skip("a GPU is present")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--bodies", "2048",
-                        "--same-device", "--dist-backend", "gloo", "--gather", "p2p"], capture_output=True, text=True, timeout=300, env=env)
+                        "--same-device", "--no-survey-leg", "--dist-backend", "gloo", "--gather", "p2p"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0
     assert "[bench launcher] rank 0 exited with code" in r.stderr and "[bench launcher] rank 1 exited with code" in r.stderr
     assert not any(line.startswith("{") for line in r.stdout.splitlines())
@@ -240,6 +240,8 @@ def test_bench_two_ranks_one_gpu_with_the_direct_exchange():
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["exchange"] == "p2p"
+    s8 = d["config"]["survey_8d"]           # (this one N > 1 test keeps the five 100-step regions: they run through the same closing collective, MAX over ranks)
+    assert s8["steps"] == 100 and s8["repeats"] == 5 and s8["meets_survey_8d"] is True and s8["min"] <= s8["median_ms_per_step"] <= s8["max"]
     assert d["config"]["replicas_bit_identical_after_run"] is True
     assert d["config"]["parallelism"] == "bodies sharded x2" and "cpu_baseline" not in d
     # the contract's figure includes the closing collective; the time until every rank's own device was idle (MAX over ranks) is listed beside it
@@ -255,7 +257,7 @@ def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
     JSON line and the worst exit code."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "3", "--gather", "p2p",
-                        "--dist-backend", "gloo", "--same-device", "--prewarm-ms", "20"], capture_output=True, text=True, timeout=900, env=env)
+                        "--dist-backend", "gloo", "--same-device", "--no-survey-leg", "--prewarm-ms", "20"], capture_output=True, text=True, timeout=900, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads(lines[0])
@@ -273,7 +275,7 @@ def test_bench_two_ranks_one_gpu_with_the_in_kernel_exchange():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "30", "--warmup", "3", "--gather", "flow", "--dist-backend", "gloo",
-                        "--same-device", "--prewarm-ms", "20", "--bodies", "8192"], capture_output=True, text=True, timeout=900)
+                        "--same-device", "--no-survey-leg", "--prewarm-ms", "20", "--bodies", "8192"], capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads(lines[0])
@@ -289,7 +291,7 @@ def test_bench_two_ranks_one_gpu_with_the_sharded_symmetric_step():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "30", "--warmup", "3", "--gather", "sym", "--dist-backend", "gloo",
-                        "--same-device", "--prewarm-ms", "20", "--bodies", "16384"], capture_output=True, text=True, timeout=900)
+                        "--same-device", "--no-survey-leg", "--prewarm-ms", "20", "--bodies", "16384"], capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads(lines[0])
@@ -307,7 +309,7 @@ def test_bench_falls_back_once_when_a_verified_form_fails_in_the_run_itself():
     to the next verified form, times the K steps again and says so in its line."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "3", "--gather", "sympush",
-                        "--dist-backend", "gloo", "--same-device", "--prewarm-ms", "20", "--bodies", "16384", "--test-inject-push-failure",
+                        "--dist-backend", "gloo", "--same-device", "--no-survey-leg", "--prewarm-ms", "20", "--bodies", "16384", "--test-inject-push-failure",
                         "--p2p-timeout-ms", "3000"], capture_output=True, text=True, timeout=900, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
@@ -329,7 +331,7 @@ def test_bench_eight_ranks_one_gpu_trial_over_every_peer_to_peer_form():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                         "--gpus", "8", "--steps", "24", "--warmup", "3", "--gather", "p2pall", "--dist-backend", "gloo",
-                        "--same-device", "--prewarm-ms", "10", "--bodies", "16384", "--p2p-timeout-ms", "10000", "--xcd", "off"], capture_output=True, text=True, timeout=1500)   # (--xcd off: eight creation-time calibrations on one shared device are 10 s of this test and not its subject)
+                        "--same-device", "--no-survey-leg", "--prewarm-ms", "10", "--bodies", "16384", "--p2p-timeout-ms", "10000", "--xcd", "off"], capture_output=True, text=True, timeout=1500)   # (--xcd off: eight creation-time calibrations on one shared device are 10 s of this test and not its subject)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads(lines[0])

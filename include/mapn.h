@@ -343,7 +343,11 @@ int mapn_comm_init(mapn_ctx *ctx, const void *id128);
  * produced for another rank's bodies -- summed over its blocks first, one row per destination -- straight
  * into that rank's receive region, and integrates its bodies from its own rows plus the rows received;
  * the same launch then publishes the rank's new slice and pulls the peers'; needs N / world_size to be a multiple of
- * 1024 and all bodies active, otherwise the step runs as 2), 5 = as 4, but that launch also STORES the new positions
+ * 1024, otherwise the step runs as 2.  A PARTIALLY ACTIVE step (num_active < N, at least 2048 bodies active) keeps the symmetric kernel
+ * since round 6: the active bodies form a ring of blocks of their own which their owners run, and every rank that owns FROZEN bodies
+ * computes what those do to all active bodies -- one one-sided launch -- and sends the sums in the same rows as the reactions
+ * (mapn_shard_split_describe, mapn_tuning.h, says who does what; before: the one-sided kernel over (a rank's active bodies) x N and a pull)),
+ * 5 = as 4, but that launch also STORES the new positions
  * into every peer's replica (posted writes instead of read round trips) and the peers' next force launch waits for
  * this rank's counter before it reads them, 6 = the sharded symmetric step over RCCL alone (after mapn_comm_init, no
  * mapped peer memory): a pack launch, one group of ncclSend / ncclRecv carrying the per-destination reaction rows into

@@ -70,13 +70,13 @@ class TorchGroup:
         return out
 
     def barrier(self):
-        self.grp.barrier()
+        self.dist.barrier()
 
     def failed(self):
         pass
 
     def close(self):
-        self.grp.close()
+        self.dist.destroy_process_group()
 
 
 def main():

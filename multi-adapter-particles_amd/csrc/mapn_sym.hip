@@ -606,10 +606,14 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 //      for the peers' counters and pulls its share of their slices with cache-bypassing system-scope loads.  PUSH form
 //      (gather algorithm 5): (4) has already stored every new position into every peer's replica as well, the counter
 //      says so, and the launch ends here -- the wait moves to the head of the peers' next force launch.
-template <int G>
+// PARTIAL: a partially active step (p.active < the job's bodies; enqueue_sym_shard_split) -- frozen bodies are skipped, the frozen rows added, count_active
+// bodies integrated.  The all-active step is instantiated WITHOUT any of it: its code is round 5's (same box: exchange launch 12.0 - 12.1 us
+// either way; with the checks compiled in unconditionally 12.3).
+template <int G, bool PARTIAL>
 __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardArgs p)
 {
     const uint32_t bid = blockIdx.x, nblk = gridDim.x;
+    const uint32_t count_active = PARTIAL ? p.count_active : p.count;
     constexpr uint32_t B = 256u / G;                       // bodies per workgroup and pass
     __shared__ uint32_t ok;
     __shared__ float part[G][3][B];
@@ -625,11 +629,11 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     const uint32_t total = p.phase == 2u ? 0u : p.world * p.count;
     for (uint32_t t = bid * 256u + threadIdx.x; t < total; t += nblk * 256u) {
         const uint32_t q = t / p.count, jl = t - q * p.count;
-        if (!((p.send_mask >> q) & 1u) || t >= p.active) continue;            // (t is the body's index in the whole job; a frozen body collects nothing)
+        if (!((p.send_mask >> q) & 1u) || (PARTIAL && t >= p.active)) continue;   // (t is the body's index in the whole job; a frozen body collects nothing)
         const uint32_t b = t / SYM_BLOCK, jb = t >> 6, tt = jb % SYM_JPI;
         const SymRow *rows = p.brow + (size_t)jb * p.nbl * 64u + (t & 63u);
         float fx = 0.f, fy = 0.f, fz = 0.f;
-        if (p.extra) {
+        if (PARTIAL && p.extra) {
             // a PARTIALLY ACTIVE step: what this rank's FROZEN bodies do to body t -- the partial rows of the one-sided launch in front of this
             // one, in ascending row order from zero (eight loads in flight); the reactions of this rank's active blocks follow
             const float4 *xr = p.extra + t;
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     const uint32_t bl = threadIdx.x % B, g = threadIdx.x / B;
     auto own_rows = [&](uint32_t il, float &ax, float &ay, float &az) {
         ax = ay = az = 0.f;
-        if (il >= p.count_active) return;
+        if (il >= count_active) return;
         const uint32_t la = il / SYM_BLOCK;
         const SymRow *ar = p.arow + (size_t)la * p.parts * SYM_BLOCK + (il - la * SYM_BLOCK);
         const uint32_t s0 = (uint32_t)(((uint64_t)p.parts * g) / G), s1 = (uint32_t)(((uint64_t)p.parts * (g + 1u)) / G);
@@ -751,9 +755,9 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
     if (!ok) return;
     if (!p.chunk_flags && !p.poll_rows) stamp(3);          // the peers' rows are here
 
-    for (uint32_t base = bid * B; base < p.count_active; base += nblk * B) {     // (count_active: this rank's bodies that advance -- all of them, or fewer in a partially active step)
+    for (uint32_t base = bid * B; base < count_active; base += nblk * B) {       // (count_active: this rank's bodies that advance -- all of them, or fewer in a partially active step)
         const uint32_t il = base + bl;
-        const bool live = il < p.count_active;
+        const bool live = il < count_active;
         if (base != bid * B) own_rows(il, ax, ay, az);
         if (p.chunk_flags && !p.poll_rows && p.phase == 0u && threadIdx.x < 64u) {
             // the senders' flags of THIS chunk (one lane per sender; bounded)
@@ -904,7 +908,7 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
             const uint32_t eu = e + u * nblk * 256u;
             const bool in = eu < others;
             const uint32_t k = in ? eu / p.count : 0u, q = k < p.rank ? k : k + 1u;        // skip self
-            const bool live = in && q * p.count + (eu - k * p.count) < p.active;           // (a partially active step: the frozen bodies did not move)
+            const bool live = in && (!PARTIAL || q * p.count + (eu - k * p.count) < p.active);   // (a partially active step: the frozen bodies did not move)
             at[u] = live ? q * p.count + (eu - k * p.count) : 0xffffffffu;
             const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p.pos_peer[q] + (live ? at[u] : 0u));
             lo[u] = live ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
@@ -991,9 +995,16 @@ uint32_t sym_shard_exchange_resident_workgroups(uint32_t count, int cus)
 {
     int per_cu = 0;
     const int g = exchange_threads_per_body(count);
-    hipError_t e = g == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sym_shard_exchange_kernel<8>, 256, 0)
-                 : g == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sym_shard_exchange_kernel<4>, 256, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sym_shard_exchange_kernel<1>, 256, 0);
+    // (the PARTIAL instantiation: it holds no more registers than the plain one would allow -- the smaller of the two answers)
+    int plain = 0, part = 0;
+    hipError_t e = g == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&plain, sym_shard_exchange_kernel<8, false>, 256, 0)
+                 : g == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&plain, sym_shard_exchange_kernel<4, false>, 256, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&plain, sym_shard_exchange_kernel<1, false>, 256, 0);
+    if (e == hipSuccess)
+        e = g == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&part, sym_shard_exchange_kernel<8, true>, 256, 0)
+          : g == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&part, sym_shard_exchange_kernel<4, true>, 256, 0)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&part, sym_shard_exchange_kernel<1, true>, 256, 0);
+    per_cu = std::min(plain, part);
     if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
     return (uint32_t)std::max(1, per_cu * cus / 2);
 }
@@ -1002,9 +1013,14 @@ hipError_t launch_sym_shard_exchange(const SymShardArgs &a, uint32_t max_workgro
 {
     const int g = exchange_threads_per_body(a.count);
     const uint32_t want = (a.count * (uint32_t)g + 255u) / 256u, grid = std::max(1u, std::min(max_workgroups, want));
-    if (g == 8) hipLaunchKernelGGL((sym_shard_exchange_kernel<8>), dim3(grid), dim3(256), 0, st, a);
-    else if (g == 4) hipLaunchKernelGGL((sym_shard_exchange_kernel<4>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((sym_shard_exchange_kernel<1>), dim3(grid), dim3(256), 0, st, a);
+    const bool partial = a.active < a.world * a.count;     // (phase 1 / 2 launches of the RCCL form: always all bodies)
+    if (partial) {
+        if (g == 8) hipLaunchKernelGGL((sym_shard_exchange_kernel<8, true>), dim3(grid), dim3(256), 0, st, a);
+        else if (g == 4) hipLaunchKernelGGL((sym_shard_exchange_kernel<4, true>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((sym_shard_exchange_kernel<1, true>), dim3(grid), dim3(256), 0, st, a);
+    } else if (g == 8) hipLaunchKernelGGL((sym_shard_exchange_kernel<8, false>), dim3(grid), dim3(256), 0, st, a);
+    else if (g == 4) hipLaunchKernelGGL((sym_shard_exchange_kernel<4, false>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((sym_shard_exchange_kernel<1, false>), dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

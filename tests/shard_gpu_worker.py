@@ -260,8 +260,11 @@ def run(grp, rank, world, n, steps, out_dir, mode):
         c.set_timeouts(p2p_ms=5000 if n <= 65536 else 60000)
         num_active = int(sys.argv[8]) if len(sys.argv) > 8 else n
         grp.barrier()                   # start stepping together: process start-up skews by seconds on a cold box
+        slider = os.environ.get("MAPN_WORKER_SLIDER")      # "a,b,c,...": num_active of step k = the k-th entry (cyclic) -- the slider dragged on a sharded job
+        counts = [int(x) for x in slider.split(",")] if slider else None
         for k in range(steps):
-            c.Simulate(num_active if not (mixed and k % 3 == 1) else num_active // 2 + 100, c.GetFenceValue())
+            na = counts[k % len(counts)] if counts else (num_active if not (mixed and k % 3 == 1) else num_active // 2 + 100)
+            c.Simulate(na, c.GetFenceValue())
         c.WaitForGpu()
         assert c.p2p_status() == 0, f"p2p wait timed out: status {c.p2p_status()}"
         # a PARTIALLY ACTIVE step of the sharded symmetric forms takes the split form (round 6) where mapn_shard_split_describe says so
@@ -269,14 +272,14 @@ def run(grp, rank, world, n, steps, out_dir, mode):
         if mode in ("sym", "sympush") and count % 1024 == 0 and num_active < n and not os.environ.get("MAPN_SHARD_PARTIAL_FORM"):
             from mapn.compute import describe_shard_split
             split_form = bool(describe_shard_split(n, rank, world, num_active).applies)
-        if mode in ("sym", "sympush") and not mixed:
+        if mode in ("sym", "sympush") and not mixed and not counts:
             st = c.kernel_stats()
             want = "force_sym_kernel" if ((num_active == n or split_form) and count % 1024 == 0) else "force_sgpr_kernel"
             assert st.kernel_name.decode() == want, st.kernel_name
             assert (st.split_active != 0) == split_form, (st.split_active, split_form)
         pos, vel = c.download_state()
         other = c.download_buffer(c.buffer_index)[0]
-        if split_form and not mixed:
+        if split_form and not mixed and not counts:
             # this rank's part of the step, for the order-matched restatement (oracle: ORDER_MATCHED_SHARDED_SPLIT) -- and what the device-less
             # description promised must be what the context ran
             role = describe_shard_split(n, rank, world, num_active)
@@ -292,7 +295,7 @@ def run(grp, rank, world, n, steps, out_dir, mode):
             pos0, _ = mapn.generate_initial_state(n, seed=1)
             a = role.active
             assert np.array_equal(pos[a:], pos0[a:]) and np.array_equal(other[a:], pos0[a:]), f"rank {rank}: a frozen body moved"
-        if mode in ("sym", "sympush") and not mixed and num_active == n and count % 1024 == 0:
+        if mode in ("sym", "sympush") and not mixed and not counts and num_active == n and count % 1024 == 0:
             # this rank's launch plan, for the order-matched restatement of the sharded step (oracle: ORDER_MATCHED_SHARDED)
             pl = c.sym_plan()
             np.savez(os.path.join(out_dir, f"plan_rank{rank}.npz"), windows=pl.windows, tables=pl.tables,

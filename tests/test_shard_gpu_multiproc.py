@@ -297,6 +297,34 @@ def test_partially_active_sharded_step_against_the_oracle_and_its_order_matched_
     assert np.linalg.norm(got["vel"][:A].astype(np.float64) - vel[:A], axis=1).max() / 15.0 < 1e-6
 
 
+@pytest.mark.parametrize("world,n", [(8, 65536), (4, 16384)])
+def test_the_slider_dragged_on_a_sharded_job_pushed_equals_pulled_and_follows_the_oracle(tmp_path, oracle, world, n):
+    """num_active changing from step to step on P ranks (Particles.cpp:391-394's slider): all bodies (the sharded symmetric step), half (the
+    split form: four ranks run the active ring, four compute their frozen bodies' forces), the same again (cached plan), 5/8 (another
+    plan), a count that is not whole blocks, a handful (< 2048: the one-sided step + pull), nothing at all, more counts than the plan
+    cache holds, all again.  Every transition changes who waits for whose pushes and which bodies a publication covers (the checksums
+    are verified against the PREVIOUS publication's count).  Pushed positions (5) and pulled ones (4) must give the same bits, every
+    replica identical (checked in the workers), and the trajectory must sit where the oracle's run of the same sequence sits."""
+    import os as _os
+    from oracle import OracleSim, Params
+    seq = [n, n // 2, n // 2, 5 * n // 8, n // 2 + 1000, 1500, 0, 3 * n // 8, 3 * n // 4, 7 * n // 8, n // 4 + 64, n // 2, n, 5 * n // 8]
+    env = {"MAPN_WORKER_SLIDER": ",".join(str(x) for x in seq)}
+    d4, d5 = tmp_path / "pull", tmp_path / "push"
+    _os.makedirs(d4); _os.makedirs(d5)
+    a = _run_ranks(d4, world, n, len(seq), "sym", str(n), env=env)
+    b = _run_ranks(d5, world, n, len(seq), "sympush", str(n), env=env)
+    for k in ("pos", "vel", "other"):
+        np.testing.assert_array_equal(a[k], b[k])
+    pos0, vel0 = oracle.initial_state(n, seed=1)
+    sim = OracleSim(oracle, pos0, vel0, params=Params(mass=70000.0 / n))
+    for na in seq:
+        sim.simulate(num_active=na)
+    dx = np.linalg.norm(b["pos"][:, :3].astype(np.float64) - sim.latest[0][:, :3], axis=1).max() / 400.0
+    dxo = np.linalg.norm(b["other"][:, :3].astype(np.float64) - sim.pos[sim.buffer_index][:, :3], axis=1).max() / 400.0
+    dv = np.linalg.norm(b["vel"].astype(np.float64) - sim.latest[1], axis=1).max() / 15.0
+    assert dx < 8e-6 and dxo < 8e-6 and dv < 2e-4, (dx, dxo, dv)
+
+
 def test_config3_sharded_symmetric_step_with_eight_processes(tmp_path, oracle):
     """configs[3] (1 048 576 bodies sharded over 8 ranks) through gather algorithm 4, all eight ranks real
     processes on ONE GPU: one step of the whole job (every unordered pair once: ~160 ms of the GPU), then

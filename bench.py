@@ -33,7 +33,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from bench_legs import (FLOP_PER_PAIR, HBM_BYTES_PER_BODY, central_well_leg, cpu_baseline, kernel_source_sha16, partial_active_leg, pmc_traffic,   # noqa: E402,F401
-                        power_leg, power_sensor, read_sensor, roofline_all_pairs, roofline_central_well, survey_8d)
+                        power_leg, power_sensor, read_sensor, roofline_all_pairs, roofline_central_well, step_spread, survey_8d)
 from bench_ranks import Job, launch_ranks   # noqa: E402
 
 
@@ -291,6 +291,15 @@ def main():
                 c.set_sym_xcd_weights(None)
             except mapn.MapnError:
                 pass
+    if a.prewarm_ms > 0 and "trial_ms" in xcd:
+        # the A/B ends with a re-plan (scratch freed and allocated: the device idles for milliseconds) and the chip needs ~15 steps to be back at
+        # the clock it holds under load -- with W = 5 the driver's K = 20 region sat on that ramp (first region 0.616 ms against 0.593 for the
+        # four behind it, same run).  A short untimed ramp, as in front of the A/B: the W warm-up steps and the K timed ones follow it.
+        ramp = 256 if dist is None else max(16, prewarm_steps // 4)
+        for _ in range(ramp):
+            job.step()
+        job.c.WaitForGpu()
+        prewarm_steps += ramp
     closing = job.closing_collective()                     # its tensors and events: made here, before any timed region (run_steps)
 
     def reduce_max(*vals):
@@ -323,19 +332,7 @@ def main():
     gather_algo, trial = job.gather_algo, job.trial
 
     st = c.kernel_stats()
-    # how the step time is spread over the timed region: the steps that carried HIP events (every timer_interval-th), by quarter
-    quarters = None
-    try:
-        idx, step_ms, _ = c.step_samples()
-        if len(idx):
-            quarters = []
-            for qn in range(4):
-                m = (idx >= a.steps * qn // 4) & (idx < a.steps * (qn + 1) // 4)
-                quarters.append(round(float(step_ms[m].mean()), 5) if m.any() else None)
-            spread = {"steps_timed": int(len(idx)), "min_ms": round(float(step_ms.min()), 5), "median_ms": round(float(sorted(step_ms)[len(idx) // 2]), 5),
-                      "max_ms": round(float(step_ms.max()), 5)}
-    except mapn.MapnError:
-        pass
+    quarters, spread = step_spread(mapn, c, a.steps)       # how the step time is spread over the timed region (the steps that carried HIP events), by quarter
     first, count = c.shard_range()
     # the clock the chip held under this kernel: stamped diagnostic steps right behind the timed region
     # (same state of the chip; untimed).  Single GPU, scalar-cache and symmetric kernels.
@@ -469,7 +466,7 @@ def main():
                        "grid": [st.grid_x, st.grid_y], "block": st.block_x, "fused_integrator": bool(st.fused),
                        "epilogue": {0: "partial rows + reduce_integrate launch", 1: "fused in the workgroup", 2: "last-arriver ticket (one launch per step)", 3: "symmetric kernel: force rows + sym_reduce_integrate launch"}.get(st.epilogue, "?"),
                        "launches_per_step": int(st.force_launches_per_step) * (1 if st.fused else 2), "timer_interval": timer_interval,
-                       "step_ms_by_quarter_of_the_timed_region": quarters, "step_ms_spread": spread if quarters else None,
+                       "step_ms_by_quarter_of_the_timed_region": quarters, "step_ms_spread": spread,
                        "repeats": repeats, "survey_8d": s8d,
                        "step_ms_note": "device time (HIP events on the compute stream) of the steps of the timed region that carried events; ms_per_step is the wall clock over all of them",
                        "p2p_failure": job.p2p_failure, "fallback_after_failure": job.fallback_after_failure, "sharded_symmetric_deviation_after_run": sym_dev_after,

@@ -319,3 +319,20 @@ def survey_8d(region_ms, steps, pairs_per_step):
             "interactions_per_s": pairs_per_step / (med * 1e-3), "meets_survey_8d": steps >= 100 and len(r) >= 5,
             "note": "five regions of `steps` steps each, every one closed like the contract's (barrier + device sync on both sides, MAX over ranks); untimed by "
                     "the contract -- `value` stays the K-step region the driver asked for"}
+
+
+def step_spread(mapn, c, steps):
+    """How the step time is spread over the timed region: the steps that carried HIP events (every timer_interval-th), by quarter of the
+    region, and their minimum / median / maximum.  (None, None) when there are none."""
+    try:
+        idx, step_ms, _ = c.step_samples()
+    except mapn.MapnError:
+        return None, None
+    if not len(idx):
+        return None, None
+    quarters = []
+    for qn in range(4):
+        m = (idx >= steps * qn // 4) & (idx < steps * (qn + 1) // 4)
+        quarters.append(round(float(step_ms[m].mean()), 5) if m.any() else None)
+    return quarters, {"steps_timed": int(len(idx)), "min_ms": round(float(step_ms.min()), 5), "median_ms": round(float(sorted(step_ms)[len(idx) // 2]), 5),
+                      "max_ms": round(float(step_ms.max()), 5)}

@@ -72,11 +72,11 @@ def test_committed_pmc_summaries_belong_to_the_current_kernel_sources():
     spec = importlib.util.spec_from_file_location("bench_for_sha", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
     sha = bench.kernel_source_sha16()
-    for tag, kernel in (("r05_sym", "force_sym_kernel"), ("r05_onesided", "force_sgpr_kernel")):
+    for tag, kernel in (("r06_sym", "force_sym_kernel"), ("r06_onesided", "force_sgpr_kernel")):
         d = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json")))
         assert d["_kernel_source_sha16"] == sha, f"profiles/{tag}_pmc_summary.json is stale: re-run tools/evidence.sh pmc"
     traffic, src = bench.pmc_traffic("force_sym_kernel", 65536, 1)
-    assert traffic and 3e7 < traffic < 2e8 and src.endswith("r05_sym_pmc_summary.json")     # rows: N^2 / 128 + 16 N x parts bytes, + the positions
+    assert traffic and 3e7 < traffic < 2e8 and src.endswith("r06_sym_pmc_summary.json")     # rows: N^2 / 128 + 16 N x parts bytes, + the positions
 
 
 @pytest.mark.gpu

@@ -2,6 +2,7 @@
 // include/mapn.h, the error helpers and the internal entry points.  Internal; the public boundary is include/mapn.h.
 //   mapn_context.cpp   creation / destruction, Simulate and the fence (Compute.cpp:72-123, 928-1055), consumer fence, timers, the one-sided step
 //   mapn_sym_host.cpp  the symmetric kernel's plan, scratch and launches (unsharded, sharded over hipIpc, sharded over RCCL)
+//   mapn_partial.cpp   partially active steps (num_active < N): step forms, the split form unsharded and sharded, the per-count plan cache, deferred frees
 //   mapn_shard.cpp     the sharded mode's exchanges: RCCL, peer-to-peer set-up (hipIpc), gather algorithms, replica checksum
 //   mapn_state.cpp     state hand-off: upload / download, snapshot file, consumer copy, the consumer in another process (mapn_ipc_*)
 #pragma once
@@ -249,6 +250,11 @@ uint32_t active_bodies(int num_active, uint32_t n);
 int choose_epilogue(const mapn_ctx *c, const mapn::ForcePlan &p, bool allow_fused);
 mapn::ForcePlan choose_plan(const mapn_ctx *c, uint32_t i_count, uint32_t j_total, uint32_t nseg, bool allow_fused);
 // mapn_sym_host.cpp
+struct Shape { uint32_t parts, t1, t2, waves, hi, lo; };     // a launch shape prepare_sym / prepare_sym_active try: parts per block, taper, waves, wave bias
+std::vector<Shape> candidate_shapes(const mapn_ctx *c, bool sharded, uint32_t nb, uint32_t nbl, uint32_t gsym, uint32_t &gpw, bool tunable);
+mapn::SymArgs sym_args_of(const mapn::SymPlanHost &pl, mapn::SymRow *arow, mapn::SymRow *brow, mapn::SymRow *brow1, const uint32_t *tab, uint32_t n,
+                          const mapn::StepArgs &base, size_t window);
+int export_plan(const mapn::SymPlanHost &p, const char *who, mapn_sym_plan_info *info, uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity);
 void release_sym(mapn_ctx *c);
 void sym_shard_masks(uint32_t nb, uint32_t world, uint32_t rank, uint32_t &send, uint32_t &recv);
 bool sym_applies(const mapn_ctx *c, bool sharded);

@@ -56,8 +56,6 @@ bool sym_applies(const mapn_ctx *c, bool sharded)
     return c->cfg.world_size == 1 && c->n >= mapn::SYM_BLOCK;   // (a smaller job does not fill one block: one-sided)
 }
 
-namespace {
-struct Shape { uint32_t parts, t1, t2, waves, hi, lo; };
 
 // The launch shapes prepare_sym tries, in order, for a job of nb blocks (nbl of them in one launch; gsym symmetric groups; gpw: groups
 // per window, may be narrowed by a hook / the user's plan).  tunable: honour mapn_set_sym_plan and the MAPN_SYM_* hooks (the
@@ -128,7 +126,6 @@ std::vector<Shape> candidate_shapes(const mapn_ctx *c, bool sharded, uint32_t nb
     }
     return tries;
 }
-}  // namespace
 
 // Build the launch plan and allocate ALL of the symmetric step's scratch: a-rows [blocks][parts][1024], b-rows
 // (unsharded: [N/64][groups of the widest window][64], bounded by MAPN_SYM_MAX_MB -- a step is made in as many windows
@@ -244,7 +241,6 @@ int stamps_prepare(mapn_ctx *c, size_t nw, mapn::SymArgs &a)
     return timeline_prepare(c, nw, a);
 }
 
-namespace {
 mapn::SymArgs sym_args_of(const mapn::SymPlanHost &pl, mapn::SymRow *arow, mapn::SymRow *brow, mapn::SymRow *brow1, const uint32_t *tab, uint32_t n,
                           const mapn::StepArgs &base, size_t window)
 {
@@ -268,7 +264,6 @@ mapn::SymArgs sym_args_of(const mapn::SymPlanHost &pl, mapn::SymRow *arow, mapn:
     a.stage_iblock = stage;
     return a;
 }
-}  // namespace
 
 mapn::SymArgs sym_args(const mapn_ctx *c, const mapn::StepArgs &base, size_t window)
 {
@@ -598,6 +593,30 @@ int calibrate_at_creation(mapn_ctx *c)
     return rc;
 }
 
+// a plan as the C ABI describes it (info + the two arrays, capacities checked)
+int export_plan(const mapn::SymPlanHost &p, const char *who, mapn_sym_plan_info *info, uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity)
+{
+    info->nb = p.nb; info->groups = p.groups; info->windows = (uint32_t)p.windows.size();
+    info->parts = p.parts; info->taper1 = p.taper1; info->taper2 = p.taper2; info->waves = p.waves;
+    info->wave_bias[0] = p.bias_hi; info->wave_bias[1] = p.bias_lo;
+    info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
+    info->sets = p.sets; for (int k = 0; k < 8; k++) info->xcd_weight[k] = p.xcd_weight[k];
+    info->xcd_mode = p.xcd_mode; info->wgmap_offset = p.wgmap_offset; info->wgmap_entries = p.wgmap_entries; info->la_flip = p.la_flip;
+    for (int k = 0; k < 8; k++) info->class_die[k] = p.class_die[k / 4][k % 4];
+    if (windows && windows_capacity < 4u * p.windows.size())
+        return fail(MAPN_ERR_INVALID_ARGUMENT, "%s: windows_capacity %llu < %zu (the plan has changed since the arrays were sized: query again)", who, (unsigned long long)windows_capacity, 4u * p.windows.size());
+    if (windows)
+        for (size_t k = 0; k < p.windows.size(); k++) {
+            windows[4 * k + 0] = p.windows[k].g0; windows[4 * k + 1] = p.windows[k].g1;
+            windows[4 * k + 2] = p.windows[k].meetings[0]; windows[4 * k + 3] = p.windows[k].meetings[1];
+        }
+    if (tables) {
+        if (tables_capacity < p.tables.size()) return fail(MAPN_ERR_INVALID_ARGUMENT, "%s: tables_capacity %llu < %zu", who, (unsigned long long)tables_capacity, p.tables.size());
+        std::copy(p.tables.begin(), p.tables.end(), tables);
+    }
+    return MAPN_OK;
+}
+
 }  // namespace host
 }  // namespace mapn
 
@@ -717,31 +736,6 @@ int mapn_calibrate_sym_xcds(mapn_ctx *c, int steps, uint32_t out[8])
     return MAPN_OK;
 }
 
-namespace {
-// a plan as the C ABI describes it (info + the two arrays, capacities checked)
-int export_plan(const mapn::SymPlanHost &p, const char *who, mapn_sym_plan_info *info, uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity)
-{
-    info->nb = p.nb; info->groups = p.groups; info->windows = (uint32_t)p.windows.size();
-    info->parts = p.parts; info->taper1 = p.taper1; info->taper2 = p.taper2; info->waves = p.waves;
-    info->wave_bias[0] = p.bias_hi; info->wave_bias[1] = p.bias_lo;
-    info->brows = p.brows; info->max_meetings = p.max_meetings; info->table_stride = p.table_stride;
-    info->sets = p.sets; for (int k = 0; k < 8; k++) info->xcd_weight[k] = p.xcd_weight[k];
-    info->xcd_mode = p.xcd_mode; info->wgmap_offset = p.wgmap_offset; info->wgmap_entries = p.wgmap_entries; info->la_flip = p.la_flip;
-    for (int k = 0; k < 8; k++) info->class_die[k] = p.class_die[k / 4][k % 4];
-    if (windows && windows_capacity < 4u * p.windows.size())
-        return fail(MAPN_ERR_INVALID_ARGUMENT, "%s: windows_capacity %llu < %zu (the plan has changed since the arrays were sized: query again)", who, (unsigned long long)windows_capacity, 4u * p.windows.size());
-    if (windows)
-        for (size_t k = 0; k < p.windows.size(); k++) {
-            windows[4 * k + 0] = p.windows[k].g0; windows[4 * k + 1] = p.windows[k].g1;
-            windows[4 * k + 2] = p.windows[k].meetings[0]; windows[4 * k + 3] = p.windows[k].meetings[1];
-        }
-    if (tables) {
-        if (tables_capacity < p.tables.size()) return fail(MAPN_ERR_INVALID_ARGUMENT, "%s: tables_capacity %llu < %zu", who, (unsigned long long)tables_capacity, p.tables.size());
-        std::copy(p.tables.begin(), p.tables.end(), tables);
-    }
-    return MAPN_OK;
-}
-}  // namespace
 
 int mapn_get_sym_plan(mapn_ctx *c, mapn_sym_plan_info *info, uint32_t *windows, uint64_t windows_capacity, uint32_t *tables, uint64_t tables_capacity)
 {

@@ -18,6 +18,8 @@
 #   parity1000                   tests/parity_report.py at 65 536 bodies, 1000 steps, all legs -> JSON
 #   ubench                       BASELINE configs[4]: the MFMA-against-packed-VALU A/B (tools/ubench --ab) under rocprofv3 --kernel-trace --stats + the gpu test's report
 #   soak MODE                    several real processes on one GPU, long runs: MODE = flow | sym | sympush (against p2p)
+#   soakslider                   the slider dragged on a sharded job for many steps (partially active steps in their split form, all-active, one-sided, nothing), several real
+#                                processes on one GPU: pushed (5) against pulled (4) positions bit for bit -> slider_soak.txt
 #   closing                      what the ONE closing collective (barrier + verdict) adds to a timed region of K = 20 / 200 steps: two ranks sharing this GPU
 #                                (gloo) and one rank over the RCCL backend -> closing_cost.txt
 #   partial                      partially active steps: one-sided / full symmetric / split form over a sweep of num_active (tools/partial_sweep.py)
@@ -257,6 +259,26 @@ a = np.load("/tmp/soak/p2p/gpu_sharded.npz"); b = np.load(f"/tmp/soak/{mode}/gpu
 same = all(np.array_equal(a[k], b[k]) for k in ("pos", "vel", "other"))
 d = np.linalg.norm(a["pos"][:, :3].astype(np.float64) - b["pos"][:, :3], axis=1) / np.maximum(np.linalg.norm(a["pos"][:, :3].astype(np.float64), axis=1), 1e-30)
 print(f"world={Wd} n={N} steps={S}  {mode} vs p2p: bitwise equal {same}, relative position difference max {d.max():.2e} median {np.median(d):.2e}, finite {bool(np.isfinite(b['pos']).all())}")
+PY
+  done ;;
+soakslider)
+  mkdir -p /tmp/soak
+  for cfg in "8 65536 700" "4 65536 500" "2 32768 500" "8 16384 1400"; do
+    set -- $cfg; Wd=$1; N=$2; S=$3
+    export MAPN_WORKER_SLIDER="$N,$((N/2)),$((N/2)),$((5*N/8)),$((N/2+1000)),1500,0,$((3*N/8)),$((3*N/4)),$((7*N/8)),$((N/4+64)),$((N/2)),$N,$((5*N/8)),$((N/2+64)),$((N-64)),$N"
+    for m in sym sympush; do
+      rm -rf /tmp/soak/$m; mkdir -p /tmp/soak/$m; pids=""
+      for r in $(seq 0 $((Wd - 1))); do python tests/shard_gpu_worker.py $r $Wd $((29850 + Wd)) $N $S /tmp/soak/$m $m $N > /tmp/soak/$m/log_$r.txt 2>&1 & pids="$pids $!"; done
+      t0=$(date +%s); ok=1; for p in $pids; do wait $p || ok=0; done
+      [ $ok = 1 ] && echo "world=$Wd n=$N steps=$S mode=$m: done in $(( $(date +%s) - t0 )) s" | tee -a $O/slider_soak.txt
+      [ $ok = 1 ] || { echo "world=$Wd n=$N steps=$S mode=$m FAILED" | tee -a $O/slider_soak.txt; for f in /tmp/soak/$m/log_*.txt; do tail -n 3 $f; done; }
+    done
+    python - $Wd $N $S <<'PY' | tee -a $O/slider_soak.txt
+import sys, numpy as np
+Wd, N, S = sys.argv[1:4]
+a = np.load("/tmp/soak/sym/gpu_sharded.npz"); b = np.load("/tmp/soak/sympush/gpu_sharded.npz")
+same = all(np.array_equal(a[k], b[k]) for k in ("pos", "vel", "other"))
+print(f"world={Wd} n={N} steps={S}, slider sequence of 17 counts cycled: pushed vs pulled bitwise equal {same}, finite {bool(np.isfinite(b['pos']).all())}")
 PY
   done ;;
 *) echo "unknown: $W"; exit 2 ;;

@@ -307,7 +307,8 @@ def test_the_slider_dragged_on_a_sharded_job_pushed_equals_pulled_and_follows_th
     replica identical (checked in the workers), and the trajectory must sit where the oracle's run of the same sequence sits."""
     import os as _os
     from oracle import OracleSim, Params
-    seq = [n, n // 2, n // 2, 5 * n // 8, n // 2 + 1000, 1500, 0, 3 * n // 8, 3 * n // 4, 7 * n // 8, n // 4 + 64, n // 2, n, 5 * n // 8]
+    seq = [n, n // 2, n // 2, 5 * n // 8, n // 2 + 1000, 1500, 0, 3 * n // 8, 3 * n // 4, 7 * n // 8, n // 4 + 64, n // 2, n, 5 * n // 8, n - 64, 2048, n - 2000]
+    # (n - 64: the last rank keeps ONE tile of frozen bodies; 2048: the smallest count that takes the split form -- one rank runs a two-block ring)
     env = {"MAPN_WORKER_SLIDER": ",".join(str(x) for x in seq)}
     d4, d5 = tmp_path / "pull", tmp_path / "push"
     _os.makedirs(d4); _os.makedirs(d5)

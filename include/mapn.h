@@ -176,8 +176,8 @@ int mapn_destroy(mapn_ctx *ctx);
  * A PARTIALLY ACTIVE all-pairs step (num_active < N) runs the cheapest of three forms for that (N, num_active) -- always the same one,
  * so results stay bit-reproducible: the full symmetric step whose reduce launch stops early; the one-sided kernel over active x N; or
  * the SPLIT form (active x active under the symmetric kernel with a plan of the active blocks alone + active x frozen one-sided: measured
- * 1.16 x the one-sided step at half of the bodies active -- the bound there is 1.18 x -- to 1.34 x at 7/8).  The split form's plans are
- * kept for the last four counts; a NEW count builds its plan on the host and uploads it stream-ordered into its own table buffer, rows that
+ * 1.16 x the one-sided step at half of the bodies active -- the bound there is 1.18 x -- to 1.34 x at 7/8).  The split form's plans belong
+ * to the RING of active blocks (ceil(active / 1024)) and are kept for the last four rings; a NEW ring builds its plan on the host and uploads it stream-ordered into its own table buffer, rows that
  * have to grow are allocated anew and the old ones freed later, once the stream has run dry: the call never waits for the device, also
  * while a step is parked behind the consumer's fence (mapn_kernel_stats.split_plans_built counts the plans built).
  * Afterwards the fence value is +1 and the buffer index flipped (MoveToNextFrame,

@@ -39,9 +39,10 @@ typedef struct mapn_kernel_stats {
     uint32_t split_active;       /* != 0: the step enqueued last was a PARTIALLY ACTIVE one in its split form -- these many bodies met each other under
                                     the symmetric kernel (a plan of the active blocks alone), the frozen ones acted on them through one one-sided
                                     launch in front (kernel_name "force_sym_kernel", grid of the symmetric launch) */
-    uint32_t split_plans_built;  /* host plans built for the split form since the context was created: the last four counts keep theirs, so a slider
-                                    moving between a few values stops building (and a NEW count never blocks mapn_simulate: its plan is uploaded
-                                    stream-ordered into its own table buffer) */
+    uint32_t split_plans_built;  /* host plans built for the split form since the context was created.  A plan belongs to a RING of active blocks
+                                    (ceil(active / 1024)), not to a count: the last four rings keep theirs, so a slider dragged in 64-body steps
+                                    re-plans once per 1024 bodies and one moving between a few values stops building (and a NEW ring never blocks
+                                    mapn_simulate: its plan is uploaded stream-ordered into its own table buffer) */
     uint32_t reserved;
 } mapn_kernel_stats;
 int mapn_get_kernel_stats(mapn_ctx *ctx, int reset, mapn_kernel_stats *out);

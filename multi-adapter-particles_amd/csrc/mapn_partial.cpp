@@ -168,11 +168,30 @@ int prepare_sym_active(mapn_ctx *c, uint32_t active)
     const bool sharded = c->sym_sharded;
     if (act_ready(c, active)) { c->act_plans[c->act_cur].used = ++c->act_clock; return MAPN_OK; }
     c->act_cur = -1;
+    ShardSplit role{};
+    if (sharded) role = shard_split_describe(c->n, (uint32_t)c->cfg.world_size, (uint32_t)c->cfg.rank, active);
+    else { role.nba = (active + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK; role.nbl = role.nba; role.ac = active; role.fz_first = active; role.fz_count = c->n - active; }
+    // the one-sided launch over the frozen bodies (sharded: the ones THIS rank owns): the default plan of an active x frozen launch, partial rows instead of the integrator
+    mapn::ForcePlan frozen{};
+    if (role.fz_count) {
+        frozen = choose_plan(c, active, role.fz_count, 1, false);
+        env_plan("MAPN_FROZEN_PLAN", frozen);              // (hook: "k,waves,sb" -- the sweep behind the default)
+        frozen.epi = mapn::EPI_ROWS;
+    }
     int slot = -1;
     int slots = mapn_ctx::kActPlans;
     if (const char *hk = test_hook("MAPN_ACT_PLANS")) slots = std::max(1, std::min(slots, atoi(hk)));   // (A/B: 1 = round 5's one remembered count)
-    for (int k = 0; k < slots; k++)
-        if (c->act_plans[k].active == active) { c->act_cur = k; c->act_plans[k].used = ++c->act_clock; return MAPN_OK; }
+    // The symmetric plan is a function of the BLOCKS, not of the count: every count with the same ring (ceil(active / 1024) blocks; sharded:
+    // the same blocks of it on this rank) runs the cached plan -- only the count itself (the kernel's bound for the far-away stand-ins), the
+    // frozen launch and the roles are per step.  A slider dragged through 64-body steps re-plans once per 1024 bodies, not per frame.
+    for (int k = 0; k < slots; k++) {
+        mapn_ctx::SymActive &h = c->act_plans[k];
+        if (h.active == 0 || h.role.nba != role.nba || h.role.nbl != role.nbl || h.role.a0 != role.a0) continue;
+        if (role.fz_count && ensure_partial(c, frozen.sb, ((size_t)active + 63u) & ~(size_t)63u) != MAPN_OK) break;   // (cannot be had: the slow path below reports it)
+        h.active = active; h.role = role; h.frozen = frozen; h.used = ++c->act_clock;
+        c->act_cur = k;
+        return MAPN_OK;
+    }
     for (int k = 0; k < slots; k++) {
         if (c->act_plans[k].active == 0) { slot = k; break; }
         if (slot < 0 || c->act_plans[k].used < c->act_plans[slot].used) slot = k;
@@ -186,9 +205,6 @@ int prepare_sym_active(mapn_ctx *c, uint32_t active)
         g_last_error = why;
         return (int)MAPN_OK;
     };
-    ShardSplit role{};
-    if (sharded) role = shard_split_describe(c->n, (uint32_t)c->cfg.world_size, (uint32_t)c->cfg.rank, active);
-    else { role.nba = (active + mapn::SYM_BLOCK - 1) / mapn::SYM_BLOCK; role.nbl = role.nba; role.ac = active; role.fz_first = active; role.fz_count = c->n - active; }
     const uint32_t nb = role.nba, nbl = role.nbl;
     const uint32_t gsym = (nb - 1u) / 2u + ((nb & 1u) ? 0u : 1u);
     const char *e = getenv("MAPN_SYM_MAX_MB");
@@ -207,13 +223,6 @@ int prepare_sym_active(mapn_ctx *c, uint32_t active)
         if (!built) return give_up("partially active step: " + err + (sharded ? "" : "; another form runs"));
     }
     c->split_plans_built++;
-    // the one-sided launch over the frozen bodies (sharded: the ones THIS rank owns): the default plan of an active x frozen launch, partial rows instead of the integrator
-    mapn::ForcePlan frozen{};
-    if (role.fz_count) {
-        frozen = choose_plan(c, active, role.fz_count, 1, false);
-        env_plan("MAPN_FROZEN_PLAN", frozen);              // (hook: "k,waves,sb" -- the sweep behind the default)
-        frozen.epi = mapn::EPI_ROWS;
-    }
     bool moved = false;                                    // a buffer captured graphs hold the address of was replaced
     auto grow = [&](void **p, size_t &have, size_t need) -> hipError_t {
         if (need <= have) return hipSuccess;

@@ -18,6 +18,7 @@
 #   parity1000                   tests/parity_report.py at 65 536 bodies, 1000 steps, all legs -> JSON
 #   ubench                       BASELINE configs[4]: the MFMA-against-packed-VALU A/B (tools/ubench --ab) under rocprofv3 --kernel-trace --stats + the gpu test's report
 #   soak MODE                    several real processes on one GPU, long runs: MODE = flow | sym | sympush (against p2p)
+#   slider                       ms per step with num_active steady / alternating between two counts / NEW every step (the slider dragged), one GPU (tools/slider_drag.py)
 #   soakslider                   the slider dragged on a sharded job for many steps (partially active steps in their split form, all-active, one-sided, nothing), several real
 #                                processes on one GPU: pushed (5) against pulled (4) positions bit for bit -> slider_soak.txt
 #   closing                      what the ONE closing collective (barrier + verdict) adds to a timed region of K = 20 / 200 steps: two ranks sharing this GPU
@@ -261,6 +262,8 @@ d = np.linalg.norm(a["pos"][:, :3].astype(np.float64) - b["pos"][:, :3], axis=1)
 print(f"world={Wd} n={N} steps={S}  {mode} vs p2p: bitwise equal {same}, relative position difference max {d.max():.2e} median {np.median(d):.2e}, finite {bool(np.isfinite(b['pos']).all())}")
 PY
   done ;;
+slider)
+  python tools/slider_drag.py 2>&1 | tee $O/slider_drag.txt ;;
 soakslider)
   mkdir -p /tmp/soak
   for cfg in "8 65536 700" "4 65536 500" "2 32768 500" "8 16384 1400"; do

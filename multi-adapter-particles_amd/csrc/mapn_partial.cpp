@@ -175,6 +175,10 @@ int prepare_sym_active(mapn_ctx *c, uint32_t active)
     mapn::ForcePlan frozen{};
     if (role.fz_count) {
         frozen = choose_plan(c, active, role.fz_count, 1, false);
+        // (a rank's frozen bodies are FEW -- 8192 at 65 536 / 8: 128 tiles -- and the default plan would give every wave ONE tile and the step
+        //  sixteen rows to add up: at least two tiles per wave, half the rows -- 67.4 against 69.8 and 80.7 against 84.0 us per step of a frozen
+        //  rank at N / 2 and 5 N / 8 active, tools/shard_frozen_plan_sweep.py; an unsharded step's frozen range is mostly long enough not to be touched)
+        while (frozen.sb >= 2u && (uint64_t)frozen.sb * frozen.waves * 128u > role.fz_count) frozen.sb /= 2u;
         env_plan("MAPN_FROZEN_PLAN", frozen);              // (hook: "k,waves,sb" -- the sweep behind the default)
         frozen.epi = mapn::EPI_ROWS;
     }

@@ -295,7 +295,8 @@ def main():
         # the A/B ends with a re-plan (scratch freed and allocated: the device idles for milliseconds) and the chip needs ~15 steps to be back at
         # the clock it holds under load -- with W = 5 the driver's K = 20 region sat on that ramp (first region 0.616 ms against 0.593 for the
         # four behind it, same run).  A short untimed ramp, as in front of the A/B: the W warm-up steps and the K timed ones follow it.
-        ramp = 256 if dist is None else max(16, prewarm_steps // 4)
+        per_step_s = min(xcd["trial_ms"].values()) * 1e-3     # (150 ms of steps, whatever the size: a 4 Mi-body step is 2.5 s)
+        ramp = max(4, min(256, int(0.15 / per_step_s))) if dist is None else max(16, prewarm_steps // 4)
         for _ in range(ramp):
             job.step()
         job.c.WaitForGpu()
@@ -377,7 +378,9 @@ def main():
         repeats = {"ms_per_step": [round(x, 5) for x in reps], "median_ms_per_step": round(sorted(reps)[len(reps) // 2], 5), "meets_survey_8d": a.steps >= 100,
                    "note": "the timed region (first entry: `ms_per_step`, `value`) and four more regions of the same K steps behind it (after the run's validity checks); "
                            "SURVEY 8(d)'s statistic proper: config.survey_8d"}
-        r8 = reps if a.steps >= 100 else (regions(100, 5) if len(reps) == 5 and not a.no_survey_leg else [])
+        # (the five 100-step regions only where they are cheap -- under 6 s: 65 536 bodies 0.3 s, 262 144 4.8 s; a 1 Mi-body step is 0.15 s, a 4 Mi-body one 2.5 s)
+        cheap = elapsed / a.steps * 500.0 < 6.0
+        r8 = reps if a.steps >= 100 else (regions(100, 5) if len(reps) == 5 and cheap and not a.no_survey_leg else [])
         if len(r8) == 5:
             s8d = survey_8d(r8, max(a.steps, 100), pairs_per_step)
     # what the package draws under this kernel (single GPU; untimed, behind everything that is timed or checked): the symmetric kernel

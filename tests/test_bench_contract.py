@@ -340,3 +340,38 @@ def test_bench_eight_ranks_one_gpu_trial_over_every_peer_to_peer_form():
     assert set(cfg["exchange_trial_us_per_step"]) == {"p2p", "p2p+inkernel", "p2p+symmetric", "p2p+symmetric+push"}, (cfg, r.stderr[-2000:])
     assert cfg["exchange"] in cfg["exchange_trial_us_per_step"] and cfg["p2p_failure"] is None
     assert cfg["replicas_bit_identical_after_run"] is True and cfg["valid"] is True
+
+
+def test_the_exchange_trial_tries_the_overlap_structures_last_and_only_by_name():
+    """north_star's overlap structure (own-segment launch beside the previous all-gather) measures SLOWER than its plain form
+    in loopback (152 - 158 against 115 - 121 us per step: profiles/r06_shard_step_timeline.txt), so the trial of `bench.py --gpus N` holds it only
+    when asked for by name, and then BEHIND every other candidate.  The candidate list is host logic: checked here without a GPU, with the
+    peer-to-peer set-up succeeding on every rank."""
+    import types
+    sys.path.insert(0, ROOT)
+    from bench_ranks import Job
+
+    def names(gather, overlap, world=8, n=65536):
+        a = types.SimpleNamespace(bodies=n, dist_backend="gloo", gather=gather, overlap=overlap, p2p_timeout_ms=1000, seed=1, plan="")
+        fake = types.SimpleNamespace(FORCE_ALL_PAIRS=0, FORCE_CENTRAL_WELL=1)
+        job = Job(a, fake, None, None, 0, world, 0, 0, 0, 0)
+        job.c = types.SimpleNamespace(p2p_setup_torch=lambda: None, set_timeouts=lambda **k: None)
+        job.all_reduce = lambda value, op="MAX", dtype=None: value
+        return [c[0] for c in job.build_candidates()]
+    assert names("auto", False) == ["allgather", "sendrecv", "rccl+symmetric", "p2p", "p2p+symmetric", "p2p+symmetric+push"]
+    assert names("allgather", False) == ["allgather", "allgather+overlap"]
+    assert names("sendrecv", False) == ["sendrecv", "sendrecv+overlap"]
+    auto_overlap = names("auto", True)                     # --overlap: the overlap structures instead of their plain forms -- still behind everything else
+    assert auto_overlap[-2:] == ["allgather+overlap", "sendrecv+overlap"] and "allgather" not in auto_overlap and "p2p+symmetric+push" in auto_overlap
+    assert names("p2pall", False) == ["p2p", "p2p+inkernel", "p2p+symmetric", "p2p+symmetric+push"]
+    assert names("auto", False, world=8, n=65536 + 8 * 64) == ["allgather", "sendrecv", "p2p"]      # a slice that is not whole blocks: no symmetric forms
+
+
+def test_survey_8d_statistic_is_the_median_of_five_regions_of_at_least_100_steps():
+    """>= 100 timed steps per region, median of five repeats (bench_legs.survey_8d: what `config.survey_8d` carries whatever K is)."""
+    sys.path.insert(0, ROOT)
+    from bench_legs import survey_8d
+    s = survey_8d([0.60, 0.59, 0.61, 0.595, 0.592], 100, 65536.0 ** 2)
+    assert s["median_ms_per_step"] == 0.595 and s["min"] == 0.59 and s["max"] == 0.61 and s["repeats"] == 5 and s["meets_survey_8d"] is True
+    assert abs(s["interactions_per_s"] - 65536.0 ** 2 / 0.595e-3) < 1.0
+    assert survey_8d([0.6] * 5, 40, 1.0)["meets_survey_8d"] is False and survey_8d([0.6] * 3, 100, 1.0)["meets_survey_8d"] is False

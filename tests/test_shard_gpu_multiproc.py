@@ -297,6 +297,30 @@ def test_partially_active_sharded_step_against_the_oracle_and_its_order_matched_
     assert np.linalg.norm(got["vel"][:A].astype(np.float64) - vel[:A], axis=1).max() / 15.0 < 1e-6
 
 
+def test_partially_active_sharded_step_under_xcd_weights_against_its_order_matched_restatement(tmp_path, oracle):
+    """The same with XCD-WEIGHTED parts (a calibrated context: MAPN_FLAG_XCD_CALIBRATE; here a fixed lopsided set): the plan of a rank's blocks in
+    the ACTIVE ring takes the weights where they apply -- rank 0 runs 16 blocks of a 24-block ring (a multiple of 8: weighted), rank 1 eight of
+    them plus the one-sided launch over its 8192 frozen bodies -- another summation order, restated from the plans the ranks dump."""
+    from oracle import OracleSim, Params, step_sym_sharded_split
+    world, n, num_active, steps = 2, 32768, 24576, 2
+    got = _run_ranks(tmp_path, world, n, steps, "sympush", str(num_active), env={"MAPN_WORKER_XCD_W": "1024,900,1000,950,1024,880,990,1010"})
+    plans, frozen = _rank_split_plans(tmp_path, world)
+    assert plans[0].sets == 16 or plans[0].tables.size > plans[0].table_stride, "rank 0's 16 blocks must run XCD-weighted parts"
+    pos0, vel0 = oracle.initial_state(n, seed=1)
+    prm = Params(mass=70000.0 / n)
+    pos, vel = pos0, vel0
+    for _ in range(steps):
+        pos, vel = step_sym_sharded_split(oracle, pos, vel, prm, num_active, plans, frozen)
+    p = got["pos"]
+    rel = np.linalg.norm(p[:num_active, :3].astype(np.float64) - pos[:num_active, :3], axis=1) / np.maximum(np.linalg.norm(pos[:num_active, :3].astype(np.float64), axis=1), 1e-30)
+    same = float((p[:num_active, :3] == pos[:num_active, :3]).all(axis=1).mean())
+    print(f"weighted split plans: sets {[pl.sets for pl in plans if pl]}: vs the order-matched restatement after {steps} steps: max rel {rel.max():.2e}, bit-identical bodies {same:.5f}")
+    assert rel.max() <= 3e-7 and same >= 0.999
+    sim = OracleSim(oracle, pos0, vel0, params=prm); sim.simulate(num_active=num_active, steps=steps)
+    assert np.linalg.norm(p[:num_active, :3].astype(np.float64) - sim.latest[0][:num_active, :3], axis=1).max() / 400.0 < 3e-6
+    np.testing.assert_array_equal(p[num_active:], pos0[num_active:])
+
+
 @pytest.mark.parametrize("world,n", [(8, 65536), (4, 16384)])
 def test_the_slider_dragged_on_a_sharded_job_pushed_equals_pulled_and_follows_the_oracle(tmp_path, oracle, world, n):
     """num_active changing from step to step on P ranks (Particles.cpp:391-394's slider): all bodies (the sharded symmetric step), half (the

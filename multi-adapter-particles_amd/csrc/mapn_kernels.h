@@ -197,6 +197,8 @@ struct SymShardArgs {
     uint32_t      step;                       // monotonically increasing (>= 1): number of the reaction exchange
     uint32_t      pos_step;                   // number of this publication of new positions by a sharded symmetric step (0: they travel in another launch)
     uint32_t      pull_self;                  // loopback timing only: the "peers" are this rank, pull from every slot
+    uint32_t      wait_tail;                  // pushed positions, partially active step: this launch also WAITS (bounded) for the peers' pushes of this
+                                              // publication and checks them -- the rank's next launch (one-sided, over its frozen bodies) cannot
     uint32_t      pos_sums;                   // push form: word offset of the checksum rows [publication parity][sender][count / 32] in the flag arrays (0: none)
     uint32_t      corrupt_row;                // TEST HOOK (MAPN_TEST_HOOKS=1 MAPN_TEST_CORRUPT_ROW=<exchange>): one bit of ONE reaction row this launch sends
                                               // is flipped after its tag was formed -- the receiver must never accept it (bounded wait, then reported)

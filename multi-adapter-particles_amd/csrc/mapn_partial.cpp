@@ -409,7 +409,10 @@ int enqueue_sym_shard_split(mapn_ctx *c, const mapn::StepArgs &base, StepTimer *
     h.step = ++c->sym_shard_step;
     h.pos_step = ++c->sym_pos_epoch;
     c->step_pulled = true;
-    c->push_pending = push;
+    // a rank that owns frozen bodies starts its next partially active step with the one-sided launch, which cannot wait for the peers'
+    // pushes itself: this exchange launch waits for them (and checks them) at its tail -- nothing is pending behind it
+    h.wait_tail = push && (ro.fz_count || !ro.nbl) ? 1u : 0u;
+    c->push_pending = push && !h.wait_tail;
     c->push_active = A;
     h.pull_self = c->p2p_loopback ? 1u : 0u;
     h.timeout_ticks = c->p2p_timeout_ticks;

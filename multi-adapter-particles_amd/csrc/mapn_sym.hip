@@ -888,15 +888,27 @@ __global__ __launch_bounds__(256) void sym_shard_exchange_kernel(const SymShardA
         const uint32_t share = (uint32_t)(((uint64_t)SYM_COUNT_PER_LAUNCH * (bid + 1u)) / nblk) - (uint32_t)(((uint64_t)SYM_COUNT_PER_LAUNCH * bid) / nblk);
         if (threadIdx.x < p.world && (p.pull_self ? threadIdx.x == p.rank : threadIdx.x != p.rank))
             (void)__hip_atomic_fetch_add(p.flags_peer[threadIdx.x] + SYM_POS_BASE + p.rank, share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (p.push) { stamp(6); return; }                  // the peers' NEXT force launch waits for the counter; nothing to pull
+        // (pushed positions: the peers' NEXT force launch waits for the counter, nothing to pull -- unless that next launch cannot wait
+        //  itself: wait_tail, below)
+        if (p.push && !(PARTIAL && p.wait_tail)) { stamp(6); return; }
         const uint32_t q = threadIdx.x;
         const uint32_t all_good = wait_counters(p.flags_mine + SYM_POS_BASE, p.pull_self ? p.rank : q, q < p.world && q != p.rank, p.pos_step * SYM_COUNT_PER_LAUNCH,
                                                 p.timeout_ticks, p.status, 1u + q, p.flags_mine + SYM_DEAD_WORD);
         if (threadIdx.x == 0) ok = all_good;
     }
-    if (p.push) return;
+    if (p.push && !(PARTIAL && p.wait_tail)) return;
     __syncthreads();
     if (!ok) return;
+    if (PARTIAL && p.push) {
+        // WAIT TAIL (a partially active step on a rank that owns frozen bodies): its next launch is the ONE-SIDED one over its frozen bodies,
+        // which reads the peers' new positions and cannot wait for them itself -- until round 6's last day a separate wait launch in front of
+        // it (4.5 us per step of a frozen rank).  The wait moves HERE, to the tail of this step's exchange launch (every workgroup, like the
+        // pulled form; the dependency is the same, a launch less), together with the check of what the peers pushed: every wave its share.
+        if (p.pos_sums)
+            verify_pushed(p.pos_new, p.flags_mine + p.pos_sums, p.pos_step, p.count, p.world, p.rank, p.pull_self, bid * 4u + (threadIdx.x >> 6), nblk * 4u, threadIdx.x & 63u,
+                          p.status, p.flags_mine + SYM_DEAD_WORD, p.active);
+        return;
+    }
     // the peers' slices: 16 bytes per lane per access, eight in flight, past this GPU's caches (a line of q's buffer
     // cached here two steps ago must not be returned)
     const uint32_t others = (p.world - 1u) * p.count;

@@ -300,8 +300,9 @@ static void all_pairs_block_acc64(const ap_job *J, uint32_t b0, uint32_t nb)
     const float *pj = J->old_pos;
     for (uint32_t j = 0; j < J->n_total; j++, pj += 4) {
         const float xj = pj[0], yj = pj[1], zj = pj[2];
-        /* (two loops: the fp32 pair term at the full vector width, then the widening adds -- one mixed loop is vectorised at the
-         *  DOUBLE width throughout, the square root and the division included: 2.9 x the time of the reference-order leg, same bits) */
+        /* (two loops: the fp32 pair term at the full vector width, then the widening adds.  This leg costs 2.4 - 3 x the reference-order
+         *  one on the GPU box's host whichever way it is written -- one mixed loop, this form, vector-typed accumulators were all measured:
+         *  six conversions and six double adds per sixteen pairs beside one sqrt and one divide; same bits in every form) */
         float tx[IB], ty[IB], tz[IB];
 #pragma GCC ivdep
         for (int k = 0; k < IB; k++) {

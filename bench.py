@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--overlap", action="store_true", help="sharded mode: own-segment launch overlapped with the all-gather")
     ap.add_argument("--trial-seconds", type=float, default=90.0,
                     help="wall-time budget of the exchange trial (N > 1, --gather auto): once it is spent the candidates not yet tried are skipped")
+    ap.add_argument("--test-inject-trial-failure", action="store_true",
+                    help="testing only: rank 1 corrupts ONE pushed position while the exchange TRIAL steps 'p2p+symmetric+push': every rank must drop that form and go on")
     ap.add_argument("--test-inject-push-failure", action="store_true",
                     help="testing only: rank 1 corrupts ONE pushed position in the timed region (MAPN_TEST_HOOKS): the run must notice and fall back")
     ap.add_argument("--force-comm", action="store_true",
@@ -352,6 +354,7 @@ def main():
             dev_after = job.symmetric_deviation({"p2p+symmetric": 4, "p2p+symmetric+push": 5, "rccl+symmetric": 6}[gather_algo])
             sym_dev_after = reduce_max(dev_after)[0]
             consistent = sym_dev_after < 1e-5 and c.p2p_status() == 0
+            sym_dev_after = sym_dev_after if sym_dev_after != float("inf") else None      # (a rank's library failed in the check: not a JSON number)
         if not consistent and rank == 0:
             print("[bench] WARNING: position replicas differ across ranks after the run (or the sharded symmetric step "
                   "failed its check) -- the exchange misbehaved; this result is INVALID", file=sys.stderr, flush=True)
@@ -368,7 +371,8 @@ def main():
         def regions(k, how_many):
             out = []
             for _ in range(how_many):
-                job.sync()
+                if job.together(job.idle):
+                    break
                 t0 = time.perf_counter()
                 if run_steps(job, k, recoverable, closing):
                     break

@@ -76,6 +76,10 @@ def make_torch_gather(c, torch, dist, n, rank, world):
 
 
 
+class RankFailure(RuntimeError):
+    """A failure the ranks have agreed on (Job.together): raised on every rank of the job at the same point."""
+
+
 class Job:
     """One rank's side of a bench run: the context (replaced when a device-side check leaves it failed), the process group, and -- N > 1 --
     every decision the ranks take together: which exchange structure runs (exchange_trial), whether the die weights stay (sharded_xcd_ab),
@@ -114,13 +118,47 @@ class Job:
         if self.gather_fn:
             self.gather_fn()
 
-    def sync(self):
+    def idle(self):
+        """This rank's device idle.  NO collective in it."""
         self.c.WaitForGpu()
         if self.torch is not None:
             self.torch.cuda.synchronize()
+
+    def run_idle(self, k):
+        for _ in range(k):
+            self.step()
+        self.idle()
+
+    def sync(self):
+        """idle + barrier.  The barrier is taken even when this rank's wait reports a failure (raised behind it): the peers are in it."""
+        err = None
+        try:
+            self.idle()
+        except self.mapn.MapnError as e:
+            err = e
         if self.dist is not None:
             self.dist.barrier()
             self.torch.cuda.synchronize()
+        if err is not None:
+            raise err
+
+    def together(self, fn):
+        """fn() on every rank -- no collective inside it -- then ONE collective that is barrier and verdict: the failure's text on EVERY rank
+        when any rank's library reported one, else None.  Whatever the ranks decide from the result they decide alike, so a check that fails
+        on one rank (a pushed position against its checksum, a row that never validated, a wait that gave up) can never leave the others in
+        a collective that rank does not take part in."""
+        err = None
+        try:
+            fn()
+        except self.mapn.MapnError as e:
+            err = str(e) or "failed"
+        if self.dist is None:
+            return err
+        if not self.all_reduce(1 if err else 0):
+            return None
+        texts = [None] * self.world
+        self.dist.all_gather_object(texts, err)                # (only on the failure path; every rank takes it)
+        return next(f"rank {r}: {t}" for r, t in enumerate(texts) if t)
 
     def rebuild(self, with_p2p):
         """A context whose device-side wait timed out or whose row / position check failed stays failed: replace it (collective: all ranks)."""
@@ -193,17 +231,19 @@ class Job:
         import numpy as np
         c, got = self.c, []
         for algo in ((0 if sym_algo == 6 else 2), sym_algo):
-            self.sync()
-            c.set_gather_algorithm(algo)
-            pos0, vel0 = self.mapn.generate_initial_state(self.n, seed=self.a.seed)
-            c.upload_state(pos0, vel0)
-            self.sync()
-            for _ in range(4):
-                self.step()
+            def fresh():
+                c.set_gather_algorithm(algo)
+                pos0, vel0 = self.mapn.generate_initial_state(self.n, seed=self.a.seed)
+                c.upload_state(pos0, vel0)
+                self.idle()
             # ALL ranks must have finished before anyone re-initialises: a rank that is a step ahead would overwrite the
-            # buffers a slower peer is still pulling from / pushing into (seen with 8 ranks time-slicing one device)
-            self.sync()
-            got.append(c.download_state()[0][:, :3].astype(np.float64))
+            # buffers a slower peer is still pulling from / pushing into (seen with 8 ranks time-slicing one device): every stage
+            # ends in `together`'s collective.  A failure on any rank: infinity on all of them (the caller's check fails, nobody hangs).
+            def four():
+                self.run_idle(4)
+                got.append(c.download_state()[0][:, :3].astype(np.float64))
+            if self.together(self.idle) or self.together(fresh) or self.together(four):
+                return float("inf")
         return float(np.linalg.norm(got[0] - got[1], axis=1).max() / 400.0)
 
     def reinit(self):
@@ -284,25 +324,27 @@ class Job:
                     if self.rank == 0:
                         print(f"[bench] exchange trial: budget of {a.trial_seconds:.0f} s spent -> '{name}' not tried", file=sys.stderr, flush=True)
                     continue
-                failed = None
-                try:
+                # every stage is `together`: its collective is the barrier (the device-side waits are bounded -- --p2p-timeout-ms -- so the ranks
+                # start together) AND carries a failure of any rank to all of them
+                def choose():
                     self.c.set_gather_algorithm(algo)
                     self.c.set_shard_overlap(overlap)
-                    dist.barrier()                          # the device-side waits are bounded (--p2p-timeout-ms): start together
-                    for _ in range(5):
-                        self.step()
-                    self.sync()
+                inject = a.test_inject_trial_failure and algo == 5 and self.rank == 1
+                if inject:
+                    os.environ["MAPN_TEST_HOOKS"] = "1"; os.environ["MAPN_TEST_CORRUPT_PUSH"] = "once"
+                failed = self.together(choose) or self.together(lambda: self.run_idle(5))
+                dt_trial = float("inf")
+                if not failed:
                     t0 = time.perf_counter()
-                    for _ in range(30):
-                        self.step()
-                    self.sync()
+                    failed = self.together(lambda: self.run_idle(30))
                     dt_trial = time.perf_counter() - t0
-                except mapn.MapnError as e:
-                    failed, dt_trial = str(e), float("inf")
-                bad = self.all_reduce(1 if failed else 0)
+                if inject:
+                    os.environ.pop("MAPN_TEST_HOOKS", None); os.environ.pop("MAPN_TEST_CORRUPT_PUSH", None)
+                bad = bool(failed)
                 if not bad and algo >= 2:
-                    bad = self.all_reduce(0 if (self.c.p2p_status() == 0 and self.replicas_consistent()) else 1)
-                    if bad and not failed:
+                    same = self.replicas_consistent()           # (a collective: before the status word is looked at, on every rank)
+                    bad = self.all_reduce(0 if (self.c.p2p_status() == 0 and same) else 1)
+                    if bad:
                         failed = "replicas differ across ranks"
                 if not bad and algo in (4, 5, 6):
                     # identical replicas do not show that the reactions ARRIVED: compare four steps from the
@@ -366,27 +408,33 @@ class Job:
         a, c, mapn, n, world = self.a, self.c, self.mapn, self.n, self.world
         try:
             def burst_all(k):
-                self.sync(); t0 = time.perf_counter()
-                for _ in range(k):
-                    self.step()
-                self.sync()
+                err = self.together(self.idle)
+                t0 = time.perf_counter()
+                err = err or self.together(lambda: self.run_idle(k))
+                if err:
+                    raise RankFailure(err)                  # (on EVERY rank: `together`)
                 return float(self.all_reduce(time.perf_counter() - t0, dtype=self.torch.float64)) / k
+
+            def all_set(w):
+                err = self.together(lambda: c.set_sym_xcd_weights(w))
+                if err:
+                    raise RankFailure(err)
             kk = max(20, min(400, int(0.05 / (0.1e-3 * (n / 65536.0) ** 2 * 8 / world))))
             pl = c.sym_plan()
             w = list(pl.xcd_weight)
             if self.all_reduce(1 if pl.xcd_mode != 0 else 0, "MIN"):            # all ranks or none
                 t_w = min(burst_all(kk), burst_all(kk))
-                c.set_sym_xcd_weights(None)
+                all_set(None)
                 t_def = min(burst_all(kk), burst_all(kk))
                 xcd.update({"weights": w, "source": "library (MAPN_FLAG_XCD_CALIBRATE: a temporary unsharded context on every rank's GPU; rank 0's weights shown)",
                             "form": {1: "spread", 2: "class-aware"}.get(pl.xcd_mode), "trial_ms": {"default": t_def * 1e3, "weighted": t_w * 1e3}})
                 if a.xcd == "on" or t_w < t_def * 0.998:
-                    c.set_sym_xcd_weights(w)
+                    all_set(w)
                     xcd["used"] = c.sym_plan().xcd_mode != 0
             else:
                 xcd["note"] = "the library's calibration did not apply on every rank (a rank's share must be a multiple of 8 blocks)"
                 c.set_sym_xcd_weights(None)
-        except mapn.MapnError as e:                            # (a failure here leaves the default plan: the run goes on)
+        except (mapn.MapnError, RankFailure) as e:            # (a failure here leaves the default plan: the run goes on)
             xcd["error"] = str(e)[:200]
             try:
                 c.set_sym_xcd_weights(None)

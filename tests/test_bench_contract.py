@@ -321,6 +321,25 @@ def test_bench_falls_back_once_when_a_verified_form_fails_in_the_run_itself():
 
 
 @pytest.mark.gpu
+def test_a_form_that_fails_on_one_rank_during_the_trial_is_dropped_by_all_of_them():
+    """The exchange TRIAL is where a cross-GPU form meets real links for the first time.  Here rank 1 corrupts ONE pushed position while
+    'p2p+symmetric+push' is being tried (test hook): rank 0's library reports it, rank 1's own steps may or may not -- every stage of the
+    trial ends in one collective that carries the failure to all ranks (Job.together), so both drop that form, replace their contexts, and
+    the run goes on with what else was verified: nobody is left in a barrier the other rank skipped."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "3", "--gather", "p2pall",
+                        "--dist-backend", "gloo", "--same-device", "--no-survey-leg", "--prewarm-ms", "20", "--bodies", "16384", "--test-inject-trial-failure",
+                        "--p2p-timeout-ms", "3000", "--xcd", "off"], capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    cfg = json.loads(lines[0])["config"]
+    assert "p2p+symmetric+push" not in cfg["exchange_trial_us_per_step"] and "p2p+symmetric" in cfg["exchange_trial_us_per_step"], cfg
+    assert "p2p+symmetric+push" in cfg["p2p_failure"], cfg["p2p_failure"]
+    assert cfg["exchange"] in cfg["exchange_trial_us_per_step"] and cfg["fallback_after_failure"] is None
+    assert cfg["replicas_bit_identical_after_run"] is True and cfg["valid"] is True
+
+
+@pytest.mark.gpu
 @pytest.mark.slow
 def test_bench_eight_ranks_one_gpu_trial_over_every_peer_to_peer_form():
     """The exchange TRIAL of bench.py as the driver's 8-GPU run goes through it, with eight ranks sharing device 0 (gloo
@@ -375,3 +394,85 @@ def test_survey_8d_statistic_is_the_median_of_five_regions_of_at_least_100_steps
     assert s["median_ms_per_step"] == 0.595 and s["min"] == 0.59 and s["max"] == 0.61 and s["repeats"] == 5 and s["meets_survey_8d"] is True
     assert abs(s["interactions_per_s"] - 65536.0 ** 2 / 0.595e-3) < 1.0
     assert survey_8d([0.6] * 5, 40, 1.0)["meets_survey_8d"] is False and survey_8d([0.6] * 3, 100, 1.0)["meets_survey_8d"] is False
+
+
+class _FakeMapnError(RuntimeError):
+    pass
+
+
+def _trial_worker(rank, world, port, out_dir, fail_where):
+    """One rank of bench_ranks.Job.exchange_trial over gloo with a FAKE library: the algorithm under test fails on rank 1 only."""
+    import types
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from bench_ranks import Job
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 16384
+    made = []
+
+    class FakeCompute:
+        def __init__(self):
+            self.algo, self.steps, self.failed, self.weights = 0, 0, False, [1.0] * 8
+            made.append(self)
+        def set_gather_algorithm(self, algo): self.algo = algo
+        def set_shard_overlap(self, on): pass
+        def GetFenceValue(self): return self.steps
+        def Simulate(self, n_active, fence):
+            self.steps += 1
+            if fail_where == "ab" and rank == 1 and self.weights is None and self.steps > 400:
+                raise _FakeMapnError("mapn status 7: a reaction row never validated")
+            if self.algo == 5 and rank == 1 and fail_where == "simulate":
+                self.failed = True
+                raise _FakeMapnError("mapn status 7: a PUSHED position did not match its checksum")
+        def WaitForGpu(self):
+            if self.algo == 5 and rank == 1 and fail_where == "wait":
+                self.failed = True
+                raise _FakeMapnError("mapn status 7: a device-side wait gave up")
+        def p2p_status(self): return 1 if self.failed else 0
+        def replica_checksum(self): return (1, 2)
+        def upload_state(self, pos, vel): pass
+        def download_state(self): return np.zeros((n, 4), np.float32), None
+        def close(self): pass
+        def p2p_setup_torch(self): dist.barrier()            # (the real one is a collective too)
+        def comm_init_torch(self): dist.barrier()
+        def set_timeouts(self, **k): pass
+        def set_timers(self, k): pass
+        def sym_plan(self): return types.SimpleNamespace(xcd_mode=2 if self.weights else 0, xcd_weight=self.weights or [1.0] * 8)
+        def set_sym_xcd_weights(self, w): self.weights = w
+
+    fake = types.SimpleNamespace(FORCE_ALL_PAIRS=0, MapnError=_FakeMapnError, Compute=lambda *a, **k: FakeCompute(),
+                                 generate_initial_state=lambda n, seed: (None, None))
+    fake_torch = types.SimpleNamespace(cuda=types.SimpleNamespace(synchronize=lambda: None), tensor=torch.tensor, float64=torch.float64)
+    a = types.SimpleNamespace(bodies=n, dist_backend="gloo", gather="p2pall", overlap=False, p2p_timeout_ms=1000, seed=1, plan="",
+                              trial_seconds=60.0, test_inject_trial_failure=False, xcd="auto")
+    job = Job(a, fake, fake_torch, dist, rank, world, 0, 0, 0, 0)
+    job.create()
+    job.exchange_trial()
+    xcd = {}
+    if fail_where == "ab":
+        job.sharded_xcd_ab(xcd)
+    json.dump({"trial": sorted(job.trial), "chosen": job.gather_algo, "p2p_failure": job.p2p_failure, "contexts": len(made), "xcd": xcd},
+              open(os.path.join(out_dir, f"trial_rank{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_where", ["simulate", "wait", "ab"])
+def test_the_exchange_trial_stays_in_lockstep_when_one_rank_alone_fails(tmp_path, fail_where):
+    """bench_ranks.Job.exchange_trial over a real two-rank gloo group and a fake library (no GPU): 'p2p+symmetric+push' fails on rank 1 ONLY -- in
+    `Simulate` or in the wait behind the steps -- while rank 0's library reports nothing.  Every stage of the trial ends in one collective that
+    carries the failure (Job.together), so both ranks drop the form, both replace their context, both end with the same table and choice; before
+    round 6's last change rank 0 sat in a barrier rank 1 had skipped."""
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000) + {"simulate": 0, "wait": 7, "ab": 14}[fail_where]
+    mp.spawn(_trial_worker, args=(2, port, str(tmp_path), fail_where), nprocs=2, join=True)
+    got = [json.load(open(os.path.join(str(tmp_path), f"trial_rank{r}.json"))) for r in range(2)]
+    assert got[0] == got[1], got
+    if fail_where == "ab":                 # the untimed A/B of the die weights behind the trial: rank 1 fails in the unweighted bursts
+        assert len(got[0]["trial"]) == 4 and "rank 1: mapn status 7" in got[0]["xcd"]["error"], got[0]
+        return
+    assert got[0]["trial"] == ["p2p", "p2p+inkernel", "p2p+symmetric"] and got[0]["chosen"] in got[0]["trial"]
+    assert "rank 1: mapn status 7" in got[0]["p2p_failure"] and "p2p+symmetric+push" in got[0]["p2p_failure"] and got[0]["contexts"] == 2

@@ -249,9 +249,9 @@ def main():
             # steps -- a fixed count (about prewarm_ms at the single-GPU step time / world)
             prewarm_steps = max(16, int(a.prewarm_ms * 1e-3 / (0.9e-3 / world * (n / 65536.0) ** 2)) // 16 * 16)
             prewarm_steps = min(prewarm_steps, 4096)
-            for _ in range(prewarm_steps):
-                job.step()
-            job.c.WaitForGpu()
+            fail = job.together(lambda: job.run_idle(prewarm_steps))
+            if fail:                                           # (a verified form failing here: the next verified one takes over, as in the timed run)
+                job.fall_back(fail)
     # XCD-aware parts (symmetric kernel): the eight dies do not run at one speed and a launch gives each the same work.
     # Untimed: the library has calibrated; an A/B of the weighted plan against the default one decides -- the weights stay only if they win.
     xcd = {"mode": a.xcd, "weights": None, "used": False, "source": None}
@@ -299,9 +299,9 @@ def main():
         # four behind it, same run).  A short untimed ramp, as in front of the A/B: the W warm-up steps and the K timed ones follow it.
         per_step_s = min(xcd["trial_ms"].values()) * 1e-3     # (150 ms of steps, whatever the size: a 4 Mi-body step is 2.5 s)
         ramp = max(4, min(256, int(0.15 / per_step_s))) if dist is None else max(16, prewarm_steps // 4)
-        for _ in range(ramp):
-            job.step()
-        job.c.WaitForGpu()
+        fail = job.together(lambda: job.run_idle(ramp))
+        if fail:
+            job.fall_back(fail); xcd["used"] = False           # (N = 1: nothing to fall back to -- it exits with the library's text)
         prewarm_steps += ramp
     closing = job.closing_collective()                     # its tensors and events: made here, before any timed region (run_steps)
 

@@ -177,11 +177,14 @@ class Job:
         a = self.a
         self.transport = a.transport
         if self.transport == "rccl" and a.gather not in self.P2P_ONLY:
+            ok = 1
             try:
                 self.c.comm_init_torch()
             except Exception as e:     # RCCL-in-library unavailable: use torch's RCCL instead, loudly
                 print(f"[bench rank {self.rank}] native RCCL transport failed ({e}); falling back to torch.distributed all-gather",
                       file=sys.stderr, flush=True)
+                ok = 0
+            if not self.all_reduce(ok, "MIN"):                 # all ranks or none
                 self.transport = "torch"
         if self.transport == "torch":
             self.c.set_external_gather(True)

@@ -205,8 +205,17 @@ class Compute:
         """Rendezvous through an already-initialised torch.distributed group: rank 0 creates the
         RCCL unique id, everybody receives it, then all ranks join the communicator."""
         import torch.distributed as dist
-        ids = [self.comm_unique_id() if dist.get_rank() == 0 else None]
+        ids, err = [None], None
+        if dist.get_rank() == 0:
+            try:
+                ids = [self.comm_unique_id()]
+            except MapnError as e:                 # (the peers are in the broadcast below: send them the verdict, then report)
+                err = e
         dist.broadcast_object_list(ids, src=0)
+        if err is not None:
+            raise err
+        if ids[0] is None:
+            raise MapnError(-4, "rank 0 could not create the RCCL unique id")      # (MAPN_ERR_COMM)
         self.comm_init(ids[0])
 
     def set_gather_algorithm(self, algorithm: int):
@@ -230,7 +239,17 @@ class Compute:
         and map every peer's buffers; afterwards set_gather_algorithm(2) selects the exchange."""
         import torch.distributed as dist
         blobs = [None] * dist.get_world_size()
-        dist.all_gather_object(blobs, self.p2p_export())
+        mine, err = None, None
+        try:
+            mine = self.p2p_export()
+        except MapnError as e:                     # (the peers are in the collective below: take part in it, then report)
+            err = e
+        dist.all_gather_object(blobs, mine)
+        if err is not None:
+            raise err
+        missing = [r for r, b in enumerate(blobs) if b is None]
+        if missing:
+            raise MapnError(-4, f"peer-to-peer set-up: rank(s) {missing} could not export their buffers")      # (MAPN_ERR_COMM)
         self.p2p_import(blobs)
 
     def p2p_status(self) -> int:

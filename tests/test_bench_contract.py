@@ -476,3 +476,46 @@ def test_the_exchange_trial_stays_in_lockstep_when_one_rank_alone_fails(tmp_path
         return
     assert got[0]["trial"] == ["p2p", "p2p+inkernel", "p2p+symmetric"] and got[0]["chosen"] in got[0]["trial"]
     assert "rank 1: mapn status 7" in got[0]["p2p_failure"] and "p2p+symmetric+push" in got[0]["p2p_failure"] and got[0]["contexts"] == 2
+
+
+def _setup_worker(rank, world, port, out_dir):
+    """mapn.compute.Compute.p2p_setup_torch / comm_init_torch over gloo with the library calls stubbed: rank 1 cannot export, rank 0 cannot make the id."""
+    import types
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "multi-adapter-particles_amd"))
+    sys.path.insert(0, ROOT)
+    from mapn.compute import Compute, MapnError
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    got = {}
+
+    def export():
+        if rank == 1:
+            raise MapnError(-2, "hipIpcGetMemHandle: invalid argument")
+        return b"x" * 8
+
+    def make_id():
+        raise MapnError(-4, "librccl.so not found")
+    stub = types.SimpleNamespace(p2p_export=export, p2p_import=lambda blobs: got.setdefault("imported", True),
+                                 comm_unique_id=make_id, comm_init=lambda uid: got.setdefault("joined", True))
+    for name, fn in (("p2p", Compute.p2p_setup_torch), ("comm", Compute.comm_init_torch)):
+        try:
+            fn(stub)
+            got[name] = "ok"
+        except MapnError as e:
+            got[name] = str(e)
+    json.dump(got, open(os.path.join(out_dir, f"setup_rank{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_rank_that_cannot_set_up_its_transport_still_takes_part_in_the_rendezvous(tmp_path):
+    """The two set-up rendezvous of the N > 1 run (hipIpc blobs: all_gather_object; RCCL unique id: broadcast) with ONE rank's library call
+    failing in front of the collective: that rank takes part in it anyway and every rank gets a MapnError -- nobody maps half a job, nobody
+    waits for a blob that never comes (a two-rank gloo group, the library calls stubbed: no GPU)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_setup_worker, args=(2, 29500 + (os.getpid() % 2000) + 21, str(tmp_path)), nprocs=2, join=True)
+    got = [json.load(open(os.path.join(str(tmp_path), f"setup_rank{r}.json"))) for r in range(2)]
+    assert "hipIpcGetMemHandle" in got[1]["p2p"] and "rank(s) [1] could not export" in got[0]["p2p"], got
+    assert "librccl.so not found" in got[0]["comm"] and "rank 0 could not create the RCCL unique id" in got[1]["comm"], got
+    assert not any("imported" in g or "joined" in g for g in got)

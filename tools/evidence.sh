@@ -25,6 +25,8 @@
 #                                (gloo) and one rank over the RCCL backend -> closing_cost.txt
 #   partial                      partially active steps: one-sided / full symmetric / split form over a sweep of num_active (tools/partial_sweep.py)
 #   partialstats [N ACTIVE]      rocprofv3 --kernel-trace --stats of 2000 half-active steps in the split form: the three launches' durations
+#   rankfail                     eight real processes on one GPU (gloo): rank 1 corrupts one pushed position (a) while the exchange TRIAL steps that form, (b) in
+#                                the timed region -- what every rank decides, in bench.py's own words -> rank_failure_8_ranks.txt
 #   power                        rocm-smi package power / shader clock / temperature while each force kernel runs flat out for 14 s (tools/power_probe.sh)
 set -u
 R=$PWD; W=${1:-suite}; shift || true
@@ -65,6 +67,16 @@ PY
   n=${1:-65536}; na=${2:-32768}; cd /tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/pstats -- python3 /tmp/partial_steps.py $n $na 2000 > /dev/null 2> $O/pstats.err
   cd $R; f=$(ls -t $(find $O/pstats -name "*kernel_stats.csv") | head -1); cp $f $O/partial_kernel_stats.csv; head -6 $f; rm -rf $O/pstats ;;
+rankfail)
+  show() { python -c "import sys,json; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); c=d['config']; print('  ->', 'exchange', c['exchange'], '| trial us/step', {k: round(v, 1) for k, v in c['exchange_trial_us_per_step'].items()}, '| p2p_failure:', c['p2p_failure'], '| fallback_after_failure:', c['fallback_after_failure'], '| replicas bit-identical after the run:', c['replicas_bit_identical_after_run'], '| valid:', c['valid'], '| ms/step %.4f' % d['ms_per_step'])"; }
+  : > $O/rank_failure_8_ranks.txt
+  for inj in --test-inject-trial-failure --test-inject-push-failure; do
+    [ $inj = --test-inject-trial-failure ] && G=p2pall || G=sympush        # (b): the pushed form asked for by name, so that it is the one the timed region runs
+    echo "== bench.py --gpus 8 --gather $G $inj (8 processes sharing one GPU, gloo rendezvous, 65536 bodies)" | tee -a $O/rank_failure_8_ranks.txt
+    timeout 600 python bench.py --gpus 8 --steps 40 --warmup 5 --gather $G --dist-backend gloo --same-device --no-survey-leg --prewarm-ms 20 --bodies 65536 \
+        --p2p-timeout-ms 5000 --xcd off $inj 2> $O/rankfail$inj.err | show | tee -a $O/rank_failure_8_ranks.txt
+    grep "^\[bench\]" $O/rankfail$inj.err | cut -c1-400 | sed 's/^/  /' | tee -a $O/rank_failure_8_ranks.txt
+  done ;;
 power)
   bash tools/power_probe.sh > $O/power_probe.txt 2>&1; cat $O/power_probe.txt ;;
 bench)

@@ -354,6 +354,62 @@ def test_xcd_calibration_flag_on_a_sharded_context_plans_the_ranks_launch_with_i
             assert c.sym_plan().xcd_mode == want_mode
 
 
+def test_one_context_goes_through_every_exchange_form_in_the_order_of_the_auto_trial(monkeypatch):
+    """`bench.py --gpus 8` (--gather auto) takes ONE context per rank through every exchange form in turn -- RCCL all-gather, grouped
+    send / recv, the sharded symmetric step over RCCL, then the peer-to-peer pull, the sharded symmetric step with pulled and with pushed
+    positions -- and between them toggles back to the one-sided form from a re-uploaded state (the symmetric check).  No test with several
+    processes can run that sequence on a 1-GPU box (RCCL refuses several ranks on one device), so here rank 0 of an 8-way job runs it
+    ALONE: a real one-rank RCCL communicator (MAPN_COMM_LOOPBACK), every peer's memory mapped to its own (MAPN_P2P_LOOPBACK).  The
+    numbers mean nothing (nobody answers); what is checked is that every switch leaves a context that steps, drains, reports status 0
+    and checksums its replicas: counters, epochs, tickets, scratch given back and made again, across RCCL and peer-to-peer forms, all-active
+    and partially active steps."""
+    for k, v in (("MAPN_TEST_HOOKS", "1"), ("MAPN_P2P_LOOPBACK", "1"), ("MAPN_COMM_LOOPBACK", "1"), ("MAPN_XCD_VERIFY", "0")):
+        monkeypatch.setenv(k, v)
+    n, world = 65536, 8
+    pos0, vel0 = mapn.generate_initial_state(n, seed=1)
+    with mapn.Compute(n, mass=70000.0 / n, rank=0, world_size=world, flags=mapn.FLAG_XCD_CALIBRATE) as c:
+        c.comm_init(mapn.Compute.comm_unique_id())
+        blob = c.p2p_export()
+        c.p2p_import([blob] * world)
+        c.set_timeouts(p2p_ms=1000)
+
+        def run(k, num_active=None):
+            draw(c, k, num_active)
+            c.WaitForGpu()
+            assert c.p2p_status() == 0
+            sums = c.replica_checksum()
+            p, _ = c.download_state()
+            assert np.isfinite(p).all() and len(sums) == 2
+
+        def symmetric_check(base, sym):                        # bench_ranks.Job.symmetric_deviation's sequence
+            for algo in (base, sym):
+                c.WaitForGpu()
+                c.set_gather_algorithm(algo)
+                c.upload_state(pos0, vel0)
+                run(4)
+        for algo, overlap in ((0, False), (1, False), (6, False), (2, False), (4, False), (5, False), (0, True), (1, True)):
+            c.set_gather_algorithm(algo)
+            c.set_shard_overlap(overlap)
+            run(35)
+            want = "force_sym_kernel" if algo >= 4 else "force_sgpr_kernel"
+            assert c.kernel_stats().kernel_name.decode().startswith(want), (algo, c.kernel_stats().kernel_name)
+            if algo in (4, 5, 6):
+                symmetric_check(0 if algo == 6 else 2, algo)
+        # the form that is kept: the die-weight A/B, then the reference's slider on it (partially active steps in their sharded split form,
+        # a count below the split form's floor -> the one-sided step, all bodies again), then an RCCL form once more
+        c.set_shard_overlap(False)
+        c.set_gather_algorithm(5)
+        run(20)
+        c.set_sym_xcd_weights(None)
+        run(20)
+        for active in (n // 2, 5 * n // 8, n, 1000, n, n // 2 + 64, n):
+            run(5, active)
+        for algo in (6, 4, 0):
+            c.set_gather_algorithm(algo)
+            run(10)
+            run(3, n // 2)
+
+
 def _loopback_expectation(pos, vel, nb, nbl, mass, soft2, dt):
     """What rank 0 of a sharded job computes when no peer ever answers (float64): its blocks meet what the schedule says; its
     bodies get the forces of those meetings plus the reactions of meetings between two of its own blocks."""

@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed clock-ramp phase before the W warm-up steps (the chip needs a few hundred ms of "
                          "load to settle its clock; 0 disables)")
-    ap.add_argument("--p2p-timeout-ms", type=int, default=1000,
+    ap.add_argument("--p2p-timeout-ms", type=int, default=3000,
                     help="bound of the device-side waits of the peer-to-peer forms (raise it when ranks time-slice one device in tests)")
     ap.add_argument("--xcd", choices=["auto", "off", "on"], default="auto",
                     help="XCD-aware parts of the symmetric kernel (1 GPU): calibrate the dies' speeds during the untimed prewarm and size "

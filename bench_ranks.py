@@ -332,10 +332,17 @@ class Job:
                 def choose():
                     self.c.set_gather_algorithm(algo)
                     self.c.set_shard_overlap(overlap)
+                    if is_p2p:                               # a form's FIRST launches load code objects and touch lazily mapped peer memory
+                        self.c.set_timeouts(p2p_ms=max(10000, a.p2p_timeout_ms))     # for the first time: a generous bound for those ...
+
+                def first_steps():
+                    self.run_idle(5)
+                    if is_p2p:
+                        self.c.set_timeouts(p2p_ms=a.p2p_timeout_ms)                 # ... the bound asked for from then on
                 inject = a.test_inject_trial_failure and algo == 5 and self.rank == 1
                 if inject:
                     os.environ["MAPN_TEST_HOOKS"] = "1"; os.environ["MAPN_TEST_CORRUPT_PUSH"] = "once"
-                failed = self.together(choose) or self.together(lambda: self.run_idle(5))
+                failed = self.together(choose) or self.together(first_steps)
                 dt_trial = float("inf")
                 if not failed:
                     t0 = time.perf_counter()
